@@ -1,0 +1,235 @@
+/*
+ * oracle.h -- CPU restatement of the Arrow IPC <-> DuckDB-vector hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only as
+ * the checker / the timed CPU baseline.  The product (duckdb-arrow_amd/csrc) has its own host
+ * parser and its own HIP kernels and never links or calls this code.
+ *
+ * What is restated and from where (all paths relative to /root/reference):
+ *   framing      src/ipc/stream_reader/ipc_file_stream_reader.cpp:96-141   (prefix, magic skip, align)
+ *                src/ipc/stream_reader/base_stream_reader.cpp:214-236      (metadata size, header, body)
+ *                src/ipc/stream_reader/ipc_buffer_stream_reader.cpp:12-69  (caller-owned buffers)
+ *   metadata     apache/arrow-nanoarrow@4bf5a932 (CMakeLists.txt:7-13, not vendored): the published
+ *                Arrow columnar format, Message.fbs / Schema.fbs / File.fbs flatbuffer tables
+ *   transcode    duckdb/duckdb (.gitmodules:1-4, submodule empty; v1.2.1 / v1.3): ArrowToDuckDB,
+ *                ColumnArrowToDuckDB, GetValidityMask, SetVectorString, ArrowAppender -- restated from
+ *                the published behaviour summarised in SURVEY.md Appendix C.  Call sites in the
+ *                reference: src/scanner/scan_arrow_ipc.cpp:56, src/file_scanner/arrow_file_scan.cpp:68-72,
+ *                src/writer/column_data_collection_serializer.cpp:80-95, src/writer/to_arrow_ipc.cpp:134-141
+ *
+ * Parity pinning: the reference itself cannot be built here (DuckDB + nanoarrow absent), so this oracle is
+ * pinned LOGICALLY against pyarrow (the oracle of the reference's own python tests,
+ * test/python/test_integration.py:32-61) on the reference's own data files (data/test.arrows, data/fruit.arrow,
+ * data/multifile/..., data/parquet-testing/lineitem_sf0_01.parquet) and the known answers of test/sql/ *.test.
+ * The byte layout of DuckDB vectors (string_t, validity_t, hugeint_t) has no fixture in the reference:
+ * "layout parity unpinned"; dictionary decode (K5) and filter->selection (K6) are beyond the reference:
+ * "parity unpinned" (SURVEY.md section 8c).
+ */
+#ifndef MI_ORACLE_H
+#define MI_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_VECTOR_SIZE 2048 /* STANDARD_VECTOR_SIZE, src/writer/to_arrow_ipc.cpp:21 */
+
+/* ---- status codes (errno-style like the C stream boundary, src/include/ipc/array_stream.hpp:29-48) ---- */
+#define ORC_OK 0
+#define ORC_EIO 5
+#define ORC_EINVAL 22
+#define ORC_ENODATA 61
+#define ORC_ENOTSUP 95
+
+/* ---- message types (nanoarrow ArrowIpcMessageType; Message.fbs MessageHeader union) ---- */
+#define ORC_MSG_UNINITIALIZED 0
+#define ORC_MSG_SCHEMA 1
+#define ORC_MSG_DICTIONARY_BATCH 2
+#define ORC_MSG_RECORD_BATCH 3
+
+/* ---- Arrow type ids = Schema.fbs `Type` union tags ---- */
+enum {
+  ORC_T_NONE = 0, ORC_T_NULL = 1, ORC_T_INT = 2, ORC_T_FLOAT = 3, ORC_T_BINARY = 4, ORC_T_UTF8 = 5,
+  ORC_T_BOOL = 6, ORC_T_DECIMAL = 7, ORC_T_DATE = 8, ORC_T_TIME = 9, ORC_T_TIMESTAMP = 10,
+  ORC_T_INTERVAL = 11, ORC_T_LIST = 12, ORC_T_STRUCT = 13, ORC_T_UNION = 14, ORC_T_FIXED_BINARY = 15,
+  ORC_T_FIXED_LIST = 16, ORC_T_MAP = 17, ORC_T_DURATION = 18, ORC_T_LARGE_BINARY = 19,
+  ORC_T_LARGE_UTF8 = 20, ORC_T_LARGE_LIST = 21, ORC_T_RUN_END = 22, ORC_T_BINARY_VIEW = 23,
+  ORC_T_UTF8_VIEW = 24
+};
+
+typedef struct {
+  int32_t type;       /* ORC_MSG_* */
+  int32_t meta_len;   /* metadata_size from the prefix (padded flatbuffer length) */
+  int64_t prefix_off; /* offset of the 8-byte prefix */
+  int64_t meta_off;   /* offset of the flatbuffer */
+  int64_t body_off;   /* offset of the body (8-byte aligned) */
+  int64_t body_len;   /* Message.bodyLength */
+} orc_msg;
+
+typedef struct {
+  char name[128];
+  char tz[64];
+  int32_t type;         /* ORC_T_* */
+  int32_t bit_width;    /* Int / Decimal / Time */
+  int32_t is_signed;    /* Int */
+  int32_t precision;    /* Decimal precision or FloatingPoint precision (0 half,1 single,2 double) */
+  int32_t scale;        /* Decimal */
+  int32_t unit;         /* Date (0 day,1 ms) / Time / Timestamp / Duration (0 s,1 ms,2 us,3 ns) / Interval */
+  int32_t byte_width;   /* FixedSizeBinary */
+  int32_t nullable;
+  int32_t n_children;
+  int32_t has_dict;
+  int64_t dict_id;
+  int32_t dict_index_bit_width;
+  int32_t dict_index_signed;
+} orc_field;
+
+typedef struct { int64_t length, null_count; } orc_node;
+typedef struct { int64_t offset, length; } orc_buf;
+
+/* ---- framing -------------------------------------------------------------------------------------- */
+/* Walk an in-memory IPC stream (or the stream embedded in an IPC file: the ARROW1 magic at offset 0 is
+ * skipped like ipc_file_stream_reader.cpp:116-119).  Stops at EOS (metadata size 0), at a truncated
+ * message (treated as end of stream, :126-129) or at `max` messages.  Returns ORC_OK or ORC_EIO with
+ * `err` filled ("Expected continuation token (0xFFFFFFFF) but got N", "Expected metadata size >= 0 ..."). */
+int orc_walk_stream(const uint8_t* buf, int64_t size, orc_msg* out, int32_t max, int32_t* n_out,
+                    char* err, int32_t err_cap);
+
+/* Message flatbuffer -> header type, body length, metadata version. */
+int orc_decode_message(const uint8_t* meta, int32_t meta_len, int32_t* type, int64_t* body_len,
+                       int32_t* version);
+/* Schema message -> depth-first flattened field list (children follow their parent), endianness. */
+int orc_decode_schema(const uint8_t* meta, int32_t meta_len, orc_field* out, int32_t max, int32_t* n_out,
+                      int32_t* n_top_level, int32_t* endianness);
+/* RecordBatch (or DictionaryBatch.data) -> nodes / buffers.  dict_id = -1 for a plain RecordBatch.
+ * compression = -1 none, 0 LZ4_FRAME, 1 ZSTD. */
+int orc_decode_record_batch(const uint8_t* meta, int32_t meta_len, int64_t* length, orc_node* nodes,
+                            int32_t max_nodes, int32_t* n_nodes, orc_buf* bufs, int32_t max_bufs,
+                            int32_t* n_bufs, int32_t* compression, int64_t* dict_id, int32_t* is_delta);
+/* Arrow IPC file footer (File.fbs): record-batch blocks {offset, metaDataLength, bodyLength}. */
+int orc_decode_footer(const uint8_t* file, int64_t size, int64_t* blocks3, int32_t max_blocks,
+                      int32_t* n_blocks, int32_t* n_dict_blocks);
+
+/* FULL validation of one offsets buffer as nanoarrow's NANOARROW_VALIDATION_LEVEL_FULL does
+ * (base_stream_reader.cpp:117,124,135,139): first offset >= 0, non-decreasing, last <= data_len. */
+int orc_validate_offsets32(const int32_t* off, int64_t n, int64_t data_len);
+int orc_validate_offsets64(const int64_t* off, int64_t n, int64_t data_len);
+
+/* ---- decode kernels: Arrow buffers -> one DuckDB flat vector window ---------------------------------
+ * o = first row of the window inside the batch (chunk_offset), n = rows in the window (<= 2048 in the
+ * reference's scan loop; any n is accepted here).  Canonical values for slots the reference leaves
+ * undefined: null rows of converted columns = 0, validity pad bits = 1. */
+
+/* K1: validity.  bitmap may be NULL.  Writes ceil(n/64) words. */
+void orc_validity(const uint8_t* bitmap, int64_t null_count, int64_t o, int64_t n, uint64_t* out);
+/* K2: bit-packed bool -> 1 byte per row (all rows, valid or not). */
+void orc_bool(const uint8_t* bits, int64_t o, int64_t n, uint8_t* out);
+/* K3a: fixed-width direct = pointer alias in the reference (FlatVector::SetData); here returns the alias. */
+const uint8_t* orc_direct(const uint8_t* data, int32_t width, int64_t o);
+/* K3b: decimal128 -> int16/int32/int64 (out_width 2/4/8) for valid rows. `valid` = window validity words
+ * from orc_validity. */
+void orc_decimal128_narrow(const uint8_t* data, const uint64_t* valid, int64_t o, int64_t n,
+                           int32_t out_width, void* out);
+/* K3c: temporal.  Return ORC_EINVAL on multiply overflow ("Could not convert ... to Microsecond"). */
+void orc_date64_to_date32(const int64_t* src, int64_t o, int64_t n, int32_t* out);
+int orc_mul_i32_to_i64(const int32_t* src, const uint64_t* valid, int64_t o, int64_t n, int64_t factor,
+                       int64_t* out);
+int orc_mul_i64(const int64_t* src, const uint64_t* valid, int64_t o, int64_t n, int64_t factor,
+                int64_t* out);
+void orc_div_i64(const int64_t* src, int64_t o, int64_t n, int64_t divisor, int64_t* out);
+/* duration -> interval_t{int32 months,int32 days,int64 micros}: factor>0 multiply, factor<0 divide by -factor */
+int orc_duration_to_interval(const int64_t* src, const uint64_t* valid, int64_t o, int64_t n,
+                             int64_t factor, uint8_t* out16);
+/* K4a/b: utf8/binary with int32 / int64 offsets -> string_t (16 B).  ptr_base is the address the
+ * consumer will see for byte 0 of the data buffer (host or device). */
+int orc_string32(const int32_t* off, const uint8_t* data, const uint64_t* valid, int64_t o, int64_t n,
+                 uint64_t ptr_base, uint8_t* out16);
+int orc_string64(const int64_t* off, const uint8_t* data, const uint64_t* valid, int64_t o, int64_t n,
+                 uint64_t ptr_base, uint8_t* out16);
+/* K4c: fixed-size binary w:N -> string_t */
+void orc_fixed_binary(const uint8_t* data, int32_t width, const uint64_t* valid, int64_t o, int64_t n,
+                      uint64_t ptr_base, uint8_t* out16);
+/* K5: dictionary indices -> sel_t; null -> dict_len.  idx_width in {1,2,4,8}. */
+int orc_dict_sel(const void* idx, int32_t idx_width, int32_t idx_signed, const uint64_t* valid, int64_t o,
+                 int64_t n, uint32_t dict_len, uint32_t* sel);
+/* K6 (extension of the reference: filter_pushdown=false at read_arrow.cpp:47, scan_arrow_ipc.cpp:60):
+ * lo <= v < hi on valid rows -> ascending window-relative row indices. Returns count. */
+int64_t orc_filter_range_i32(const int32_t* v, const uint64_t* valid, int64_t n, int32_t lo, int32_t hi,
+                             uint32_t* sel);
+int64_t orc_filter_range_i64(const int64_t* v, const uint64_t* valid, int64_t n, int64_t lo, int64_t hi,
+                             uint32_t* sel);
+
+/* ---- encode kernels: DuckDB flat vectors -> Arrow buffers (ArrowAppender semantics) -----------------
+ * `valid` may be NULL (all valid).  Row i of the input maps to row row0+i of the output buffers. */
+/* K7a: bitmap bytes for rows [row0,row0+n) (caller pre-fills new bytes with 0xFF like ResizeValidity). */
+void orc_enc_validity(const uint64_t* valid, int64_t n, int64_t row0, uint8_t* bitmap, int64_t* null_count);
+/* K7b: int16/32/64 -> decimal128 by sign extension (in_width 2/4/8). */
+void orc_enc_decimal_widen(const void* src, int32_t in_width, int64_t n, uint8_t* out16);
+/* K7c: byte bool -> bits */
+void orc_enc_bool(const uint8_t* src, const uint64_t* valid, int64_t n, int64_t row0, uint8_t* bits);
+/* K7d: string_t -> int32 offsets + data.  off[row0] must hold the running offset (0 for row0 == 0).
+ * Long-string pointers are resolved as (ptr - ptr_base) into `heap`.  Returns ORC_EINVAL when the running
+ * offset exceeds INT32_MAX. */
+int orc_enc_varchar32(const uint8_t* str16, const uint64_t* valid, int64_t n, int64_t row0,
+                      uint64_t ptr_base, const uint8_t* heap, int32_t* off, uint8_t* data);
+
+/* ---- whole-column drivers (the 2048-row pull loop of ArrowScanFunction, arrow_file_scan.cpp:68-72) -- */
+enum {
+  ORC_K_COPY = 1,      /* param = width */
+  ORC_K_BOOL = 2,
+  ORC_K_DEC128 = 3,    /* param = out width 2/4/8 */
+  ORC_K_DATE64 = 4,
+  ORC_K_MUL_I32 = 5,   /* param = factor */
+  ORC_K_MUL_I64 = 6,   /* param = factor */
+  ORC_K_DIV_I64 = 7,   /* param = divisor */
+  ORC_K_STR32 = 8,
+  ORC_K_STR64 = 9,
+  ORC_K_DICT = 10,     /* param = idx_width | (signed<<8); param2 = dict_len */
+  ORC_K_FIXED_BINARY = 11, /* param = width */
+  ORC_K_DURATION = 12  /* param = factor (neg = divide) */
+};
+
+typedef struct {
+  int32_t kind;
+  int32_t _pad;
+  int64_t param;
+  int64_t param2;
+  const uint8_t* validity; /* Arrow bitmap or NULL */
+  const uint8_t* buf1;
+  const uint8_t* buf2;
+  int64_t buf2_len;
+  int64_t null_count;
+  int64_t nrows;
+  uint64_t ptr_base;
+  uint8_t* out_data;      /* nrows * out width */
+  uint64_t* out_validity; /* ceil(nrows/64) words (windows are 2048-row aligned => 32-word slices) */
+} orc_col_task;
+
+/* Output element width for a task kind. */
+int32_t orc_out_width(int32_t kind, int64_t param);
+/* Runs the window loop over one column of one batch.  copy_direct != 0 materialises K3a columns into
+ * out_data (what the GPU path produces); 0 = the reference's zero-copy alias (nothing to do). */
+int orc_decode_column(const orc_col_task* t, int32_t copy_direct);
+
+/* ---- whole-stream driver (oracle_scan.c): the timed CPU baseline ---------------------------------- */
+typedef struct {
+  int64_t rows;
+  int64_t batches;
+  int64_t bytes_in;
+  int64_t bytes_out;
+  uint64_t checksum;
+} orc_scan_stats;
+
+/* Arrow field -> (kind, param, IPC buffer count); ORC_ENOTSUP for nested / view / half-float types. */
+int orc_plan_column(const orc_field* f, int32_t* kind, int64_t* param, int32_t* n_buffers);
+int orc_scan_stream(const uint8_t* buf, int64_t size, int32_t max_batches, int32_t want_checksum,
+                    orc_scan_stats* st);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,71 @@
+"""Shared test helpers: DuckDB-layout vectors -> canonical logical values (the same canonical form
+tests/golden/make_golden.py computes with pyarrow), used for both the oracle and the HIP path."""
+import hashlib
+import json
+
+import numpy as np
+
+from oracle import pyoracle as po
+
+# Arrow type ids (Schema.fbs Type union)
+T_INT, T_FLOAT, T_BINARY, T_UTF8, T_BOOL, T_DECIMAL, T_DATE, T_TIME, T_TIMESTAMP = 2, 3, 4, 5, 6, 7, 8, 9, 10
+T_FIXED_BINARY, T_DURATION, T_LARGE_BINARY, T_LARGE_UTF8 = 15, 18, 19, 20
+
+
+def column_digest(values):
+    return hashlib.sha256(json.dumps(values, separators=(",", ":")).encode()).hexdigest()
+
+
+def _fixed(data, ok, dtype):
+    vals = data.view(dtype)
+    return [vals[i].item() if ok[i] else None for i in range(len(ok))]
+
+
+def canon_flat(field, kind, param, width, data, validity, n, heap, heap_base=0):
+    """One decoded flat vector -> canonical logical list.  `heap_base` = pointer value of heap[0]; with
+    pyoracle.decode_stream's default pointer bases the heap is the whole stream and heap_base is 0."""
+    ok = po.valid_bits(validity, n) if n else np.zeros(0, bool)
+    t = field["type"]
+    if kind in (po.K_STR32, po.K_STR64, po.K_FIXED_BINARY):
+        as_bytes = t in (T_BINARY, T_LARGE_BINARY, T_FIXED_BINARY)
+        vals = po.strings_to_pylist(data, validity, n, heap, heap_base, as_bytes=as_bytes)
+        return [("b:" + v.hex()) if (as_bytes and v is not None) else v for v in vals]
+    if kind == po.K_BOOL:
+        return [bool(data[i]) if ok[i] else None for i in range(n)]
+    if t == T_FLOAT:
+        vals = data.view(np.float32 if width == 4 else np.float64)
+        return [repr(float(vals[i])) if ok[i] else None for i in range(n)]
+    if t == T_INT:
+        dt = np.dtype("%s%d" % ("i" if field["is_signed"] else "u", width))
+        return _fixed(data, ok, dt)
+    if t == T_DECIMAL and width == 16:
+        lo = data.view(np.uint64)[0::2]
+        hi = data.view(np.int64)[1::2]
+        return [(int(hi[i]) << 64) + int(lo[i]) if ok[i] else None for i in range(n)]
+    if kind == po.K_DURATION:
+        return [int(data.view(np.int64)[2 * i + 1]) if ok[i] else None for i in range(n)]
+    dt = {2: np.int16, 4: np.int32, 8: np.int64}[width]
+    return _fixed(data, ok, dt)
+
+
+def canon_oracle_column(field, col, n, heap, heap_base=0):
+    """A column dict from pyoracle.decode_stream (or the GPU equivalent) -> canonical logical list."""
+    if col["kind"] == po.K_DICT:
+        d = col["dictionary"]
+        vf = dict(field, has_dict=0)
+        base = canon_flat(vf, d["kind"], d["param"], d["width"], d["data"], d["validity"], d["nrows"], heap,
+                          heap_base) + [None]
+        sel = col["data"].view(np.uint32)
+        return [base[int(sel[i])] for i in range(n)]
+    return canon_flat(field, col["kind"], col["param"], col["width"], col["data"], col["validity"], n, heap,
+                      heap_base)
+
+
+def canon_stream(fields, batches, heap, heap_base=0):
+    """-> {column name: canonical list over all batches}"""
+    out = {f["name"]: [] for f in fields}
+    by_name = {f["name"]: f for f in fields}
+    for b in batches:
+        for c in b["columns"]:
+            out[c["name"]].extend(canon_oracle_column(by_name[c["name"]], c, b["nrows"], heap, heap_base))
+    return out
