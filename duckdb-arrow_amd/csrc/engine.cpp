@@ -1,0 +1,338 @@
+// engine.cpp -- device context + transcode plans.  See engine.hpp.
+#include "engine.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+
+namespace miarrow {
+
+Context::Context(int device_id) : device(device_id) {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    // The product path has no CPU fallback: without a HIP device it fails loudly.
+    throw Exception(MI_ENODEV, std::string("No HIP device available (hipGetDeviceCount: ") +
+                                   (e == hipSuccess ? "0 devices" : hipGetErrorString(e)) +
+                                   "); the MI355X Arrow IPC path has no CPU fallback");
+  }
+  if (device_id < 0 || device_id >= count) {
+    throw Exception(MI_ENODEV, "HIP device " + std::to_string(device_id) + " out of range (" + std::to_string(count) + " devices)");
+  }
+  MI_HIP_CHECK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  MI_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  MI_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  MI_HIP_CHECK(hipStreamCreateWithFlags(&h2d_stream, hipStreamNonBlocking));
+  MI_HIP_CHECK(hipStreamCreateWithFlags(&d2h_stream, hipStreamNonBlocking));
+}
+
+Context::~Context() {
+  if (stream) (void)hipStreamDestroy(stream);
+  if (h2d_stream) (void)hipStreamDestroy(h2d_stream);
+  if (d2h_stream) (void)hipStreamDestroy(d2h_stream);
+}
+
+void Context::Bind() const { MI_HIP_CHECK(hipSetDevice(device)); }
+
+int OutWidth(int32_t kind, int64_t param) {
+  switch (kind) {
+    case MI_K_COPY: return static_cast<int>(param);
+    case MI_K_BOOL: return 1;
+    case MI_K_DEC128: return static_cast<int>(param);
+    case MI_K_DATE64: return 4;
+    case MI_K_MUL_I32: case MI_K_MUL_I64: case MI_K_DIV_I64: return 8;
+    case MI_K_STR32: case MI_K_STR64: case MI_K_FIXED_BINARY: case MI_K_DURATION: return 16;
+    case MI_K_DICT: return 4;
+    default: return 0;
+  }
+}
+
+static void ValidateTask(const mi_col_task& t, size_t i) {
+  auto fail = [&](const std::string& what) {
+    throw InvalidInputException("task " + std::to_string(i) + ": " + what);
+  };
+  if (device::ClassOfKind(t.kind) < 0) fail("unknown kind " + std::to_string(t.kind));
+  if (t.nrows < 0) fail("negative row count");
+  if (t.row_offset < 0) fail("negative row offset");
+  if (t.nrows == 0) return;
+  if (t.out_data == nullptr) fail("out_data is NULL");
+  if (reinterpret_cast<uintptr_t>(t.out_data) % 16 != 0) fail("out_data must be 16-byte aligned");
+  if (t.out_validity && reinterpret_cast<uintptr_t>(t.out_validity) % 8 != 0) fail("out_validity must be 8-byte aligned");
+  if (t.validity && reinterpret_cast<uintptr_t>(t.validity) % 8 != 0) fail("validity bitmap must be 8-byte aligned");
+  if (t.buf1 == nullptr) fail("buf1 is NULL");
+  switch (t.kind) {
+    case MI_K_COPY:
+      if (t.param != 1 && t.param != 2 && t.param != 4 && t.param != 8 && t.param != 16) fail("COPY width must be 1,2,4,8,16");
+      break;
+    case MI_K_DEC128:
+      if (t.param != 2 && t.param != 4 && t.param != 8) fail("DEC128 out width must be 2,4,8");
+      if (reinterpret_cast<uintptr_t>(t.buf1) % 8 != 0) fail("decimal buffer must be 8-byte aligned");
+      break;
+    case MI_K_STR32:
+    case MI_K_STR64:
+      if (t.buf2 == nullptr && t.buf2_len != 0) fail("string data buffer is NULL");
+      if (reinterpret_cast<uintptr_t>(t.buf1) % (t.kind == MI_K_STR32 ? 4 : 8) != 0) fail("offsets buffer misaligned");
+      if (t.buf2 && reinterpret_cast<uintptr_t>(t.buf2) % 4 != 0) fail("string data buffer must be 4-byte aligned");
+      if (t.buf2_len < 0) fail("negative buf2_len");
+      break;
+    case MI_K_FIXED_BINARY:
+      if (t.param <= 0) fail("fixed binary width must be positive");
+      if (reinterpret_cast<uintptr_t>(t.buf1) % 4 != 0) fail("fixed binary buffer must be 4-byte aligned");
+      break;
+    case MI_K_DICT: {
+      int iw = static_cast<int>(t.param & 0xFF);
+      if (iw != 1 && iw != 2 && iw != 4 && iw != 8) fail("dictionary index width must be 1,2,4,8");
+      break;
+    }
+    case MI_K_MUL_I32: case MI_K_MUL_I64:
+      if (t.param <= 0) fail("multiplier must be positive");
+      break;
+    case MI_K_DIV_I64:
+      if (t.param <= 0) fail("divisor must be positive");
+      break;
+    case MI_K_DURATION:
+      if (t.param == 0) fail("duration factor must be non-zero");
+      break;
+    case MI_K_ENC_COPY:
+      if (t.param != 1 && t.param != 2 && t.param != 4 && t.param != 8 && t.param != 16) fail("ENC_COPY width must be 1,2,4,8,16");
+      break;
+    case MI_K_ENC_DEC128:
+      if (t.param != 2 && t.param != 4 && t.param != 8) fail("ENC_DEC128 in width must be 2,4,8");
+      break;
+    case MI_K_ENC_STR32:
+      if (t.out_aux == nullptr) fail("out_aux (string data) is NULL");
+      if (reinterpret_cast<uintptr_t>(t.buf1) % 16 != 0) fail("string_t vector must be 16-byte aligned");
+      break;
+    default: break;
+  }
+  if (t.kind >= MI_K_ENC_COPY && t.out_validity == nullptr) fail("encode tasks need out_validity (the bitmap is always emitted)");
+}
+
+static int64_t TaskBytesRead(const mi_col_task& t) {
+  const int64_t n = t.nrows;
+  int64_t b = 0;
+  if (t.kind < MI_K_ENC_COPY) {
+    if (t.validity && t.null_count != 0) b += (n + 7) / 8;
+    switch (t.kind) {
+      case MI_K_COPY: case MI_K_FIXED_BINARY: b += n * t.param; break;
+      case MI_K_BOOL: b += (n + 7) / 8; break;
+      case MI_K_DEC128: b += n * 16; break;
+      case MI_K_DATE64: case MI_K_MUL_I64: case MI_K_DIV_I64: case MI_K_DURATION: b += n * 8; break;
+      case MI_K_MUL_I32: b += n * 4; break;
+      case MI_K_STR32: b += (n ? (n + 1) * 4 : 0) + t.buf2_len; break;
+      case MI_K_STR64: b += (n ? (n + 1) * 8 : 0) + t.buf2_len; break;
+      case MI_K_DICT: b += n * (t.param & 0xFF); break;
+      default: break;
+    }
+  } else {
+    if (t.validity) b += ((n + 63) / 64) * 8;
+    switch (t.kind) {
+      case MI_K_ENC_COPY: case MI_K_ENC_DEC128: b += n * t.param; break;
+      case MI_K_ENC_BOOL: b += n; break;
+      case MI_K_ENC_STR32: b += n * 16; break;  // + payload, known only after the scan (reported via buf2_len if given)
+      default: break;
+    }
+    if (t.kind == MI_K_ENC_STR32) b += t.buf2_len;
+  }
+  return b;
+}
+
+static int64_t TaskBytesWritten(const mi_col_task& t) {
+  const int64_t n = t.nrows;
+  if (t.kind < MI_K_ENC_COPY) {
+    return n * OutWidth(t.kind, t.param) + (t.out_validity ? ((n + 63) / 64) * 8 : 0);
+  }
+  int64_t b = (n + 7) / 8;  // bitmap
+  switch (t.kind) {
+    case MI_K_ENC_COPY: b += n * t.param; break;
+    case MI_K_ENC_DEC128: b += n * 16; break;
+    case MI_K_ENC_BOOL: b += (n + 7) / 8; break;
+    case MI_K_ENC_STR32: b += (n + 1) * 4 + t.buf2_len; break;
+    default: break;
+  }
+  return b;
+}
+
+Plan::Plan(Context* ctx_p, const mi_col_task* in_tasks, int32_t n_tasks) : ctx(ctx_p) {
+  Set(in_tasks, n_tasks, nullptr);
+}
+
+Plan::Plan(Context* ctx_p) : ctx(ctx_p), reusable(true) {
+  ctx->Bind();
+  MI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_status), 64));
+  MI_HIP_CHECK(hipMemset(d_status, 0, 64));
+}
+
+template <typename T>
+static void EnsureDevice(T** p, size_t* cap, size_t need) {
+  if (need <= *cap && *p) return;
+  if (*p) MI_HIP_CHECK(hipFree(*p));
+  *p = nullptr;
+  size_t n = std::max<size_t>(need, *cap * 2);
+  n = std::max<size_t>(n, 64);
+  MI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T)));
+  *cap = n;
+}
+
+void Plan::Set(const mi_col_task* in_tasks, int32_t n_tasks, hipStream_t upload_stream) {
+  ctx->Bind();
+  tasks.clear();
+  order.clear();
+  tile_begin.clear();
+  total_tiles = 0;
+  bytes_read = bytes_written = rows = 0;
+  is_encode = false;
+  // group by kernel class, stable inside a class
+  std::vector<std::vector<mi_col_task>> by_class(device::kNumClasses);
+  int64_t null_counter = 0;
+  for (int32_t i = 0; i < n_tasks; i++) {
+    ValidateTask(in_tasks[i], static_cast<size_t>(i));
+    mi_col_task t = in_tasks[i];
+    const int cls = device::ClassOfKind(t.kind);
+    if (t.kind >= MI_K_ENC_COPY) {
+      is_encode = true;
+      t.param2 = null_counter++;  // slot of this task's NULL counter
+    }
+    bytes_read += TaskBytesRead(t);
+    bytes_written += TaskBytesWritten(t);
+    rows += t.nrows;
+    order.push_back({cls, static_cast<int32_t>(by_class[static_cast<size_t>(cls)].size())});
+    by_class[static_cast<size_t>(cls)].push_back(t);
+  }
+  n_null_counts = null_counter;
+  for (int c = 0; c < device::kNumClasses; c++) {
+    ClassSlice& s = classes[c];
+    s.first_task = static_cast<int32_t>(tasks.size());
+    s.n_tasks = static_cast<int32_t>(by_class[static_cast<size_t>(c)].size());
+    s.tile_begin_at = static_cast<int32_t>(tile_begin.size());
+    uint64_t tiles = 0;
+    for (auto& t : by_class[static_cast<size_t>(c)]) {
+      tile_begin.push_back(static_cast<uint32_t>(tiles));
+      tiles += static_cast<uint64_t>((t.nrows + device::kTileRows - 1) / device::kTileRows);
+      if (tiles > 0xFFFFFFF0ull) throw InvalidInputException("plan has too many tiles");
+      tasks.push_back(t);
+    }
+    tile_begin.push_back(static_cast<uint32_t>(tiles));
+    s.total_tiles = static_cast<uint32_t>(tiles);
+    total_tiles += s.total_tiles;
+  }
+  // device tables
+  const size_t old_cap_tasks = cap_tasks, old_cap_tb = cap_tile_begin;
+  EnsureDevice(&d_tasks, &cap_tasks, tasks.size());
+  EnsureDevice(&d_tile_begin, &cap_tile_begin, tile_begin.size());
+  if (!d_status) {
+    MI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_status), 64));
+    MI_HIP_CHECK(hipMemset(d_status, 0, 64));
+  }
+  if (classes[device::kClassEncString].total_tiles)
+    EnsureDevice(&d_tile_sums, &cap_tile_sums, classes[device::kClassEncString].total_tiles);
+  if (n_null_counts) {
+    const size_t before = cap_null_counts;
+    EnsureDevice(&d_null_counts, &cap_null_counts, static_cast<size_t>(n_null_counts));
+    if (cap_null_counts != before) MI_HIP_CHECK(hipMemset(d_null_counts, 0, cap_null_counts * sizeof(int64_t)));
+  }
+  if (reusable && upload_stream) {
+    if (cap_tasks != old_cap_tasks || !h_tasks) {
+      if (h_tasks) MI_HIP_CHECK(hipHostFree(h_tasks));
+      MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_tasks), cap_tasks * sizeof(mi_col_task), hipHostMallocDefault));
+    }
+    if (cap_tile_begin != old_cap_tb || !h_tile_begin) {
+      if (h_tile_begin) MI_HIP_CHECK(hipHostFree(h_tile_begin));
+      MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_tile_begin), cap_tile_begin * sizeof(uint32_t), hipHostMallocDefault));
+    }
+    if (!tasks.empty()) {
+      std::memcpy(h_tasks, tasks.data(), tasks.size() * sizeof(mi_col_task));
+      MI_HIP_CHECK(hipMemcpyAsync(d_tasks, h_tasks, tasks.size() * sizeof(mi_col_task), hipMemcpyHostToDevice, upload_stream));
+    }
+    std::memcpy(h_tile_begin, tile_begin.data(), tile_begin.size() * sizeof(uint32_t));
+    MI_HIP_CHECK(hipMemcpyAsync(d_tile_begin, h_tile_begin, tile_begin.size() * sizeof(uint32_t), hipMemcpyHostToDevice, upload_stream));
+  } else {
+    if (!tasks.empty())
+      MI_HIP_CHECK(hipMemcpy(d_tasks, tasks.data(), tasks.size() * sizeof(mi_col_task), hipMemcpyHostToDevice));
+    MI_HIP_CHECK(hipMemcpy(d_tile_begin, tile_begin.data(), tile_begin.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+}
+
+Plan::~Plan() {
+  if (d_tasks) (void)hipFree(d_tasks);
+  if (d_tile_begin) (void)hipFree(d_tile_begin);
+  if (d_status) (void)hipFree(d_status);
+  if (d_tile_sums) (void)hipFree(d_tile_sums);
+  if (d_null_counts) (void)hipFree(d_null_counts);
+  if (h_tasks) (void)hipHostFree(h_tasks);
+  if (h_tile_begin) (void)hipHostFree(h_tile_begin);
+}
+
+void Plan::Launch(hipStream_t s) {
+  ctx->Bind();
+  if (!s) s = ctx->stream;
+  last_stream = s;
+  const int grid = ctx->GridBlocks();
+  for (int c = 0; c < device::kNumClasses; c++) {
+    const ClassSlice& cs = classes[c];
+    if (cs.total_tiles == 0) continue;
+    const mi_col_task* t = d_tasks + cs.first_task;
+    const uint32_t* tb = d_tile_begin + cs.tile_begin_at;
+    switch (c) {
+      case device::kClassEncFixed:
+        MI_HIP_CHECK(device::LaunchEncodeFixed(t, tb, cs.n_tasks, cs.total_tiles, d_null_counts, grid, s));
+        break;
+      case device::kClassEncString:
+        MI_HIP_CHECK(device::LaunchEncodeStringTileSums(t, tb, cs.n_tasks, cs.total_tiles, d_tile_sums, grid, s));
+        MI_HIP_CHECK(device::LaunchEncodeStringScan(t, tb, cs.n_tasks, d_tile_sums, d_status, s));
+        MI_HIP_CHECK(device::LaunchEncodeString(t, tb, cs.n_tasks, cs.total_tiles, d_tile_sums, d_null_counts, grid, s));
+        break;
+      default:
+        MI_HIP_CHECK(device::LaunchTranscode(c, t, tb, cs.n_tasks, cs.total_tiles, d_status, grid, s));
+        break;
+    }
+  }
+}
+
+uint32_t Plan::Status() {
+  ctx->Bind();
+  hipStream_t s = last_stream ? last_stream : ctx->stream;
+  MI_HIP_CHECK(hipStreamSynchronize(s));
+  uint32_t bits = 0;
+  MI_HIP_CHECK(hipMemcpy(&bits, d_status, sizeof(bits), hipMemcpyDeviceToHost));
+  if (bits) MI_HIP_CHECK(hipMemset(d_status, 0, sizeof(bits)));
+  return bits;
+}
+
+std::vector<int64_t> Plan::NullCounts(bool reset) {
+  ctx->Bind();
+  std::vector<int64_t> per_slot(static_cast<size_t>(n_null_counts), 0);
+  if (n_null_counts) {
+    hipStream_t s = last_stream ? last_stream : ctx->stream;
+    MI_HIP_CHECK(hipStreamSynchronize(s));
+    MI_HIP_CHECK(hipMemcpy(per_slot.data(), d_null_counts, per_slot.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (reset) MI_HIP_CHECK(hipMemset(d_null_counts, 0, per_slot.size() * sizeof(int64_t)));
+  }
+  // back to the caller's task order (non-encode tasks report 0)
+  std::vector<int64_t> out(order.size(), 0);
+  for (size_t i = 0; i < order.size(); i++) {
+    const mi_col_task& t = tasks[static_cast<size_t>(classes[order[i].first].first_task + order[i].second)];
+    if (t.kind >= MI_K_ENC_COPY) out[i] = per_slot[static_cast<size_t>(t.param2)];
+  }
+  return out;
+}
+
+void ThrowForStatus(uint32_t bits) {
+  if (bits == 0) return;
+  if (bits & MI_ST_BAD_OFFSETS)
+    throw InternalException("Arrow IPC validation failed: offsets buffer is not monotonically non-decreasing or exceeds the data buffer");
+  if (bits & MI_ST_STRING_TOO_LARGE) throw ConversionException("DuckDB does not support Strings over 4GB");
+  if (bits & MI_ST_MUL_OVERFLOW) throw ConversionException("Could not convert Timestamp to Microsecond");
+  if (bits & MI_ST_INDEX_RANGE) throw ConversionException("DuckDB only supports indices that fit on an uint32");
+  if (bits & MI_ST_DECIMAL_RANGE) throw ConversionException("Decimal value does not fit the physical type of its declared precision");
+  if (bits & MI_ST_OFFSET_OVERFLOW)
+    throw InvalidInputException(
+        "Arrow Appender: The maximum total string size for regular string buffers is 2147483647 but the offset exceeds this.\n"
+        "* SET arrow_large_buffer_size=true to use large string buffers");
+  throw InternalException("unknown device status " + std::to_string(bits));
+}
+
+}  // namespace miarrow

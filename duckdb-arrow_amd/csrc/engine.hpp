@@ -1,0 +1,86 @@
+// engine.hpp -- device context and transcode plans (host side of the fused kernel launch).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "ipc_format.hpp"
+#include "kernels.hpp"
+
+namespace miarrow {
+
+#define MI_HIP_CHECK(expr)                                                                                  \
+  do {                                                                                                      \
+    hipError_t _e = (expr);                                                                                 \
+    if (_e != hipSuccess) {                                                                                 \
+      throw ::miarrow::Exception(_e == hipErrorOutOfMemory ? MI_ENOMEM : MI_EIO,                            \
+                                 std::string(#expr) + " failed: " + hipGetErrorString(_e));                 \
+    }                                                                                                       \
+  } while (0)
+
+struct Context {
+  int device = 0;
+  int num_cus = 256;
+  hipStream_t stream = nullptr;       // compute
+  hipStream_t h2d_stream = nullptr;   // pinned host -> HBM
+  hipStream_t d2h_stream = nullptr;   // HBM -> pinned host
+
+  explicit Context(int device_id);
+  ~Context();
+  void Bind() const;  // hipSetDevice
+  int GridBlocks() const { return num_cus * device::kBlocksPerCU; }
+};
+
+int OutWidth(int32_t kind, int64_t param);
+
+struct ClassSlice {
+  int32_t first_task = 0;     // index into Plan::tasks / d_tasks
+  int32_t n_tasks = 0;
+  int32_t tile_begin_at = 0;  // index into Plan::tile_begin / d_tile_begin (n_tasks + 1 entries)
+  uint32_t total_tiles = 0;
+};
+
+// A plan = any number of (record batch, column) tasks, grouped by kernel class; Launch() enqueues one kernel per
+// non-empty class (lineitem: copy + dec128 + string = 3 launches for the whole table, however many batches).
+struct Plan {
+  Context* ctx;
+  std::vector<mi_col_task> tasks;                 // grouped by class
+  std::vector<std::pair<int, int32_t>> order;     // caller order -> (class, index inside the class)
+  std::vector<uint32_t> tile_begin;
+  ClassSlice classes[device::kNumClasses];
+  mi_col_task* d_tasks = nullptr;
+  uint32_t* d_tile_begin = nullptr;
+  uint32_t* d_status = nullptr;
+  int64_t* d_tile_sums = nullptr;    // encode plans with string columns
+  int64_t* d_null_counts = nullptr;  // encode plans: one counter per task
+  int64_t n_null_counts = 0;
+  uint32_t total_tiles = 0;
+  bool is_encode = false;
+  hipStream_t last_stream = nullptr;
+  int64_t bytes_read = 0, bytes_written = 0, rows = 0;
+  // capacities + pinned mirrors (reusable plans)
+  size_t cap_tasks = 0, cap_tile_begin = 0, cap_tile_sums = 0, cap_null_counts = 0;
+  mi_col_task* h_tasks = nullptr;
+  uint32_t* h_tile_begin = nullptr;
+  bool reusable = false;
+
+  Plan(Context* ctx, const mi_col_task* tasks, int32_t n_tasks);
+  //! Reusable plan (scan / writer pipelines): tables are re-filled with Set() and uploaded asynchronously from
+  //! pinned host mirrors, so a new record batch costs no hipMalloc and no synchronous copy.
+  explicit Plan(Context* ctx);
+  void Set(const mi_col_task* tasks, int32_t n_tasks, hipStream_t upload_stream);
+  ~Plan();
+  Plan(const Plan&) = delete;
+  Plan& operator=(const Plan&) = delete;
+  void Launch(hipStream_t stream);
+  uint32_t Status();
+  std::vector<int64_t> NullCounts(bool reset);
+};
+
+// status word -> the exception the reference would throw
+void ThrowForStatus(uint32_t bits);
+
+}  // namespace miarrow

@@ -1,0 +1,566 @@
+// ipc_stream_reader.cpp -- see ipc_stream_reader.hpp.
+#include "ipc_stream_reader.hpp"
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cctype>
+#include <cerrno>
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+#include <unordered_map>
+#include <unordered_set>
+
+namespace miarrow {
+
+static std::string Lower(std::string s) {
+  for (auto& c : s) c = static_cast<char>(std::tolower(static_cast<unsigned char>(c)));
+  return s;
+}
+
+// Same observable behaviour as DuckDB's QueryResult::DeduplicateColumns (used at base_stream_reader.cpp:177 and
+// arrow_file_scan.cpp:19): case-insensitive; a repeated name gets "_<n>" appended, n counting repetitions and
+// skipping suffixes that are already taken.
+void DeduplicateColumns(std::vector<std::string>& names) {
+  std::unordered_map<std::string, idx_t> seen;
+  for (auto& name : names) {
+    std::string low = Lower(name);
+    auto it = seen.find(low);
+    if (it == seen.end()) {
+      seen[low] = 1;
+      continue;
+    }
+    std::string candidate = name + "_" + std::to_string(seen[low]);
+    while (seen.find(Lower(candidate)) != seen.end()) {
+      seen[low]++;
+      candidate = name + "_" + std::to_string(seen[low]);
+    }
+    name = candidate;
+    seen[Lower(candidate)] = 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ base reader
+const ArrowSchemaModel& IPCStreamReader::GetBaseSchema() {
+  if (have_base_schema) return base_schema;
+  ReadNextMessage({MessageType::SCHEMA}, /*end_of_stream_ok*/ false);
+  base_schema = DecodeSchema(message_meta, message_meta_len);
+  if (base_schema.features & (1u << 1)) {
+    throw IOException("This stream uses unsupported feature DICTIONARY_REPLACEMENT");
+  }
+  if (base_schema.endianness != 0) {
+    // The reference byte-swaps through nanoarrow (base_stream_reader.cpp:68-69); the device path is little-endian only.
+    throw NotImplementedException("Big-endian Arrow IPC streams are not supported by the MI355X scan path");
+  }
+  have_base_schema = true;
+  return base_schema;
+}
+
+const ArrowSchemaModel& IPCStreamReader::GetOutputSchema() {
+  if (HasProjection()) return projected_schema;
+  return GetBaseSchema();
+}
+
+void IPCStreamReader::SetColumnProjection(const std::vector<std::string>& column_names) {
+  if (column_names.empty()) {
+    throw InternalException("Can't request zero fields projected from IpcStreamReader");
+  }
+  GetBaseSchema();
+
+  std::vector<std::string> names;
+  for (auto& f : base_schema.fields) names.push_back(f.name);
+  DeduplicateColumns(names);
+
+  // flattened field index (the decoder addresses columns depth-first) + top-level index per name
+  std::unordered_map<std::string, std::pair<int64_t, int32_t>> name_to_field;
+  std::unordered_set<std::string> duplicate_column_names;
+  int64_t field_count = 0;
+  for (size_t i = 0; i < base_schema.fields.size(); i++) {
+    if (name_to_field.find(names[i]) != name_to_field.end()) duplicate_column_names.insert(names[i]);
+    name_to_field.insert({names[i], {field_count, static_cast<int32_t>(i)}});
+    field_count += CountFields(base_schema.fields[i]);
+  }
+
+  std::vector<int64_t> new_fields;
+  std::vector<int32_t> new_columns;
+  ArrowSchemaModel schema;
+  schema.endianness = base_schema.endianness;
+  schema.metadata = base_schema.metadata;
+  for (const auto& column_name : column_names) {
+    if (duplicate_column_names.find(column_name) != duplicate_column_names.end()) {
+      throw InternalException(std::string("Field '") + column_name + "' refers to a duplicate column name in IPC file schema");
+    }
+    auto item = name_to_field.find(column_name);
+    if (item == name_to_field.end()) {
+      throw InternalException(std::string("Field '") + column_name + "' does not exist in IPC file schema");
+    }
+    new_fields.push_back(item->second.first);
+    new_columns.push_back(item->second.second);
+    schema.fields.push_back(base_schema.fields[static_cast<size_t>(item->second.second)]);
+  }
+  projected_fields = std::move(new_fields);
+  projected_columns = std::move(new_columns);
+  projected_schema = std::move(schema);
+}
+
+idx_t IPCStreamReader::DecodeMetadata() const {
+  // little-endian host: no BSWAP (base_stream_reader.cpp:216-220)
+  int64_t metadata_size = message_prefix.metadata_size;
+  if (metadata_size < 0) {
+    throw IOException(std::string("Expected metadata size >= 0 but got " + std::to_string(metadata_size)));
+  }
+  return static_cast<idx_t>(metadata_size) + sizeof(message_prefix);
+}
+
+MessageType IPCStreamReader::DecodeMessage() {
+  auto message_header_size = DecodeMetadata();
+  if (DecodeHeader(message_header_size)) {
+    return MessageType::UNINITIALIZED;
+  }
+  DecodeBody();
+  return message.type;
+}
+
+bool IPCStreamReader::ParseHeader(const uint8_t* header_with_prefix, idx_t size) {
+  // ArrowIpcDecoderDecodeHeader: metadata size 0 is the end-of-stream marker => ENODATA
+  if (message_prefix.metadata_size == 0) return false;
+  message_meta = header_with_prefix + sizeof(message_prefix);
+  message_meta_len = static_cast<int64_t>(size - sizeof(message_prefix));
+  message = DecodeMessageHeader(message_meta, message_meta_len);
+  return true;
+}
+
+MessageType IPCStreamReader::ReadNextMessage(std::vector<MessageType> expected_types, bool end_of_stream_ok) {
+  MessageType actual_type = ReadNextMessage();
+  if (end_of_stream_ok && actual_type == MessageType::UNINITIALIZED) return actual_type;
+  for (const auto expected_type : expected_types) {
+    if (expected_type == actual_type) return actual_type;
+  }
+  std::stringstream expected_types_label;
+  for (size_t i = 0; i < expected_types.size(); i++) {
+    if (i > 0) expected_types_label << " or ";
+    expected_types_label << MessageTypeString(expected_types[i]);
+  }
+  std::string actual_type_label =
+      actual_type == MessageType::UNINITIALIZED ? "end of stream" : MessageTypeString(actual_type);
+  throw IOException(std::string("Expected ") + expected_types_label.str() + " Arrow IPC message but got " + actual_type_label);
+}
+
+bool IPCStreamReader::GetNextBatch(DecodedBatch* out, bool accept_dictionaries, bool skip_body) {
+  GetBaseSchema();
+  std::vector<MessageType> expected = {MessageType::RECORD_BATCH};
+  if (accept_dictionaries) expected.push_back(MessageType::DICTIONARY_BATCH);
+  skip_record_batch_body = skip_body;
+  MessageType message_type;
+  try {
+    message_type = ReadNextMessage(expected);
+  } catch (...) {
+    skip_record_batch_body = false;
+    throw;
+  }
+  skip_record_batch_body = false;
+  if (message_type == MessageType::UNINITIALIZED) return false;
+  RecordBatchMeta meta = DecodeRecordBatch(message_meta, message_meta_len);
+  if (skip_body && message_type == MessageType::RECORD_BATCH) {
+    *out = DecodedBatch();
+    out->length = meta.length;
+    out->body_file_offset = cur_body_offset;
+    return true;
+  }
+  SliceBatch(meta, out);
+  return true;
+}
+
+static std::string BufferSizeError(const std::string& column, int buffer, int64_t need, int64_t have) {
+  return "Expected " + column + " buffer " + std::to_string(buffer) + " to have size >= " + std::to_string(need) +
+         " bytes but found buffer with " + std::to_string(have) + " bytes";
+}
+
+void IPCStreamReader::SliceBatch(const RecordBatchMeta& meta, DecodedBatch* out) {
+  out->length = meta.length;
+  out->body = cur_ptr;
+  out->body_size = cur_size;
+  out->body_file_offset = cur_body_offset;
+  out->is_dictionary = meta.is_dictionary;
+  out->dict_id = meta.dict_id;
+  out->is_delta = meta.is_delta;
+  out->compression = meta.compression;
+  out->owner = cur_owner;
+  out->column_field.clear();
+  out->null_count.clear();
+  out->column_length.clear();
+  out->buffers.clear();
+  if (meta.compression != -1) {
+    // The reference decompresses zstd buffers on the CPU (base_stream_reader.cpp:11-50); SURVEY 8f ranks that "next".
+    throw NotImplementedException("Compressed IPC bodies (BodyCompression codec " + std::to_string(meta.compression) +
+                                  ") are not supported by the MI355X scan path yet");
+  }
+
+  auto check_span = [&](const mi_buffer_span& s) {
+    if (s.offset < 0 || s.length < 0 || s.offset + s.length > cur_size) {
+      throw InternalException("Buffer requires body offsets [" + std::to_string(s.offset) + ", " +
+                              std::to_string(s.offset + s.length) + ") but body has size " + std::to_string(cur_size));
+    }
+    if (s.offset % 8 != 0) throw InternalException("Buffer offset " + std::to_string(s.offset) + " is not 8-byte aligned");
+  };
+
+  auto emit = [&](const ArrowField& f, int32_t top_index, size_t node_i, size_t buf_i) {
+    int32_t kind, w, nb;
+    int64_t param;
+    bool ok = f.Plan(&kind, &param, &w, &nb, /*value_only*/ meta.is_dictionary);
+    if (node_i >= meta.nodes.size()) throw InternalException("RecordBatch has too few field nodes");
+    int64_t n = meta.nodes[node_i].first;
+    int64_t nulls = meta.nodes[node_i].second;
+    if (n < 0) throw InternalException("Field node length is negative");
+    if (!ok) nb = static_cast<int32_t>(std::min<int64_t>(f.CountBuffers(), 3));
+    mi_buffer_span spans[3] = {{0, 0}, {0, 0}, {0, 0}};
+    for (int32_t k = 0; k < nb && k < 3; k++) {
+      if (buf_i + static_cast<size_t>(k) >= meta.buffers.size()) throw InternalException("RecordBatch has too few buffers");
+      spans[k] = meta.buffers[buf_i + static_cast<size_t>(k)];
+      check_span(spans[k]);
+    }
+    if (ok) {
+      // size checks of ArrowArrayViewValidate (FULL), minus the data-dependent offsets walk
+      if (spans[0].length != 0 && spans[0].length < (n + 7) / 8)
+        throw InternalException(BufferSizeError(f.name, 0, (n + 7) / 8, spans[0].length));
+      if (nulls != 0 && spans[0].length == 0 && n > 0 && nulls > 0)
+        throw InternalException("Column " + f.name + " has null_count " + std::to_string(nulls) + " but no validity buffer");
+      int64_t need1 = 0;
+      switch (kind) {
+        case MI_K_COPY: case MI_K_FIXED_BINARY: need1 = n * param; break;
+        case MI_K_BOOL: need1 = (n + 7) / 8; break;
+        case MI_K_DEC128: need1 = n * 16; break;
+        case MI_K_DATE64: case MI_K_MUL_I64: case MI_K_DIV_I64: case MI_K_DURATION: need1 = n * 8; break;
+        case MI_K_MUL_I32: need1 = n * 4; break;
+        case MI_K_STR32: need1 = n > 0 ? (n + 1) * 4 : 0; break;
+        case MI_K_STR64: need1 = n > 0 ? (n + 1) * 8 : 0; break;
+        case MI_K_DICT: need1 = n * (param & 0xFF); break;
+        default: break;
+      }
+      if (spans[1].length < need1) throw InternalException(BufferSizeError(f.name, 1, need1, spans[1].length));
+    }
+    out->column_field.push_back(top_index);
+    out->null_count.push_back(nulls);
+    out->column_length.push_back(n);
+    out->buffers.push_back(spans[0]);
+    out->buffers.push_back(spans[1]);
+    out->buffers.push_back(spans[2]);
+  };
+
+  if (meta.is_dictionary) {
+    // one node: the dictionary values of the field(s) that carry this id
+    const ArrowField* owner_field = nullptr;
+    int32_t top = -1;
+    for (size_t i = 0; i < base_schema.fields.size(); i++) {
+      if (base_schema.fields[i].has_dictionary && base_schema.fields[i].dict_id == meta.dict_id) {
+        owner_field = &base_schema.fields[i];
+        top = static_cast<int32_t>(i);
+        break;
+      }
+    }
+    if (!owner_field) throw IOException("DictionaryBatch refers to unknown dictionary id " + std::to_string(meta.dict_id));
+    emit(*owner_field, top, 0, 0);
+    return;
+  }
+
+  // node / buffer cursor per top-level field (depth-first layout of RecordBatch.nodes / .buffers)
+  std::vector<size_t> node_start(base_schema.fields.size()), buf_start(base_schema.fields.size());
+  size_t node_i = 0, buf_i = 0;
+  for (size_t i = 0; i < base_schema.fields.size(); i++) {
+    node_start[i] = node_i;
+    buf_start[i] = buf_i;
+    node_i += static_cast<size_t>(base_schema.fields[i].CountFields());
+    buf_i += static_cast<size_t>(base_schema.fields[i].CountBuffers());
+  }
+  if (node_i != meta.nodes.size()) {
+    throw InternalException("Expected " + std::to_string(node_i) + " field nodes in message but found " +
+                            std::to_string(meta.nodes.size()));
+  }
+  if (buf_i > meta.buffers.size()) {
+    throw InternalException("Expected " + std::to_string(buf_i) + " buffers in message but found " +
+                            std::to_string(meta.buffers.size()));
+  }
+  if (HasProjection()) {
+    for (int32_t c : projected_columns)
+      emit(base_schema.fields[static_cast<size_t>(c)], c, node_start[static_cast<size_t>(c)], buf_start[static_cast<size_t>(c)]);
+  } else {
+    for (size_t i = 0; i < base_schema.fields.size(); i++) emit(base_schema.fields[i], static_cast<int32_t>(i), node_start[i], buf_start[i]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ file reader
+namespace {
+struct SerializationException : std::runtime_error {
+  SerializationException() : std::runtime_error("not enough data in file to deserialize result") {}
+};
+
+std::shared_ptr<void> DefaultBodyAlloc(size_t bytes, MessageType, uint8_t** ptr) {
+  void* p = nullptr;
+  if (posix_memalign(&p, 256, bytes ? bytes : 8) != 0) throw std::bad_alloc();
+  *ptr = static_cast<uint8_t*>(p);
+  return std::shared_ptr<void>(p, [](void* q) { std::free(q); });
+}
+}  // namespace
+
+IPCFileStreamReader::IPCFileStreamReader(const std::string& path_p) : path(path_p) {
+  fd = ::open(path.c_str(), O_RDONLY);
+  if (fd < 0) {
+    throw IOException("Cannot open file \"" + path + "\": " + std::strerror(errno));
+  }
+  struct stat st;
+  if (fstat(fd, &st) != 0) {
+    ::close(fd);
+    fd = -1;
+    throw IOException("Cannot stat file \"" + path + "\": " + std::strerror(errno));
+  }
+  file_size = st.st_size;
+}
+
+IPCFileStreamReader::~IPCFileStreamReader() {
+  if (fd >= 0) ::close(fd);
+}
+
+void IPCFileStreamReader::PopulateNames(std::vector<std::string>& names) {
+  GetBaseSchema();
+  for (auto& f : base_schema.fields) names.push_back(f.name);
+}
+
+double IPCFileStreamReader::GetProgress() {
+  if (file_size == 0) return 100;
+  return (static_cast<double>(offset) / static_cast<double>(file_size)) * 100;
+}
+
+const uint8_t* IPCFileStreamReader::ReadData(uint8_t* ptr, idx_t size) {
+  // BufferedFileReader::ReadData throws SerializationException when the file ends early
+  idx_t done = 0;
+  while (done < size) {
+    ssize_t r = ::pread(fd, ptr + done, size - done, static_cast<off_t>(offset + static_cast<int64_t>(done)));
+    if (r < 0) {
+      if (errno == EINTR) continue;
+      throw IOException("Could not read from file \"" + path + "\": " + std::strerror(errno));
+    }
+    if (r == 0) throw SerializationException();
+    done += static_cast<idx_t>(r);
+  }
+  offset += static_cast<int64_t>(size);
+  return ptr;
+}
+
+void IPCFileStreamReader::EnsureInputStreamAligned() {
+  uint8_t padding[8];
+  int padding_bytes = 8 - static_cast<int>(offset % 8);
+  if (padding_bytes != 8) ReadData(padding, static_cast<idx_t>(padding_bytes));
+}
+
+MessageType IPCFileStreamReader::ReadNextMessage() {
+  if (finished) return MessageType::UNINITIALIZED;
+  // If there is no more data to be read, we're done!
+  try {
+    EnsureInputStreamAligned();
+    ReadData(reinterpret_cast<uint8_t*>(&message_prefix), sizeof(message_prefix));
+    // Arrow *file* format: skip the magic and read the stream embedded in the file (ipc_file_stream_reader.cpp:107-119)
+    if (offset == 8 && std::memcmp("ARROW1\0\0", &message_prefix, 8) == 0) {
+      return ReadNextMessage();
+    }
+    if (message_prefix.continuation_token != kContinuationToken) {
+      throw IOException(std::string("Expected continuation token (0xFFFFFFFF) but got " +
+                                    std::to_string(message_prefix.continuation_token)));
+    }
+  } catch (SerializationException&) {
+    finished = true;
+    return MessageType::UNINITIALIZED;
+  }
+  try {
+    return DecodeMessage();
+  } catch (SerializationException& e) {
+    throw IOException(std::string("SerializationException: ") + e.what());
+  }
+}
+
+bool IPCFileStreamReader::DecodeHeader(const idx_t message_header_size) {
+  if (message_header.size() < message_header_size) message_header.resize(message_header_size);
+  std::memcpy(message_header.data(), &message_prefix, sizeof(message_prefix));
+  ReadData(message_header.data() + sizeof(message_prefix), static_cast<idx_t>(message_prefix.metadata_size));
+  if (!ParseHeader(message_header.data(), message_header_size)) {
+    finished = true;
+    return true;
+  }
+  return false;
+}
+
+void IPCFileStreamReader::DecodeBody() {
+  cur_owner.reset();
+  cur_ptr = nullptr;
+  cur_size = 0;
+  if (message.body_length > 0) {
+    EnsureInputStreamAligned();
+    cur_body_offset = offset;
+    if (skip_record_batch_body && message.type == MessageType::RECORD_BATCH) {
+      if (offset + message.body_length > file_size) throw SerializationException();
+      offset += message.body_length;  // step over the body without reading it
+      return;
+    }
+    uint8_t* p = nullptr;
+    cur_owner = body_allocator ? body_allocator(static_cast<size_t>(message.body_length), message.type, &p)
+                               : DefaultBodyAlloc(static_cast<size_t>(message.body_length), message.type, &p);
+    ReadData(p, static_cast<idx_t>(message.body_length));
+    cur_ptr = p;
+    cur_size = message.body_length;
+  } else {
+    cur_body_offset = offset;
+  }
+}
+
+void IPCFileStreamReader::Seek(int64_t prefix_offset) {
+  offset = prefix_offset;
+  finished = false;
+}
+
+const std::vector<BatchIndexEntry>& IPCFileStreamReader::BuildIndex() {
+  if (index_built) return index;
+  GetBaseSchema();
+  int64_t saved = offset;
+  bool saved_finished = finished;
+  // Walk headers only; bodies are skipped (the stream format has no footer index: SURVEY "Hard parts")
+  std::vector<uint8_t> meta;
+  int64_t pos = offset;
+  while (true) {
+    pos = (pos + 7) & ~static_cast<int64_t>(7);
+    if (pos + 8 > file_size) break;
+    ArrowIpcMessagePrefix p;
+    offset = pos;
+    try {
+      ReadData(reinterpret_cast<uint8_t*>(&p), 8);
+    } catch (SerializationException&) { break; }
+    if (p.continuation_token != kContinuationToken || p.metadata_size <= 0) break;
+    if (pos + 8 + p.metadata_size > file_size) break;
+    meta.resize(static_cast<size_t>(p.metadata_size));
+    ReadData(meta.data(), static_cast<idx_t>(p.metadata_size));
+    MessageHeader h = DecodeMessageHeader(meta.data(), p.metadata_size);
+    BatchIndexEntry e{pos, p.metadata_size, static_cast<int32_t>(h.type), 0, h.body_length, 0};
+    int64_t body = (offset + 7) & ~static_cast<int64_t>(7);
+    e.body_offset = body;
+    if (body + h.body_length > file_size) break;
+    if (h.type == MessageType::RECORD_BATCH || h.type == MessageType::DICTIONARY_BATCH)
+      e.n_rows = DecodeRecordBatch(meta.data(), p.metadata_size).length;
+    index.push_back(e);
+    pos = body + h.body_length;
+  }
+  offset = saved;
+  finished = saved_finished;
+  index_built = true;
+  return index;
+}
+
+// ------------------------------------------------------------------------------------------------ buffer reader
+IPCBufferStreamReader::IPCBufferStreamReader(std::vector<ArrowIPCBuffer> buffers_p) : buffers(std::move(buffers_p)) {}
+
+const uint8_t* IPCBufferStreamReader::ReadData(idx_t size) {
+  // the reference only asserts (ipc_buffer_stream_reader.cpp:37); a short buffer is reported instead of read past
+  if (cur_buffer.pos + static_cast<int64_t>(size) > cur_buffer.size) {
+    throw IOException("Unexpected end of Arrow IPC buffer: need " + std::to_string(size) + " bytes at position " +
+                      std::to_string(cur_buffer.pos) + " of " + std::to_string(cur_buffer.size));
+  }
+  const uint8_t* p = cur_buffer.ptr + cur_buffer.pos;
+  cur_buffer.pos += static_cast<int64_t>(size);
+  return p;
+}
+
+MessageType IPCBufferStreamReader::ReadNextMessage() {
+  if ((!initialized && cur_idx == buffers.size()) || finished) {
+    finished = true;
+    return MessageType::UNINITIALIZED;
+  }
+  if (!initialized || cur_buffer.pos >= cur_buffer.size) {
+    if (initialized) cur_idx++;
+    if (cur_idx >= buffers.size()) {
+      finished = true;
+      return MessageType::UNINITIALIZED;
+    }
+    cur_buffer.ptr = reinterpret_cast<const uint8_t*>(static_cast<uintptr_t>(buffers[cur_idx].ptr));
+    cur_buffer.size = static_cast<int64_t>(buffers[cur_idx].size);
+    cur_buffer.pos = 0;
+    initialized = true;
+  }
+  std::memcpy(&message_prefix, ReadData(sizeof(message_prefix)), sizeof(message_prefix));
+  // An IPC *file* handed over as a buffer: skip the magic like the file reader does (ipc_file_stream_reader.cpp:116-119).
+  // The reference's buffer reader has no such case; accepting it is a superset.
+  if (cur_buffer.pos == 8 && cur_idx == 0 && std::memcmp("ARROW1\0\0", &message_prefix, 8) == 0) {
+    return ReadNextMessage();
+  }
+  if (message_prefix.continuation_token != kContinuationToken) {
+    throw IOException(std::string("Expected continuation token (0xFFFFFFFF) but got " +
+                                  std::to_string(message_prefix.continuation_token)));
+  }
+  return DecodeMessage();
+}
+
+bool IPCBufferStreamReader::DecodeHeader(idx_t message_header_size) {
+  // Our Header must contain the message prefix
+  const uint8_t* header = ReadData(static_cast<idx_t>(message_prefix.metadata_size)) - sizeof(message_prefix);
+  if (!ParseHeader(header, message_header_size)) {
+    finished = true;
+    return true;
+  }
+  return false;
+}
+
+void IPCBufferStreamReader::DecodeBody() {
+  cur_owner.reset();
+  if (message.body_length > 0) {
+    // bodies are 8-byte aligned relative to the start of the stream
+    int64_t aligned = (cur_buffer.pos + 7) & ~static_cast<int64_t>(7);
+    if (aligned != cur_buffer.pos) ReadData(static_cast<idx_t>(aligned - cur_buffer.pos));
+    cur_body_offset = cur_buffer.pos;
+    cur_ptr = ReadData(static_cast<idx_t>(message.body_length));
+    cur_size = message.body_length;
+  } else {
+    cur_body_offset = cur_buffer.pos;
+    cur_ptr = nullptr;
+    cur_size = 0;
+  }
+}
+
+double IPCBufferStreamReader::GetProgress() {
+  if (buffers.empty()) return 100;
+  double done = static_cast<double>(cur_idx);
+  if (cur_buffer.size > 0 && cur_idx < buffers.size()) done += static_cast<double>(cur_buffer.pos) / static_cast<double>(cur_buffer.size);
+  return std::min(100.0, 100.0 * done / static_cast<double>(buffers.size()));
+}
+
+const std::vector<BatchIndexEntry>& IPCBufferStreamReader::BuildIndex() {
+  if (index_built) return index;
+  GetBaseSchema();
+  // header walk over every buffer from the current position, without touching reader state
+  int64_t global_base = 0;
+  for (idx_t b = 0; b < buffers.size(); b++) {
+    const uint8_t* base = reinterpret_cast<const uint8_t*>(static_cast<uintptr_t>(buffers[b].ptr));
+    int64_t size = static_cast<int64_t>(buffers[b].size);
+    int64_t pos = 0;
+    if (b < cur_idx) { global_base += size; continue; }
+    if (b == cur_idx && initialized) pos = cur_buffer.pos;
+    if (pos == 0 && b == 0 && size >= 8 && std::memcmp("ARROW1\0\0", base, 8) == 0) pos = 8;
+    while (pos + 8 <= size) {
+      ArrowIpcMessagePrefix p;
+      std::memcpy(&p, base + pos, 8);
+      if (p.continuation_token != kContinuationToken || p.metadata_size <= 0) break;
+      if (pos + 8 + p.metadata_size > size) break;
+      MessageHeader h = DecodeMessageHeader(base + pos + 8, p.metadata_size);
+      int64_t body = (pos + 8 + p.metadata_size + 7) & ~static_cast<int64_t>(7);
+      if (body + h.body_length > size) break;
+      BatchIndexEntry e{global_base + pos, p.metadata_size, static_cast<int32_t>(h.type), global_base + body, h.body_length, 0};
+      if (h.type == MessageType::RECORD_BATCH || h.type == MessageType::DICTIONARY_BATCH)
+        e.n_rows = DecodeRecordBatch(base + pos + 8, p.metadata_size).length;
+      index.push_back(e);
+      pos = body + h.body_length;
+    }
+    global_base += size;
+  }
+  index_built = true;
+  return index;
+}
+
+}  // namespace miarrow

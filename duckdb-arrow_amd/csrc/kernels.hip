@@ -1,0 +1,788 @@
+// kernels.hip -- hand-written gfx950 (CDNA4) kernels for the Arrow IPC <-> DuckDB vector transcode.
+//
+// Everything here is HBM-bound integer / byte work ("no MFMA"): the design rules that matter are
+// coalesced 16-byte-per-lane accesses, enough bytes in flight per CU, a handful of launches over a device-resident
+// task table for ANY number of record batches (a 122880-row record batch is ~40 MB of traffic = ~7 us at HBM speed,
+// so per-column-per-batch launches would be launch-bound), and a persistent grid of 8 x 256-thread workgroups per CU
+// that strides over 2048-row tiles.
+//
+// One TILE = 2048 rows of one column of one record batch = exactly one DuckDB vector (STANDARD_VECTOR_SIZE), so
+// tile t of a column writes vector t: data at out_data + t*2048*width, validity words at out_validity + t*32.
+// Tiles are numbered across all tasks of a kernel class; workgroup b handles tiles b, b+G, b+2G, ... so that at any
+// moment the resident workgroups stream adjacent tiles (adjacent HBM pages / channels).  Workgroups b and b+8 share
+// an XCD (and its L2); neighbouring tiles only share the cache lines at their seams, so no XCD remap is needed.
+//
+// Kernel classes: each class is its own kernel so that it gets the register budget of its own inner loop (a single
+// switch over all kinds needed 154 VGPRs = 3 waves/SIMD).  A plan groups its tasks by class (engine.cpp).
+//
+// Semantics restated per kernel from DuckDB's ArrowToDuckDB / ArrowAppender (call sites in the reference:
+// src/scanner/scan_arrow_ipc.cpp:56, src/file_scanner/arrow_file_scan.cpp:68-72,
+// src/writer/column_data_collection_serializer.cpp:85); canonical values for slots upstream leaves undefined:
+// NULL rows of converted columns = 0, validity pad bits = 1.
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+
+namespace miarrow {
+namespace device {
+
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// Pointers inside a task descriptor are loaded from memory, so the compiler only knows them as generic ("flat")
+// addresses.  Everything they point to is HBM: casting to the global address space turns flat_load/flat_store into
+// global_load/global_store (no LDS aperture check, vmcnt-only accounting).
+template <typename T>
+using gptr = T __attribute__((address_space(1)))*;
+template <typename T>
+__device__ __forceinline__ gptr<const T> GC(const void* p) {
+  return (gptr<const T>)p;
+}
+template <typename T>
+__device__ __forceinline__ gptr<T> GM(void* p) {
+  return (gptr<T>)p;
+}
+
+__device__ __forceinline__ void raise(uint32_t* status, uint32_t bits) {
+  if (bits) atomicOr(status, bits);
+}
+
+// Row validity straight from the Arrow bitmap (bit = 1 valid). null_count == 0 => bitmap ignored (GetValidityMask).
+__device__ __forceinline__ bool row_valid(gptr<const uint8_t> bitmap, bool has_nulls, int64_t bit) {
+  if (!has_nulls) return true;
+  return (bitmap[bit >> 3] >> (bit & 7)) & 1;
+}
+
+// Finds the task that owns a tile: largest i with tile_begin[i] <= tile.  The tile index is wave-uniform, so the
+// search runs on the scalar unit (s_load) and the task descriptor lands in SGPRs.
+__device__ __forceinline__ int find_task(const uint32_t* __restrict__ tile_begin, int n_tasks, uint32_t tile) {
+  int lo = 0, hi = n_tasks;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tile_begin[mid] <= tile) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+#define MI_TILE_PROLOGUE()                                                                          \
+  const int ti = __builtin_amdgcn_readfirstlane(find_task(tile_begin, n_tasks, tile));             \
+  const mi_col_task& t = tasks[ti];                                                                 \
+  const int64_t row0 = static_cast<int64_t>(tile - tile_begin[ti]) * kTileRows;                     \
+  const int64_t left = t.nrows - row0;                                                              \
+  const int n = left < kTileRows ? static_cast<int>(left) : kTileRows;
+
+// ---------------------------------------------------------------------------------------------------- K1
+// Validity bitmap -> DuckDB validity_t words for one tile.  Word w of the tile holds rows [64w, 64w+64); the source
+// bit position is row_offset + row0 + 64w, realigned with a 64-bit funnel shift when it is not word aligned (the CPU
+// path's "copy n+1 bytes and shift right by o%8").  The first ceil(n/64) <= 32 lanes do the work.
+__device__ __forceinline__ void tile_validity(const mi_col_task& t, int64_t row0, int n) {
+  if (t.out_validity == nullptr) return;
+  const int lane = threadIdx.x;
+  const int nwords = (n + 63) >> 6;
+  if (lane >= nwords) return;
+  uint64_t w = ~0ull;
+  if (t.validity != nullptr && t.null_count != 0) {
+    gptr<const uint64_t> W = GC<uint64_t>(t.validity);
+    const int64_t bit = t.row_offset + row0 + 64 * lane;
+    const int64_t q = bit >> 6;
+    const int sh = static_cast<int>(bit & 63);
+    const int64_t last_q = (t.row_offset + t.nrows - 1) >> 6;  // last 8-byte word that holds a bit of this column
+    const uint64_t lo = W[q];
+    const uint64_t hi = (sh != 0 && q + 1 <= last_q) ? W[q + 1] : 0ull;
+    w = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+  }
+  const int rem = n - 64 * lane;
+  if (rem < 64) w |= ~0ull << rem;  // canonical pad bits
+  GM<uint64_t>(t.out_validity)[(row0 >> 6) + lane] = w;
+}
+
+// ---------------------------------------------------------------------------------------------------- K3a
+// Fixed-width direct conversion: a coalesced copy of n*width bytes.  The destination is 16-byte aligned (tiles start
+// at multiples of 2048 rows of a 16-byte aligned vector); the source is an IPC buffer, 8-byte aligned, so it takes
+// either the 16-byte or the 8-byte lane path (wave-uniform choice).
+template <typename V>
+__device__ __forceinline__ void copy_vec(gptr<const uint8_t> src, gptr<uint8_t> dst, int bytes) {
+  constexpr int VB = sizeof(V);
+  const int nvec = bytes / VB;
+  gptr<const V> s = (gptr<const V>)src;
+  gptr<V> d = (gptr<V>)dst;
+  int i = threadIdx.x;
+  // 4 independent loads in flight per lane before the first store
+#pragma clang loop unroll(disable)
+  for (; i + 3 * kBlockThreads < nvec; i += 4 * kBlockThreads) {
+    V a = s[i], b = s[i + kBlockThreads], c = s[i + 2 * kBlockThreads], e = s[i + 3 * kBlockThreads];
+    d[i] = a;
+    d[i + kBlockThreads] = b;
+    d[i + 2 * kBlockThreads] = c;
+    d[i + 3 * kBlockThreads] = e;
+  }
+#pragma clang loop unroll(disable)
+  for (; i < nvec; i += kBlockThreads) d[i] = s[i];
+#pragma clang loop unroll(disable) vectorize(disable)
+  for (int j = nvec * VB + threadIdx.x; j < bytes; j += kBlockThreads) dst[j] = src[j];
+}
+
+__device__ __forceinline__ void copy_bytes(gptr<const uint8_t> src, gptr<uint8_t> dst, int bytes) {
+  const uintptr_t a = reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst);
+  if ((a & 15) == 0) copy_vec<u32x4>(src, dst, bytes);
+  else if ((a & 7) == 0) copy_vec<u32x2>(src, dst, bytes);
+  else if ((a & 3) == 0) copy_vec<uint32_t>(src, dst, bytes);
+  else copy_vec<uint8_t>(src, dst, bytes);
+}
+
+__global__ __launch_bounds__(kBlockThreads) void transcode_copy(const mi_col_task* __restrict__ tasks,
+                                                                const uint32_t* __restrict__ tile_begin, int n_tasks,
+                                                                uint32_t total_tiles, uint32_t* __restrict__ status) {
+  for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    MI_TILE_PROLOGUE();
+    tile_validity(t, row0, n);
+    const int w = static_cast<int>(t.param);
+    copy_bytes(GC<uint8_t>(t.buf1) + (t.row_offset + row0) * w, GM<uint8_t>(t.out_data) + row0 * w, n * w);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- K3b
+// decimal128 {u64 lower, i64 upper} -> int16/32/64 for valid rows (Hugeint::TryCast: value fits by precision);
+// NULL rows canonical 0.  Each lane reads the whole 16-byte value (the upper half is what proves the range).
+template <typename OUT>
+__device__ __forceinline__ void tile_dec128(const mi_col_task& t, int64_t row0, int n, uint32_t* status) {
+  gptr<const uint8_t> src = GC<uint8_t>(t.buf1) + (t.row_offset + row0) * 16;
+  gptr<OUT> out = GM<OUT>(t.out_data) + row0;
+  gptr<const uint8_t> bitmap = GC<uint8_t>(t.validity);
+  const bool has_nulls = t.validity != nullptr && t.null_count != 0;
+  const bool a16 = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+  uint32_t err = 0;
+#pragma unroll 4
+  for (int r = threadIdx.x; r < n; r += kBlockThreads) {
+    uint64_t lower;
+    int64_t upper;
+    if (a16) {
+      const u32x4 v = *(gptr<const u32x4>)(src + 16 * static_cast<int64_t>(r));
+      lower = static_cast<uint64_t>(v.x) | (static_cast<uint64_t>(v.y) << 32);
+      upper = static_cast<int64_t>(static_cast<uint64_t>(v.z) | (static_cast<uint64_t>(v.w) << 32));
+    } else {
+      gptr<const uint64_t> p = (gptr<const uint64_t>)(src + 16 * static_cast<int64_t>(r));
+      lower = p[0];
+      upper = static_cast<int64_t>(p[1]);
+    }
+    OUT o = 0;
+    if (row_valid(bitmap, has_nulls, t.row_offset + row0 + r)) {
+      o = static_cast<OUT>(lower);
+      const int64_t sext = static_cast<int64_t>(o);
+      if (static_cast<uint64_t>(sext) != lower || upper != (sext >> 63)) err = MI_ST_DECIMAL_RANGE;
+    }
+    out[r] = o;
+  }
+  raise(status, err);
+}
+
+__global__ __launch_bounds__(kBlockThreads) void transcode_dec128(const mi_col_task* __restrict__ tasks,
+                                                                  const uint32_t* __restrict__ tile_begin, int n_tasks,
+                                                                  uint32_t total_tiles, uint32_t* __restrict__ status) {
+  for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    MI_TILE_PROLOGUE();
+    tile_validity(t, row0, n);
+    if (t.param == 8) tile_dec128<int64_t>(t, row0, n, status);
+    else if (t.param == 4) tile_dec128<int32_t>(t, row0, n, status);
+    else tile_dec128<int16_t>(t, row0, n, status);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- K4
+// Builds one string_t from payload bytes [a, a+len) of `data`.  The payload is fetched as aligned dwords and
+// realigned with v_alignbyte_b32 (IPC buffers are 8-byte aligned and padded to 8, so the aligned dword that holds
+// the last payload byte is always readable).  len <= 12: 12 inline bytes, zero padded.  Else 4-byte prefix + pointer.
+__device__ __forceinline__ u32x4 make_string_t(gptr<const uint8_t> data, int64_t a, uint32_t len, uint64_t ptr_base) {
+  const uint32_t take = len <= 12 ? len : 4;  // payload bytes that go into the struct
+  const uint32_t mis = static_cast<uint32_t>(a & 3);
+  gptr<const uint32_t> q = (gptr<const uint32_t>)(data + (a - mis));
+  const uint32_t nwords = take ? (mis + take + 3) >> 2 : 0;  // 0..4 aligned dwords cover the payload
+  const uint32_t w0 = nwords > 0 ? q[0] : 0;
+  const uint32_t w1 = nwords > 1 ? q[1] : 0;
+  const uint32_t w2 = nwords > 2 ? q[2] : 0;
+  const uint32_t w3 = nwords > 3 ? q[3] : 0;
+  const uint32_t o0 = __builtin_amdgcn_alignbyte(w1, w0, mis);
+  const uint32_t o1 = __builtin_amdgcn_alignbyte(w2, w1, mis);
+  const uint32_t o2 = __builtin_amdgcn_alignbyte(w3, w2, mis);
+  u32x4 s;
+  s.x = len;
+  if (len <= 12) {
+    // zero the bytes past len
+    const uint32_t k0 = len >= 4 ? 4 : len, k1 = len >= 8 ? 4 : (len > 4 ? len - 4 : 0), k2 = len > 8 ? len - 8 : 0;
+    s.y = k0 == 4 ? o0 : (o0 & ((1u << (8 * k0)) - 1u));
+    s.z = k1 == 4 ? o1 : (o1 & ((1u << (8 * k1)) - 1u));
+    s.w = k2 == 4 ? o2 : (o2 & ((1u << (8 * k2)) - 1u));
+  } else {
+    const uint64_t p = ptr_base + static_cast<uint64_t>(a);
+    s.y = o0;
+    s.z = static_cast<uint32_t>(p);
+    s.w = static_cast<uint32_t>(p >> 32);
+  }
+  return s;
+}
+
+// utf8 / binary with int32 or int64 offsets.  Lane r reads off[r], off[r+1] (coalesced; the second read hits L1),
+// validates them like NANOARROW_VALIDATION_LEVEL_FULL, and stores one 16-byte string_t (1 KiB per wave store).
+template <typename OFF>
+__device__ __forceinline__ void tile_string(const mi_col_task& t, int64_t row0, int n, uint32_t* status) {
+  gptr<const OFF> off = GC<OFF>(t.buf1) + t.row_offset + row0;
+  gptr<const uint8_t> data = GC<uint8_t>(t.buf2);
+  gptr<u32x4> out = GM<u32x4>(t.out_data) + row0;
+  gptr<const uint8_t> bitmap = GC<uint8_t>(t.validity);
+  const bool has_nulls = t.validity != nullptr && t.null_count != 0;
+  const int64_t data_len = t.buf2_len;
+  uint32_t err = 0;
+#pragma unroll 2
+  for (int r = threadIdx.x; r < n; r += kBlockThreads) {
+    const int64_t a = static_cast<int64_t>(off[r]);
+    const int64_t b = static_cast<int64_t>(off[r + 1]);
+    u32x4 s = {0u, 0u, 0u, 0u};
+    const bool sane = a >= 0 && b >= a && b <= data_len;
+    if (!sane) {
+      err |= MI_ST_BAD_OFFSETS;
+    } else if (sizeof(OFF) == 8 && b > 0xFFFFFFFFll) {
+      err |= MI_ST_STRING_TOO_LARGE;  // "DuckDB does not support Strings over 4GB"
+    } else if (row_valid(bitmap, has_nulls, t.row_offset + row0 + r)) {
+      s = make_string_t(data, a, static_cast<uint32_t>(b - a), t.ptr_base);
+    }
+    out[r] = s;
+  }
+  raise(status, err);
+}
+
+// fixed_size_binary(width) -> string_t
+__device__ __forceinline__ void tile_fixed_binary(const mi_col_task& t, int64_t row0, int n) {
+  gptr<const uint8_t> data = GC<uint8_t>(t.buf1);
+  gptr<u32x4> out = GM<u32x4>(t.out_data) + row0;
+  gptr<const uint8_t> bitmap = GC<uint8_t>(t.validity);
+  const bool has_nulls = t.validity != nullptr && t.null_count != 0;
+  const int64_t width = t.param;
+#pragma unroll 2
+  for (int r = threadIdx.x; r < n; r += kBlockThreads) {
+    u32x4 s = {0u, 0u, 0u, 0u};
+    if (row_valid(bitmap, has_nulls, t.row_offset + row0 + r))
+      s = make_string_t(data, (t.row_offset + row0 + r) * width, static_cast<uint32_t>(width), t.ptr_base);
+    out[r] = s;
+  }
+}
+
+__global__ __launch_bounds__(kBlockThreads) void transcode_string(const mi_col_task* __restrict__ tasks,
+                                                                  const uint32_t* __restrict__ tile_begin, int n_tasks,
+                                                                  uint32_t total_tiles, uint32_t* __restrict__ status) {
+  for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    MI_TILE_PROLOGUE();
+    tile_validity(t, row0, n);
+    if (t.kind == MI_K_STR32) tile_string<int32_t>(t, row0, n, status);
+    else if (t.kind == MI_K_STR64) tile_string<int64_t>(t, row0, n, status);
+    else tile_fixed_binary(t, row0, n);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- K2
+// Bit-packed bool -> one byte per row, all rows (valid or not).  Lane i expands rows [8i, 8i+8) = one source byte
+// (two when the bit offset is not byte aligned) into one 8-byte store.
+__device__ __forceinline__ void tile_bool(const mi_col_task& t, int64_t row0, int n) {
+  gptr<const uint8_t> bits = GC<uint8_t>(t.buf1);
+  gptr<uint8_t> out = GM<uint8_t>(t.out_data) + row0;
+  const int r = 8 * threadIdx.x;
+  if (r >= n) return;
+  const int64_t bit = t.row_offset + row0 + r;
+  const int64_t byte = bit >> 3;
+  const int sh = static_cast<int>(bit & 7);
+  const int64_t last_byte = (t.row_offset + t.nrows - 1) >> 3;
+  uint32_t b = bits[byte];
+  if (sh != 0 && byte + 1 <= last_byte) b |= static_cast<uint32_t>(bits[byte + 1]) << 8;
+  b = (b >> sh) & 0xFFu;
+  uint64_t y = (static_cast<uint64_t>(b) * 0x0101010101010101ull) & 0x8040201008040201ull;
+  y = ((y + 0x7F7F7F7F7F7F7F7Full) >> 7) & 0x0101010101010101ull;
+  if (r + 8 <= n) {
+    *(gptr<uint64_t>)(out + r) = y;
+  } else {
+    for (int k = 0; r + k < n; k++) out[r + k] = static_cast<uint8_t>(y >> (8 * k));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- K3c
+__device__ __forceinline__ void tile_date64(const mi_col_task& t, int64_t row0, int n) {
+  gptr<const int64_t> src = GC<int64_t>(t.buf1) + t.row_offset + row0;
+  gptr<int32_t> out = GM<int32_t>(t.out_data) + row0;
+#pragma unroll 4
+  for (int r = threadIdx.x; r < n; r += kBlockThreads) out[r] = static_cast<int32_t>(src[r] / 86400000ll);
+}
+
+__device__ __forceinline__ void tile_mul_i32(const mi_col_task& t, int64_t row0, int n) {
+  gptr<const int32_t> src = GC<int32_t>(t.buf1) + t.row_offset + row0;
+  gptr<int64_t> out = GM<int64_t>(t.out_data) + row0;
+  gptr<const uint8_t> bitmap = GC<uint8_t>(t.validity);
+  const bool has_nulls = t.validity != nullptr && t.null_count != 0;
+#pragma unroll 4
+  for (int r = threadIdx.x; r < n; r += kBlockThreads) {
+    const bool ok = row_valid(bitmap, has_nulls, t.row_offset + row0 + r);
+    out[r] = ok ? static_cast<int64_t>(src[r]) * t.param : 0;  // int32 * 1e6 cannot overflow int64
+  }
+}
+
+__device__ __forceinline__ void tile_mul_i64(const mi_col_task& t, int64_t row0, int n, uint32_t* status) {
+  gptr<const int64_t> src = GC<int64_t>(t.buf1) + t.row_offset + row0;
+  gptr<int64_t> out = GM<int64_t>(t.out_data) + row0;
+  gptr<const uint8_t> bitmap = GC<uint8_t>(t.validity);
+  const bool has_nulls = t.validity != nullptr && t.null_count != 0;
+  uint32_t err = 0;
+#pragma unroll 4
+  for (int r = threadIdx.x; r < n; r += kBlockThreads) {
+    int64_t v = 0;
+    if (row_valid(bitmap, has_nulls, t.row_offset + row0 + r)) {
+      if (__builtin_mul_overflow(src[r], t.param, &v)) {  // TryMultiplyOperator => ConversionException
+        v = 0;
+        err = MI_ST_MUL_OVERFLOW;
+      }
+    }
+    out[r] = v;
+  }
+  raise(status, err);
+}
+
+__device__ __forceinline__ void tile_div_i64(const mi_col_task& t, int64_t row0, int n) {
+  gptr<const int64_t> src = GC<int64_t>(t.buf1) + t.row_offset + row0;
+  gptr<int64_t> out = GM<int64_t>(t.out_data) + row0;
+  const int64_t d = t.param;
+#pragma unroll 4
+  for (int r = threadIdx.x; r < n; r += kBlockThreads) out[r] = src[r] / d;  // all rows, like upstream
+}
+
+__device__ __forceinline__ void tile_duration(const mi_col_task& t, int64_t row0, int n, uint32_t* status) {
+  gptr<const int64_t> src = GC<int64_t>(t.buf1) + t.row_offset + row0;
+  gptr<u32x4> out = GM<u32x4>(t.out_data) + row0;
+  gptr<const uint8_t> bitmap = GC<uint8_t>(t.validity);
+  const bool has_nulls = t.validity != nullptr && t.null_count != 0;
+  uint32_t err = 0;
+#pragma unroll 4
+  for (int r = threadIdx.x; r < n; r += kBlockThreads) {
+    int64_t micros = 0;
+    if (t.param < 0) {
+      micros = src[r] / (-t.param);
+    } else if (row_valid(bitmap, has_nulls, t.row_offset + row0 + r)) {
+      if (__builtin_mul_overflow(src[r], t.param, &micros)) {
+        micros = 0;
+        err = MI_ST_MUL_OVERFLOW;
+      }
+    }
+    u32x4 o;
+    o.x = 0;  // months
+    o.y = 0;  // days
+    o.z = static_cast<uint32_t>(static_cast<uint64_t>(micros));
+    o.w = static_cast<uint32_t>(static_cast<uint64_t>(micros) >> 32);
+    out[r] = o;
+  }
+  raise(status, err);
+}
+
+// ---------------------------------------------------------------------------------------------------- K5
+// Dictionary indices -> sel_t; NULL -> dict_len (the extra NULL slot of the decoded dictionary).
+__device__ __forceinline__ void tile_dict(const mi_col_task& t, int64_t row0, int n, uint32_t* status) {
+  const int iw = static_cast<int>(t.param & 0xFF);
+  const bool is_signed = ((t.param >> 8) & 1) != 0;
+  gptr<const uint8_t> idx = GC<uint8_t>(t.buf1) + (t.row_offset + row0) * iw;
+  gptr<uint32_t> out = GM<uint32_t>(t.out_data) + row0;
+  gptr<const uint8_t> bitmap = GC<uint8_t>(t.validity);
+  const bool has_nulls = t.validity != nullptr && t.null_count != 0;
+  const uint32_t dict_len = static_cast<uint32_t>(t.param2);
+  uint32_t err = 0;
+#pragma unroll 4
+  for (int r = threadIdx.x; r < n; r += kBlockThreads) {
+    uint32_t sel = dict_len;
+    if (row_valid(bitmap, has_nulls, t.row_offset + row0 + r)) {
+      uint64_t v;
+      switch (iw) {
+        case 1: v = is_signed ? static_cast<uint64_t>(static_cast<int64_t>(((gptr<const int8_t>)idx)[r])) : idx[r]; break;
+        case 2: v = is_signed ? static_cast<uint64_t>(static_cast<int64_t>(((gptr<const int16_t>)idx)[r]))
+                              : ((gptr<const uint16_t>)idx)[r]; break;
+        case 4: v = is_signed ? static_cast<uint64_t>(static_cast<int64_t>(((gptr<const int32_t>)idx)[r]))
+                              : ((gptr<const uint32_t>)idx)[r]; break;
+        default: v = ((gptr<const uint64_t>)idx)[r]; break;
+      }
+      if (v > 0xFFFFFFFFull) {  // "DuckDB only supports indices that fit on an uint32"
+        err = MI_ST_INDEX_RANGE;
+        v = 0;
+      }
+      sel = static_cast<uint32_t>(v);
+    }
+    out[r] = sel;
+  }
+  raise(status, err);
+}
+
+__global__ __launch_bounds__(kBlockThreads) void transcode_misc(const mi_col_task* __restrict__ tasks,
+                                                                const uint32_t* __restrict__ tile_begin, int n_tasks,
+                                                                uint32_t total_tiles, uint32_t* __restrict__ status) {
+  for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    MI_TILE_PROLOGUE();
+    tile_validity(t, row0, n);
+    switch (t.kind) {
+      case MI_K_BOOL: tile_bool(t, row0, n); break;
+      case MI_K_DATE64: tile_date64(t, row0, n); break;
+      case MI_K_MUL_I32: tile_mul_i32(t, row0, n); break;
+      case MI_K_MUL_I64: tile_mul_i64(t, row0, n, status); break;
+      case MI_K_DIV_I64: tile_div_i64(t, row0, n); break;
+      case MI_K_DURATION: tile_duration(t, row0, n, status); break;
+      case MI_K_DICT: tile_dict(t, row0, n, status); break;
+      default: break;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- K6
+// Range filter lo <= v < hi AND valid -> ascending window-relative indices.  One workgroup per 2048-row window:
+// lane i owns rows [8i, 8i+8) (32 or 64 contiguous bytes), a wave-level + 4-wave LDS scan of the per-lane counts
+// gives each lane its output position, so the selection vector comes out sorted without a second pass.
+template <typename T>
+__global__ __launch_bounds__(kBlockThreads) void filter_range(const T* __restrict__ values,
+                                                              const uint64_t* __restrict__ validity, int64_t nrows,
+                                                              int64_t lo, int64_t hi, mi_sel_t* __restrict__ sel_out,
+                                                              uint32_t* __restrict__ count_out) {
+  __shared__ uint32_t wave_total[kBlockThreads / 64];
+  const int64_t row0 = static_cast<int64_t>(blockIdx.x) * kTileRows;
+  const int64_t left = nrows - row0;
+  const int n = left < kTileRows ? static_cast<int>(left) : kTileRows;
+  const int r = 8 * threadIdx.x;
+  uint32_t mask = 0;
+  if (r < n) {
+    const uint32_t vbits = validity ? static_cast<uint32_t>((validity[(row0 + r) >> 6] >> ((row0 + r) & 63)) & 0xFF) : 0xFFu;
+    const T* __restrict__ p = values + row0 + r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (r + k < n) {
+        const int64_t v = static_cast<int64_t>(p[k]);
+        if (v >= lo && v < hi && ((vbits >> k) & 1)) mask |= 1u << k;
+      }
+    }
+  }
+  const uint32_t cnt = __builtin_popcount(mask);
+  uint32_t incl = cnt;  // inclusive scan inside the wave
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
+  }
+  const int wave = threadIdx.x >> 6;
+  if (lane == 63) wave_total[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int w = 0; w < wave; w++) base += wave_total[w];
+  uint32_t pos = base + incl - cnt;
+  mi_sel_t* __restrict__ out = sel_out + row0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if ((mask >> k) & 1) out[pos++] = static_cast<mi_sel_t>(r + k);
+  }
+  if (threadIdx.x == kBlockThreads - 1) count_out[blockIdx.x] = base + incl;
+}
+
+// ==================================================================================================== K7 (encode)
+// DuckDB vectors -> Arrow buffers, ArrowAppender semantics.  Task fields for encode kinds:
+//   validity  = DuckDB validity words of the whole column (NULL = all valid)   buf1 = vector data
+//   buf2      = string heap base (long string_t pointers are ptr - ptr_base into it)
+//   out_validity = Arrow bitmap (ceil(n/8) bytes, always emitted, pad bits 1)  out_data = Arrow buffer 1
+//   out_aux   = Arrow buffer 2 (string data)          param2 = index of this task's null counter
+
+// K7a: DuckDB validity words have Arrow's bit order and polarity, so the bitmap is a byte copy of the words with
+// the pad bits of the last byte forced to 1 (ResizeValidity fills with 0xFF) and NULLs counted on the way.
+__device__ __forceinline__ void enc_tile_validity(const mi_col_task& t, int64_t row0, int n, int64_t* null_counts) {
+  const int lane = threadIdx.x;
+  const int nwords = (n + 63) >> 6;
+  if (lane >= nwords) return;
+  uint64_t w = ~0ull;
+  if (t.validity != nullptr) w = GC<uint64_t>(t.validity)[(row0 >> 6) + lane];
+  const int rem = n - 64 * lane;
+  if (rem < 64) w |= ~0ull << rem;
+  const int nulls = 64 - __builtin_popcountll(w);
+  if (nulls) atomicAdd(reinterpret_cast<unsigned long long*>(null_counts + t.param2), static_cast<unsigned long long>(nulls));
+  gptr<uint8_t> out = GM<uint8_t>(t.out_validity) + (row0 >> 3) + 8 * lane;
+  const int nbytes = rem >= 64 ? 8 : (rem + 7) >> 3;
+  if (nbytes == 8 && (reinterpret_cast<uintptr_t>(out) & 7) == 0) {
+    *(gptr<uint64_t>)out = w;
+  } else {
+    for (int k = 0; k < nbytes; k++) out[k] = static_cast<uint8_t>(w >> (8 * k));
+  }
+}
+
+__device__ __forceinline__ bool enc_row_valid(gptr<const uint64_t> v, bool has, int64_t row) {
+  return !has || ((v[row >> 6] >> (row & 63)) & 1);
+}
+
+// K7b: DECIMAL physical int16/32/64 -> decimal128 by sign extension, one 16-byte store per row
+template <typename IN>
+__device__ __forceinline__ void enc_tile_dec128(const mi_col_task& t, int64_t row0, int n) {
+  gptr<const IN> src = GC<IN>(t.buf1) + row0;
+  gptr<u32x4> out = GM<u32x4>(t.out_data) + row0;
+#pragma unroll 4
+  for (int r = threadIdx.x; r < n; r += kBlockThreads) {
+    const int64_t v = static_cast<int64_t>(src[r]);
+    const uint32_t sign = static_cast<uint32_t>(v >> 63);
+    u32x4 o;
+    o.x = static_cast<uint32_t>(static_cast<uint64_t>(v));
+    o.y = static_cast<uint32_t>(static_cast<uint64_t>(v) >> 32);
+    o.z = sign;
+    o.w = sign;
+    out[r] = o;
+  }
+}
+
+// K7c: byte bool -> bit; data bits start as 1, a valid false clears its bit, NULL rows keep 1
+__device__ __forceinline__ void enc_tile_bool(const mi_col_task& t, int64_t row0, int n) {
+  gptr<const uint8_t> src = GC<uint8_t>(t.buf1) + row0;
+  gptr<const uint64_t> valid = GC<uint64_t>(t.validity);
+  const bool has = t.validity != nullptr;
+  gptr<uint8_t> out = GM<uint8_t>(t.out_data) + (row0 >> 3);
+  const int r = 8 * threadIdx.x;
+  if (r >= n) return;
+  uint32_t b = 0xFF;
+  for (int k = 0; k < 8 && r + k < n; k++) {
+    if (enc_row_valid(valid, has, row0 + r + k) && src[r + k] == 0) b &= ~(1u << k);
+  }
+  out[threadIdx.x] = static_cast<uint8_t>(b);
+}
+
+__global__ __launch_bounds__(kBlockThreads) void encode_fixed(const mi_col_task* __restrict__ tasks,
+                                                              const uint32_t* __restrict__ tile_begin, int n_tasks,
+                                                              uint32_t total_tiles, int64_t* __restrict__ null_counts) {
+  for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    MI_TILE_PROLOGUE();
+    enc_tile_validity(t, row0, n, null_counts);
+    switch (t.kind) {
+      case MI_K_ENC_COPY: {  // NULL slots copy whatever the source slot holds, like ArrowScalarData::Append
+        const int w = static_cast<int>(t.param);
+        copy_bytes(GC<uint8_t>(t.buf1) + row0 * w, GM<uint8_t>(t.out_data) + row0 * w, n * w);
+        break;
+      }
+      case MI_K_ENC_DEC128:
+        if (t.param == 8) enc_tile_dec128<int64_t>(t, row0, n);
+        else if (t.param == 4) enc_tile_dec128<int32_t>(t, row0, n);
+        else enc_tile_dec128<int16_t>(t, row0, n);
+        break;
+      case MI_K_ENC_BOOL: enc_tile_bool(t, row0, n); break;
+      default: break;
+    }
+  }
+}
+
+// block-wide exclusive scan of one value per thread (4 waves); returns the exclusive prefix, *total = block sum
+__device__ __forceinline__ int64_t block_exclusive_scan(int64_t v, int64_t* total, int64_t* lds4) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int64_t incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int64_t up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
+  }
+  if (lane == 63) lds4[wave] = incl;
+  __syncthreads();
+  int64_t base = 0, sum = 0;
+  for (int w = 0; w < kBlockThreads / 64; w++) {
+    if (w < wave) base += lds4[w];
+    sum += lds4[w];
+  }
+  *total = sum;
+  __syncthreads();
+  return base + incl - v;
+}
+
+// K7d pass 1: payload bytes per tile (valid rows only) -> tile_sums[tile]
+__global__ __launch_bounds__(kBlockThreads) void encode_string_tile_sums(const mi_col_task* __restrict__ tasks,
+                                                                         const uint32_t* __restrict__ tile_begin,
+                                                                         int n_tasks, uint32_t total_tiles,
+                                                                         int64_t* __restrict__ tile_sums) {
+  __shared__ int64_t lds4[kBlockThreads / 64];
+  for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    MI_TILE_PROLOGUE();
+    gptr<const uint32_t> lens = GC<uint32_t>(t.buf1) + 4 * row0;  // string_t.length every 16 B
+    gptr<const uint64_t> valid = GC<uint64_t>(t.validity);
+    const bool has = t.validity != nullptr;
+    int64_t local = 0;
+    for (int r = threadIdx.x; r < n; r += kBlockThreads)
+      if (enc_row_valid(valid, has, row0 + r)) local += lens[4 * r];
+    int64_t total;
+    block_exclusive_scan(local, &total, lds4);
+    if (threadIdx.x == 0) tile_sums[tile] = total;
+  }
+}
+
+// K7d pass 2: per task, exclusive scan of its tiles' sums (in place) + INT32_MAX overflow check.  One workgroup
+// per task; a 122880-row batch has 60 tiles, so this is a handful of waves.
+__global__ __launch_bounds__(kBlockThreads) void encode_string_scan(const mi_col_task* __restrict__ tasks,
+                                                                    const uint32_t* __restrict__ tile_begin,
+                                                                    int n_tasks, int64_t* __restrict__ tile_sums,
+                                                                    uint32_t* __restrict__ status) {
+  __shared__ int64_t lds4[kBlockThreads / 64];
+  for (int ti = blockIdx.x; ti < n_tasks; ti += gridDim.x) {
+    const uint32_t first = tile_begin[ti], last = tile_begin[ti + 1];
+    int64_t carry = 0;
+    for (uint32_t base = first; base < last; base += kBlockThreads) {
+      const uint32_t i = base + threadIdx.x;
+      const int64_t v = i < last ? tile_sums[i] : 0;
+      int64_t total;
+      const int64_t ex = block_exclusive_scan(v, &total, lds4);
+      if (i < last) tile_sums[i] = carry + ex;
+      carry += total;
+    }
+    if (threadIdx.x == 0 && carry > 0x7FFFFFFFll) atomicOr(status, MI_ST_OFFSET_OVERFLOW);
+  }
+}
+
+// K7d pass 3: offsets + payload.  Lane i owns rows [8i, 8i+8) of the tile so one block scan orders the whole tile;
+// off[r+1] = tile base + inclusive length sum, NULL rows repeat the previous offset, payload bytes are gathered from
+// the inline field or from the heap behind the string_t pointer.
+__global__ __launch_bounds__(kBlockThreads) void encode_string(const mi_col_task* __restrict__ tasks,
+                                                               const uint32_t* __restrict__ tile_begin, int n_tasks,
+                                                               uint32_t total_tiles, const int64_t* __restrict__ tile_sums,
+                                                               int64_t* __restrict__ null_counts) {
+  __shared__ int64_t lds4[kBlockThreads / 64];
+  for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    MI_TILE_PROLOGUE();
+    enc_tile_validity(t, row0, n, null_counts);
+    gptr<const u32x4> str = GC<u32x4>(t.buf1) + row0;
+    gptr<const uint64_t> valid = GC<uint64_t>(t.validity);
+    const bool has = t.validity != nullptr;
+    gptr<const uint8_t> heap = GC<uint8_t>(t.buf2);
+    gptr<int32_t> off = GM<int32_t>(t.out_data);
+    gptr<uint8_t> data = GM<uint8_t>(t.out_aux);
+    const int r0 = 8 * threadIdx.x;
+    int64_t local = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int r = r0 + k;
+      if (r < n && enc_row_valid(valid, has, row0 + r)) local += ((gptr<const uint32_t>)(str + r))[0];
+    }
+    int64_t total;
+    int64_t pos = tile_sums[tile] + block_exclusive_scan(local, &total, lds4);
+    if (row0 == 0 && threadIdx.x == 0) off[0] = 0;
+#pragma clang loop unroll(disable)
+    for (int k = 0; k < 8; k++) {
+      const int r = r0 + k;
+      if (r >= n) break;
+      if (enc_row_valid(valid, has, row0 + r)) {
+        const u32x4 s = str[r];
+        const uint32_t l = s.x;
+        gptr<uint8_t> dst = data + pos;
+        if (l <= 12) {
+          const uint32_t w[3] = {s.y, s.z, s.w};
+#pragma clang loop unroll(disable) vectorize(disable)
+          for (uint32_t j = 0; j < l; j++) dst[j] = static_cast<uint8_t>(w[j >> 2] >> (8 * (j & 3)));
+        } else {
+          const uint64_t p = static_cast<uint64_t>(s.z) | (static_cast<uint64_t>(s.w) << 32);
+          gptr<const uint8_t> src = heap + (p - t.ptr_base);
+#pragma clang loop unroll(disable) vectorize(disable)
+          for (uint32_t j = 0; j < l; j++) dst[j] = src[j];
+        }
+        pos += l;
+      }
+      off[row0 + r + 1] = static_cast<int32_t>(pos);
+    }
+  }
+}
+
+inline uint32_t grid_for(uint32_t total_tiles, int grid_blocks) {
+  return total_tiles < static_cast<uint32_t>(grid_blocks) ? total_tiles : static_cast<uint32_t>(grid_blocks);
+}
+
+}  // namespace
+
+int ClassOfKind(int32_t kind) {
+  switch (kind) {
+    case MI_K_COPY: return kClassCopy;
+    case MI_K_DEC128: return kClassDec128;
+    case MI_K_STR32: case MI_K_STR64: case MI_K_FIXED_BINARY: return kClassString;
+    case MI_K_BOOL: case MI_K_DATE64: case MI_K_MUL_I32: case MI_K_MUL_I64: case MI_K_DIV_I64: case MI_K_DURATION:
+    case MI_K_DICT: return kClassMisc;
+    case MI_K_ENC_COPY: case MI_K_ENC_DEC128: case MI_K_ENC_BOOL: return kClassEncFixed;
+    case MI_K_ENC_STR32: return kClassEncString;
+    default: return -1;
+  }
+}
+
+hipError_t LaunchTranscode(int cls, const mi_col_task* d_tasks, const uint32_t* d_tile_begin, int32_t n_tasks,
+                           uint32_t total_tiles, uint32_t* d_status, int grid_blocks, hipStream_t stream) {
+  if (total_tiles == 0) return hipSuccess;
+  const dim3 grid(grid_for(total_tiles, grid_blocks)), block(kBlockThreads);
+  switch (cls) {
+    case kClassCopy:
+      hipLaunchKernelGGL(transcode_copy, grid, block, 0, stream, d_tasks, d_tile_begin, n_tasks, total_tiles, d_status);
+      break;
+    case kClassDec128:
+      hipLaunchKernelGGL(transcode_dec128, grid, block, 0, stream, d_tasks, d_tile_begin, n_tasks, total_tiles, d_status);
+      break;
+    case kClassString:
+      hipLaunchKernelGGL(transcode_string, grid, block, 0, stream, d_tasks, d_tile_begin, n_tasks, total_tiles, d_status);
+      break;
+    case kClassMisc:
+      hipLaunchKernelGGL(transcode_misc, grid, block, 0, stream, d_tasks, d_tile_begin, n_tasks, total_tiles, d_status);
+      break;
+    default:
+      return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t LaunchFilterRange(const void* values, int32_t width, const void* validity, int64_t nrows, int64_t lo,
+                             int64_t hi, mi_sel_t* sel_out, uint32_t* count_out, hipStream_t stream) {
+  if (nrows <= 0) return hipSuccess;
+  const uint32_t grid = static_cast<uint32_t>((nrows + kTileRows - 1) / kTileRows);
+  const uint64_t* v = static_cast<const uint64_t*>(validity);
+  switch (width) {
+    case 4:
+      hipLaunchKernelGGL(filter_range<int32_t>, dim3(grid), dim3(kBlockThreads), 0, stream,
+                         static_cast<const int32_t*>(values), v, nrows, lo, hi, sel_out, count_out);
+      break;
+    case 8:
+      hipLaunchKernelGGL(filter_range<int64_t>, dim3(grid), dim3(kBlockThreads), 0, stream,
+                         static_cast<const int64_t*>(values), v, nrows, lo, hi, sel_out, count_out);
+      break;
+    case 2:
+      hipLaunchKernelGGL(filter_range<int16_t>, dim3(grid), dim3(kBlockThreads), 0, stream,
+                         static_cast<const int16_t*>(values), v, nrows, lo, hi, sel_out, count_out);
+      break;
+    default:
+      return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t LaunchEncodeStringTileSums(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, int32_t n_tasks,
+                                      uint32_t total_tiles, int64_t* d_tile_sums, int grid_blocks, hipStream_t stream) {
+  if (total_tiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(encode_string_tile_sums, dim3(grid_for(total_tiles, grid_blocks)), dim3(kBlockThreads), 0, stream,
+                     d_tasks, d_tile_begin, n_tasks, total_tiles, d_tile_sums);
+  return hipGetLastError();
+}
+
+hipError_t LaunchEncodeStringScan(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, int32_t n_tasks,
+                                  int64_t* d_tile_sums, uint32_t* d_status, hipStream_t stream) {
+  if (n_tasks == 0) return hipSuccess;
+  const uint32_t grid = n_tasks < 2048 ? static_cast<uint32_t>(n_tasks) : 2048u;
+  hipLaunchKernelGGL(encode_string_scan, dim3(grid), dim3(kBlockThreads), 0, stream, d_tasks, d_tile_begin, n_tasks,
+                     d_tile_sums, d_status);
+  return hipGetLastError();
+}
+
+hipError_t LaunchEncodeFixed(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, int32_t n_tasks,
+                             uint32_t total_tiles, int64_t* d_null_counts, int grid_blocks, hipStream_t stream) {
+  if (total_tiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(encode_fixed, dim3(grid_for(total_tiles, grid_blocks)), dim3(kBlockThreads), 0, stream, d_tasks,
+                     d_tile_begin, n_tasks, total_tiles, d_null_counts);
+  return hipGetLastError();
+}
+
+hipError_t LaunchEncodeString(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, int32_t n_tasks,
+                              uint32_t total_tiles, const int64_t* d_tile_sums, int64_t* d_null_counts, int grid_blocks,
+                              hipStream_t stream) {
+  if (total_tiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(encode_string, dim3(grid_for(total_tiles, grid_blocks)), dim3(kBlockThreads), 0, stream, d_tasks,
+                     d_tile_begin, n_tasks, total_tiles, d_tile_sums, d_null_counts);
+  return hipGetLastError();
+}
+
+}  // namespace device
+}  // namespace miarrow

@@ -1,0 +1,44 @@
+// kernels.hpp -- launch interface of the gfx950 transcode kernels (kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+#include "../../include/mi_arrow_ipc.h"
+
+namespace miarrow {
+namespace device {
+
+constexpr int kBlockThreads = 256;   // 4 waves of 64
+constexpr int kTileRows = 2048;      // rows per tile == DuckDB STANDARD_VECTOR_SIZE: one tile is one output vector
+
+// Persistent grid: at most this many workgroups per CU (256 threads each => 8 x 4 waves = 32 waves/CU = full).
+constexpr int kBlocksPerCU = 8;
+
+// Kernel classes: a plan groups its tasks by class and launches one kernel per non-empty class.
+enum KernelClass { kClassCopy = 0, kClassDec128 = 1, kClassString = 2, kClassMisc = 3, kClassEncFixed = 4, kClassEncString = 5, kNumClasses = 6 };
+int ClassOfKind(int32_t kind);  // -1 for an unknown kind
+
+// One launch over a device-resident task table slice.  `tile_begin[i]` = first tile of task i within the slice,
+// tile_begin[n_tasks] = total_tiles.  `status` accumulates MI_ST_* bits.
+hipError_t LaunchTranscode(int cls, const mi_col_task* d_tasks, const uint32_t* d_tile_begin, int32_t n_tasks,
+                           uint32_t total_tiles, uint32_t* d_status, int grid_blocks, hipStream_t stream);
+
+// K6: range filter -> selection vector, one workgroup per 2048-row window.
+hipError_t LaunchFilterRange(const void* values, int32_t width, const void* validity, int64_t nrows, int64_t lo,
+                             int64_t hi, mi_sel_t* sel_out, uint32_t* count_out, hipStream_t stream);
+
+// K7d helpers (string encode needs a scan across the batch): per-tile payload byte sums, then per-task exclusive scan
+hipError_t LaunchEncodeStringTileSums(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, int32_t n_tasks,
+                                      uint32_t total_tiles, int64_t* d_tile_sums, int grid_blocks, hipStream_t stream);
+hipError_t LaunchEncodeStringScan(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, int32_t n_tasks,
+                                  int64_t* d_tile_sums, uint32_t* d_status, hipStream_t stream);
+hipError_t LaunchEncodeFixed(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, int32_t n_tasks,
+                             uint32_t total_tiles, int64_t* d_null_counts, int grid_blocks, hipStream_t stream);
+hipError_t LaunchEncodeString(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, int32_t n_tasks,
+                              uint32_t total_tiles, const int64_t* d_tile_sums, int64_t* d_null_counts, int grid_blocks,
+                              hipStream_t stream);
+
+}  // namespace device
+}  // namespace miarrow

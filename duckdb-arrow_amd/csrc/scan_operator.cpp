@@ -1,0 +1,657 @@
+// scan_operator.cpp -- see scan_operator.hpp.
+#include "scan_operator.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <functional>
+
+namespace miarrow {
+
+int WrapC(const std::function<void()>& f);  // c_api.cpp
+struct mi_ctx_fwd;
+
+namespace {
+constexpr size_t kAlign = 256;
+size_t RoundUp(size_t v, size_t a = kAlign) { return (v + a - 1) / a * a; }
+
+std::map<std::string, std::string> ParseHive(const std::string& path) {
+  // key=value path components (DuckDB's HivePartitioning::Parse behaviour for simple keys)
+  std::map<std::string, std::string> out;
+  size_t start = 0;
+  while (start < path.size()) {
+    size_t end = path.find_first_of("/\\", start);
+    if (end == std::string::npos) break;  // the last component is the file name
+    std::string part = path.substr(start, end - start);
+    size_t eq = part.find('=');
+    if (eq != std::string::npos && eq > 0 && eq + 1 < part.size()) out[part.substr(0, eq)] = part.substr(eq + 1);
+    start = end + 1;
+  }
+  return out;
+}
+
+mi_string_t MakeHostString(const std::string& s) {
+  mi_string_t r;
+  std::memset(&r, 0, sizeof(r));
+  r.value.inlined.length = static_cast<uint32_t>(s.size());
+  if (s.size() <= 12) {
+    std::memcpy(r.value.inlined.inlined, s.data(), s.size());
+  } else {
+    std::memcpy(r.value.pointer.prefix, s.data(), 4);
+    r.value.pointer.ptr = reinterpret_cast<uint64_t>(s.data());
+  }
+  return r;
+}
+}  // namespace
+
+ArrowScan::ArrowScan(Context* ctx_p, std::vector<std::string> paths, const mi_scan_options& o) : ctx(ctx_p), opts(o) {
+  if (paths.empty()) throw InvalidInputException("read_arrow needs at least one file");
+  for (auto& p : paths) {
+    Source s;
+    s.path = p;
+    sources.push_back(std::move(s));
+  }
+}
+
+ArrowScan::ArrowScan(Context* ctx_p, std::vector<ArrowIPCBuffer> buffers_p, const mi_scan_options& o)
+    : ctx(ctx_p), opts(o), buffers(std::move(buffers_p)), is_buffers(true) {
+  Source s;
+  sources.push_back(std::move(s));
+}
+
+ArrowScan::~ArrowScan() {
+  try {
+    ctx->Bind();
+  } catch (...) {
+  }
+  (void)hipStreamSynchronize(ctx->h2d_stream);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipStreamSynchronize(ctx->d2h_stream);
+  for (auto& s : slots) {
+    if (s.h_in) (void)hipHostFree(s.h_in);
+    if (s.d_in) (void)hipFree(s.d_in);
+    if (s.d_out) (void)hipFree(s.d_out);
+    if (s.h_out) (void)hipHostFree(s.h_out);
+    if (s.h_status) (void)hipHostFree(s.h_status);
+    if (s.h2d_done) (void)hipEventDestroy(s.h2d_done);
+    if (s.compute_done) (void)hipEventDestroy(s.compute_done);
+    if (s.d2h_done) (void)hipEventDestroy(s.d2h_done);
+  }
+  for (auto& kv : dicts) {
+    if (kv.second.d_data) (void)hipFree(kv.second.d_data);
+    if (kv.second.d_validity) (void)hipFree(kv.second.d_validity);
+    if (kv.second.d_heap) (void)hipFree(kv.second.d_heap);
+    if (kv.second.h_data) (void)hipHostFree(kv.second.h_data);
+    if (kv.second.h_validity) (void)hipHostFree(kv.second.h_validity);
+  }
+}
+
+void ArrowScan::OpenSource(size_t i) {
+  Source& s = sources[i];
+  if (s.opened) return;
+  if (is_buffers) {
+    s.reader = std::make_unique<IPCBufferStreamReader>(buffers);
+  } else {
+    s.reader = std::make_unique<IPCFileStreamReader>(s.path);
+    if (opts.hive_partitioning) s.hive = ParseHive(s.path);
+  }
+  s.reader->GetBaseSchema();
+  s.opened = true;
+}
+
+const std::vector<ScanColumn>& ArrowScan::Bind() {
+  if (bound) return all_columns;
+  // schema of the first file (ArrowFileScan ctor, arrow_file_scan.cpp:9-23); union_by_name visits every file
+  OpenSource(0);
+  auto add_file_columns = [&](size_t si, bool first) {
+    const ArrowSchemaModel& schema = sources[si].reader->GetBaseSchema();
+    std::vector<std::string> names;
+    for (auto& f : schema.fields) names.push_back(f.name);
+    DeduplicateColumns(names);
+    for (size_t c = 0; c < schema.fields.size(); c++) {
+      auto it = std::find_if(all_columns.begin(), all_columns.end(), [&](const ScanColumn& sc) { return sc.name == names[c]; });
+      if (it == all_columns.end()) {
+        if (!first && !opts.union_by_name) continue;
+        ScanColumn sc;
+        sc.name = names[c];
+        sc.field = schema.fields[c];
+        all_columns.push_back(std::move(sc));
+      }
+    }
+  };
+  add_file_columns(0, true);
+  if (opts.union_by_name) {
+    for (size_t i = 1; i < sources.size(); i++) {
+      OpenSource(i);
+      add_file_columns(i, false);
+    }
+  }
+  if (all_columns.empty()) {
+    throw InvalidInputException("Provided table/dataframe must have at least one column");
+  }
+  if (opts.filename && !is_buffers) {
+    ScanColumn sc;
+    sc.name = "filename";
+    sc.is_filename = true;
+    sc.field.type = MI_AT_UTF8;
+    sc.field.name = "filename";
+    all_columns.push_back(sc);
+  }
+  if (opts.hive_partitioning && !is_buffers) {
+    for (auto& kv : sources[0].hive) {
+      ScanColumn sc;
+      sc.name = kv.first;
+      sc.is_hive = true;
+      sc.hive_key = kv.first;
+      sc.field.type = MI_AT_UTF8;
+      sc.field.name = kv.first;
+      all_columns.push_back(sc);
+    }
+  }
+  bound = true;
+  return all_columns;
+}
+
+void ArrowScan::Init(const std::vector<std::string>& projected) {
+  Bind();
+  out_columns.clear();
+  if (projected.empty()) {
+    out_columns = all_columns;
+  } else {
+    for (auto& name : projected) {
+      auto it = std::find_if(all_columns.begin(), all_columns.end(), [&](const ScanColumn& sc) { return sc.name == name; });
+      if (it == all_columns.end()) throw InternalException(std::string("Field '") + name + "' does not exist in IPC file schema");
+      out_columns.push_back(*it);
+    }
+  }
+  for (auto& c : out_columns) {
+    if (c.is_filename || c.is_hive) continue;
+    int32_t kind, w, nb;
+    int64_t param;
+    if (!c.field.Plan(&kind, &param, &w, &nb)) {
+      throw NotImplementedException("Column '" + c.name + "' has Arrow type " + c.field.Format() +
+                                    " which the MI355X scan path does not decode yet");
+    }
+    if (c.field.has_dictionary && !opts.accept_dictionaries) {
+      // the reference cannot read dictionary-encoded IPC at all (base_stream_reader.cpp:86-96)
+      throw NotImplementedException("Column '" + c.name + "' is dictionary-encoded; enable accept_dictionaries");
+    }
+  }
+  all_valid.assign(MI_VECTOR_SIZE / 64, ~0ull);
+  const_vectors.assign(out_columns.size(), {});
+  chunk_vectors.assign(out_columns.size(), mi_vector{});
+  if (has_filter) {
+    filter_out_col = -1;
+    for (size_t i = 0; i < out_columns.size(); i++)
+      if (out_columns[i].name == filter_column) filter_out_col = static_cast<int>(i);
+    if (filter_out_col < 0) throw InvalidInputException("filter column '" + filter_column + "' is not in the projection");
+    int32_t kind, w, nb;
+    int64_t param;
+    out_columns[static_cast<size_t>(filter_out_col)].field.Plan(&kind, &param, &w, &nb);
+    if ((kind != MI_K_COPY && kind != MI_K_DEC128 && kind != MI_K_DATE64) || (w != 2 && w != 4 && w != 8) ||
+        out_columns[static_cast<size_t>(filter_out_col)].field.type == MI_AT_FLOAT) {
+      throw NotImplementedException("range filter pushdown needs an integer / date / decimal(<=18) column");
+    }
+  }
+  ctx->Bind();
+  for (auto& s : slots) {
+    if (!s.h2d_done) {
+      MI_HIP_CHECK(hipEventCreateWithFlags(&s.h2d_done, hipEventDisableTiming));
+      MI_HIP_CHECK(hipEventCreateWithFlags(&s.compute_done, hipEventDisableTiming));
+      MI_HIP_CHECK(hipEventCreateWithFlags(&s.d2h_done, hipEventDisableTiming));
+      s.plan = std::make_unique<Plan>(ctx);
+      MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.h_status), 64, hipHostMallocDefault));
+      *s.h_status = 0;
+    }
+  }
+  initialized = true;
+}
+
+void ArrowScan::SetFilterRange(const std::string& column, int64_t lo, int64_t hi) {
+  if (initialized) throw InvalidInputException("set the filter before mi_scan_init");
+  has_filter = true;
+  filter_column = column;
+  filter_lo = lo;
+  filter_hi = hi;
+}
+
+void ArrowScan::EnsureSlotBuffers(Slot& s, size_t in_bytes, size_t out_bytes) {
+  ctx->Bind();
+  auto grow = [](size_t need, size_t cap) { return std::max(need, cap + cap / 2); };
+  if (in_bytes > s.d_in_cap) {
+    if (s.d_in) MI_HIP_CHECK(hipFree(s.d_in));
+    s.d_in = nullptr;
+    s.d_in_cap = RoundUp(grow(in_bytes, s.d_in_cap), 1 << 16);
+    MI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s.d_in), s.d_in_cap));
+  }
+  if (out_bytes > s.d_out_cap) {
+    if (s.d_out) MI_HIP_CHECK(hipFree(s.d_out));
+    s.d_out = nullptr;
+    s.d_out_cap = RoundUp(grow(out_bytes, s.d_out_cap), 1 << 16);
+    MI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s.d_out), s.d_out_cap));
+  }
+  if (!opts.device_resident && out_bytes > s.h_out_cap) {
+    if (s.h_out) MI_HIP_CHECK(hipHostFree(s.h_out));
+    s.h_out = nullptr;
+    s.h_out_cap = RoundUp(grow(out_bytes, s.h_out_cap), 1 << 16);
+    MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.h_out), s.h_out_cap, hipHostMallocDefault));
+  }
+}
+
+ArrowScan::Slot* ArrowScan::FreeSlot() {
+  for (auto& s : slots)
+    if (!s.busy) return &s;
+  return nullptr;
+}
+
+void ArrowScan::DecodeDictionary(Source& src, const DecodedBatch& b) {
+  if (b.is_delta) throw NotImplementedException("Delta dictionaries are not supported by the MI355X scan path");
+  ctx->Bind();
+  const ArrowField& f = src.reader->GetBaseSchema().fields[static_cast<size_t>(b.column_field[0])];
+  int32_t kind, w, nb;
+  int64_t param;
+  if (!f.Plan(&kind, &param, &w, &nb, /*value_only*/ true))
+    throw NotImplementedException("Dictionary value type " + f.Format() + " is not decoded by the MI355X scan path");
+  DictState& d = dicts[b.dict_id];
+  if (d.d_data) {  // dictionary replacement: drop the old one
+    (void)hipFree(d.d_data); (void)hipFree(d.d_validity);
+    if (d.d_heap) (void)hipFree(d.d_heap);
+    if (d.h_data) (void)hipHostFree(d.h_data);
+    if (d.h_validity) (void)hipHostFree(d.h_validity);
+    d = DictState();
+  }
+  const int64_t n = b.column_length[0];
+  d.dict_len = n;
+  d.kind = kind;
+  d.out_width = w;
+  d.host_body = b.owner;
+  const size_t data_bytes = RoundUp(static_cast<size_t>(n + 1) * static_cast<size_t>(w));
+  const size_t valid_bytes = RoundUp(static_cast<size_t>((n + 1 + 63) / 64) * 8);
+  MI_HIP_CHECK(hipMalloc(&d.d_data, data_bytes));
+  MI_HIP_CHECK(hipMalloc(&d.d_validity, valid_bytes));
+  MI_HIP_CHECK(hipMemset(d.d_data, 0, data_bytes));
+  MI_HIP_CHECK(hipMemset(d.d_validity, 0xFF, valid_bytes));
+  if (b.body_size > 0) {
+    MI_HIP_CHECK(hipMalloc(&d.d_heap, RoundUp(static_cast<size_t>(b.body_size) + 16)));
+    MI_HIP_CHECK(hipMemcpy(d.d_heap, b.body, static_cast<size_t>(b.body_size), hipMemcpyHostToDevice));
+  }
+  if (n > 0) {
+    mi_col_task t;
+    std::memset(&t, 0, sizeof(t));
+    const mi_buffer_span* sp = &b.buffers[0];
+    uint8_t* base = static_cast<uint8_t*>(d.d_heap);
+    t.validity = sp[0].length ? base + sp[0].offset : nullptr;
+    t.buf1 = base + sp[1].offset;
+    t.buf2 = nb > 2 ? base + sp[2].offset : nullptr;
+    t.buf2_len = nb > 2 ? sp[2].length : 0;
+    t.out_data = d.d_data;
+    t.out_validity = d.d_validity;
+    const int64_t data_off = nb > 2 ? sp[2].offset : sp[1].offset;
+    t.ptr_base = opts.device_resident ? reinterpret_cast<uint64_t>(base + data_off) : reinterpret_cast<uint64_t>(b.body + data_off);
+    t.nrows = n;
+    t.null_count = b.null_count[0];
+    t.kind = kind;
+    t.param = param;
+    Plan plan(ctx, &t, 1);
+    plan.Launch(ctx->stream);
+    ThrowForStatus(plan.Status());
+  }
+  // the extra NULL entry at index dict_len (ColumnArrowToDuckDBDictionary): clear its validity bit
+  std::vector<uint64_t> words(valid_bytes / 8);
+  MI_HIP_CHECK(hipMemcpy(words.data(), d.d_validity, valid_bytes, hipMemcpyDeviceToHost));
+  words[static_cast<size_t>(n >> 6)] &= ~(1ull << (n & 63));
+  MI_HIP_CHECK(hipMemcpy(d.d_validity, words.data(), valid_bytes, hipMemcpyHostToDevice));
+  if (!opts.device_resident) {
+    MI_HIP_CHECK(hipHostMalloc(&d.h_data, data_bytes, hipHostMallocDefault));
+    MI_HIP_CHECK(hipHostMalloc(&d.h_validity, valid_bytes, hipHostMallocDefault));
+    MI_HIP_CHECK(hipMemcpy(d.h_data, d.d_data, data_bytes, hipMemcpyDeviceToHost));
+    std::memcpy(d.h_validity, words.data(), valid_bytes);
+  }
+}
+
+void ArrowScan::EnqueueBatch(Slot& s) {
+  ctx->Bind();
+  const DecodedBatch& b = s.batch;
+  Source& src = sources[static_cast<size_t>(s.source)];
+  const int64_t n = b.length;
+  s.nrows = n;
+  // output layout
+  size_t off = 0;
+  s.col_data_off.assign(out_columns.size(), 0);
+  s.col_valid_off.assign(out_columns.size(), 0);
+  std::vector<int32_t> kinds(out_columns.size(), 0), widths(out_columns.size(), 0), nbufs(out_columns.size(), 0);
+  std::vector<int64_t> params(out_columns.size(), 0);
+  for (size_t c = 0; c < out_columns.size(); c++) {
+    if (out_columns[c].is_filename || out_columns[c].is_hive) continue;
+    out_columns[c].field.Plan(&kinds[c], &params[c], &widths[c], &nbufs[c]);
+    s.col_data_off[c] = off;
+    off += RoundUp(static_cast<size_t>(n) * static_cast<size_t>(widths[c]) + 16);
+    s.col_valid_off[c] = off;
+    off += RoundUp(static_cast<size_t>((n + 63) / 64) * 8 + 8);
+  }
+  if (has_filter) {
+    s.sel_off = off;
+    off += RoundUp(static_cast<size_t>(n) * 4 + 16);
+    s.sel_count_off = off;
+    off += RoundUp(static_cast<size_t>((n + MI_VECTOR_SIZE - 1) / MI_VECTOR_SIZE) * 4 + 16);
+  }
+  EnsureSlotBuffers(s, static_cast<size_t>(b.body_size) + 64, off + 64);
+  // H2D of the body on the copy stream
+  if (b.body_size > 0) {
+    MI_HIP_CHECK(hipMemcpyAsync(s.d_in, b.body, static_cast<size_t>(b.body_size), hipMemcpyHostToDevice, ctx->h2d_stream));
+  }
+  MI_HIP_CHECK(hipEventRecord(s.h2d_done, ctx->h2d_stream));
+  // tasks
+  std::vector<mi_col_task> tasks;
+  for (size_t c = 0; c < out_columns.size(); c++) {
+    if (out_columns[c].is_filename || out_columns[c].is_hive) continue;
+    const int32_t fc = src.out_to_file_column[c];
+    mi_col_task t;
+    std::memset(&t, 0, sizeof(t));
+    t.out_data = s.d_out + s.col_data_off[c];
+    t.out_validity = s.d_out + s.col_valid_off[c];
+    if (fc < 0 || n == 0) continue;  // column absent in this file (union_by_name): filled with NULLs below
+    const mi_buffer_span* sp = &b.buffers[static_cast<size_t>(fc) * 3];
+    t.validity = sp[0].length ? s.d_in + sp[0].offset : nullptr;
+    t.buf1 = s.d_in + sp[1].offset;
+    t.buf2 = nbufs[c] > 2 ? s.d_in + sp[2].offset : nullptr;
+    t.buf2_len = nbufs[c] > 2 ? sp[2].length : 0;
+    const int64_t data_off = nbufs[c] > 2 ? sp[2].offset : sp[1].offset;
+    t.ptr_base = opts.device_resident ? reinterpret_cast<uint64_t>(s.d_in + data_off) : reinterpret_cast<uint64_t>(b.body + data_off);
+    t.nrows = n;
+    t.null_count = b.null_count[static_cast<size_t>(fc)];
+    t.kind = kinds[c];
+    t.param = params[c];
+    if (kinds[c] == MI_K_DICT) {
+      auto it = dicts.find(out_columns[c].field.dict_id);
+      if (it == dicts.end()) throw IOException("RecordBatch uses dictionary id " + std::to_string(out_columns[c].field.dict_id) + " before its DictionaryBatch");
+      t.param2 = it->second.dict_len;
+    }
+    tasks.push_back(t);
+  }
+  MI_HIP_CHECK(hipStreamWaitEvent(ctx->stream, s.h2d_done, 0));
+  // absent columns: all-NULL vectors (data 0, validity 0)
+  for (size_t c = 0; c < out_columns.size(); c++) {
+    if (out_columns[c].is_filename || out_columns[c].is_hive) continue;
+    if (src.out_to_file_column[c] < 0 && n > 0) {
+      MI_HIP_CHECK(hipMemsetAsync(s.d_out + s.col_data_off[c], 0, static_cast<size_t>(n) * static_cast<size_t>(widths[c]), ctx->stream));
+      MI_HIP_CHECK(hipMemsetAsync(s.d_out + s.col_valid_off[c], 0, static_cast<size_t>((n + 63) / 64) * 8, ctx->stream));
+    }
+  }
+  s.plan->Set(tasks.data(), static_cast<int32_t>(tasks.size()), ctx->stream);
+  MI_HIP_CHECK(hipMemsetAsync(s.plan->d_status, 0, sizeof(uint32_t), ctx->stream));
+  s.plan->Launch(ctx->stream);
+  if (has_filter && n > 0) {
+    const size_t fc = static_cast<size_t>(filter_out_col);
+    MI_HIP_CHECK(device::LaunchFilterRange(s.d_out + s.col_data_off[fc], widths[fc], s.d_out + s.col_valid_off[fc], n, filter_lo,
+                                           filter_hi, reinterpret_cast<mi_sel_t*>(s.d_out + s.sel_off),
+                                           reinterpret_cast<uint32_t*>(s.d_out + s.sel_count_off), ctx->stream));
+  }
+  MI_HIP_CHECK(hipEventRecord(s.compute_done, ctx->stream));
+  MI_HIP_CHECK(hipStreamWaitEvent(ctx->d2h_stream, s.compute_done, 0));
+  if (!opts.device_resident && off > 0)
+    MI_HIP_CHECK(hipMemcpyAsync(s.h_out, s.d_out, off, hipMemcpyDeviceToHost, ctx->d2h_stream));
+  // the device status word travels with the results instead of costing a stream-wide synchronisation
+  MI_HIP_CHECK(hipMemcpyAsync(s.h_status, s.plan->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->d2h_stream));
+  MI_HIP_CHECK(hipEventRecord(s.d2h_done, ctx->d2h_stream));
+}
+
+bool ArrowScan::SubmitNextBatch() {
+  while (!exhausted) {
+    if (cur_source >= sources.size()) {
+      exhausted = true;
+      return false;
+    }
+    Slot* slot = FreeSlot();
+    if (!slot) return false;
+    OpenSource(cur_source);
+    Source& src = sources[cur_source];
+    if (src.out_to_file_column.empty()) {
+      // per-file column mapping by name (DuckDB's multi-file column mapping) + reader projection
+      const ArrowSchemaModel& schema = src.reader->GetBaseSchema();
+      std::vector<std::string> names;
+      for (auto& f : schema.fields) names.push_back(f.name);
+      DeduplicateColumns(names);
+      std::vector<std::string> wanted;
+      src.out_to_file_column.assign(out_columns.size(), -1);
+      for (size_t c = 0; c < out_columns.size(); c++) {
+        if (out_columns[c].is_filename || out_columns[c].is_hive) continue;
+        auto it = std::find(names.begin(), names.end(), out_columns[c].name);
+        if (it == names.end()) {
+          if (!opts.union_by_name) {
+            throw InvalidInputException("Failed to read file \"" + src.path + "\": schema mismatch: column \"" + out_columns[c].name +
+                                        "\" is missing. If you are trying to read files with different schemas, try setting union_by_name=True");
+          }
+          continue;
+        }
+        const ArrowField& ff = schema.fields[static_cast<size_t>(it - names.begin())];
+        if (ff.Format() != out_columns[c].field.Format()) {
+          throw NotImplementedException("Column \"" + out_columns[c].name + "\" has type " + ff.DuckType() + " in file \"" + src.path +
+                                        "\" but " + out_columns[c].field.DuckType() +
+                                        " in the first file; cross-file casts are done by DuckDB's MultiFileReader above this path");
+        }
+        src.out_to_file_column[c] = static_cast<int32_t>(wanted.size());
+        wanted.push_back(*it);
+      }
+      if (!wanted.empty()) src.reader->SetColumnProjection(wanted);
+      else src.out_to_file_column.assign(out_columns.size(), -1);
+    }
+    // read the next message of this source; bodies land directly in the slot's pinned buffer
+    Slot& s = *slot;
+    src.reader->SetBodyAllocator([this, &s](size_t bytes, MessageType type, uint8_t** ptr) -> std::shared_ptr<void> {
+      ctx->Bind();
+      if (type == MessageType::DICTIONARY_BATCH) {
+        void* p = nullptr;
+        MI_HIP_CHECK(hipHostMalloc(&p, bytes + 64, hipHostMallocDefault));
+        *ptr = static_cast<uint8_t*>(p);
+        return std::shared_ptr<void>(p, [](void* q) { (void)hipHostFree(q); });
+      }
+      if (bytes + 64 > s.h_in_cap) {
+        if (s.h_in) MI_HIP_CHECK(hipHostFree(s.h_in));
+        s.h_in = nullptr;
+        s.h_in_cap = RoundUp(std::max(bytes + 64, s.h_in_cap + s.h_in_cap / 2), 1 << 16);
+        MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.h_in), s.h_in_cap, hipHostMallocDefault));
+      }
+      *ptr = s.h_in;
+      return std::shared_ptr<void>();
+    });
+    const bool mine = opts.world <= 1 || (next_batch_ordinal % opts.world) == opts.rank;
+    bool got = src.reader->GetNextBatch(&s.batch, opts.accept_dictionaries != 0, /*skip_body*/ !mine);
+    if (!got) {
+      cur_source++;
+      continue;
+    }
+    if (s.batch.is_dictionary) {
+      DecodeDictionary(src, s.batch);
+      continue;
+    }
+    const int64_t ordinal = next_batch_ordinal++;
+    if (!mine) continue;
+    s.source = static_cast<int32_t>(cur_source);
+    s.batch_index = ordinal;
+    s.busy = true;
+    EnqueueBatch(s);
+    inflight.push_back(static_cast<int>(&s - slots));
+    return true;
+  }
+  return false;
+}
+
+void ArrowScan::Next(mi_data_chunk* out) {
+  if (!initialized) Init({});
+  ctx->Bind();
+  std::memset(out, 0, sizeof(*out));
+  while (true) {
+    // release the slot the previous chunk came from once it is fully consumed
+    if (cur_slot >= 0 && cur_row >= slots[cur_slot].nrows) {
+      slots[cur_slot].busy = false;
+      slots[cur_slot].batch.owner.reset();
+      inflight.erase(inflight.begin());
+      cur_slot = -1;
+      cur_row = 0;
+    }
+    // keep the pipeline full
+    while (inflight.size() < static_cast<size_t>(kSlots) && SubmitNextBatch()) {
+    }
+    if (cur_slot < 0) {
+      if (inflight.empty()) {
+        out->size = 0;
+        out->n_columns = static_cast<int32_t>(out_columns.size());
+        return;  // exhausted
+      }
+      cur_slot = inflight.front();
+      cur_row = 0;
+      Slot& s = slots[cur_slot];
+      MI_HIP_CHECK(hipEventSynchronize(s.d2h_done));
+      ThrowForStatus(*s.h_status);
+      if (s.nrows == 0) continue;  // empty record batch: nothing to emit
+    }
+    break;
+  }
+  Slot& s = slots[cur_slot];
+  const int64_t n = std::min<int64_t>(MI_VECTOR_SIZE, s.nrows - cur_row);
+  uint8_t* base = opts.device_resident ? s.d_out : s.h_out;
+  Source& src = sources[static_cast<size_t>(s.source)];
+  for (size_t c = 0; c < out_columns.size(); c++) {
+    mi_vector& v = chunk_vectors[c];
+    std::memset(&v, 0, sizeof(v));
+    if (out_columns[c].is_filename || out_columns[c].is_hive) {
+      auto& cv = const_vectors[c];
+      // strings are kept alive in the source (path / hive map), the vector points at them
+      const std::string& stable = out_columns[c].is_filename ? src.path : src.hive[out_columns[c].hive_key];
+      if (cv.size() != MI_VECTOR_SIZE || cv[0].value.inlined.length != stable.size() ||
+          (stable.size() > 12 && cv[0].value.pointer.ptr != reinterpret_cast<uint64_t>(stable.data())) ||
+          (stable.size() <= 12 && std::memcmp(cv[0].value.inlined.inlined, stable.data(), stable.size()) != 0)) {
+        cv.assign(MI_VECTOR_SIZE, MakeHostString(stable));
+      }
+      v.data = cv.data();
+      v.validity = all_valid.data();
+      v.kind = MI_K_STR32;
+      v.out_width = 16;
+      continue;
+    }
+    int32_t kind, w, nb;
+    int64_t param;
+    out_columns[c].field.Plan(&kind, &param, &w, &nb);
+    v.data = base + s.col_data_off[c] + static_cast<size_t>(cur_row) * static_cast<size_t>(w);
+    v.validity = reinterpret_cast<mi_validity_t*>(base + s.col_valid_off[c]) + cur_row / 64;
+    v.kind = kind;
+    v.out_width = w;
+    if (kind == MI_K_DICT) {
+      const DictState& d = dicts[out_columns[c].field.dict_id];
+      v.dictionary = opts.device_resident ? d.d_data : d.h_data;
+      v.dictionary_validity = static_cast<const mi_validity_t*>(opts.device_resident ? d.d_validity : d.h_validity);
+      v.dict_len = d.dict_len;
+    }
+  }
+  out->size = n;
+  out->n_columns = static_cast<int32_t>(out_columns.size());
+  out->file_index = s.source;
+  out->batch_index = s.batch_index;
+  out->chunk_offset = cur_row;
+  out->columns = chunk_vectors.data();
+  out->sel_count = n;
+  if (has_filter) {
+    out->sel = reinterpret_cast<const mi_sel_t*>(base + s.sel_off) + cur_row;
+    if (opts.device_resident) {
+      uint32_t cnt = 0;
+      MI_HIP_CHECK(hipMemcpy(&cnt, s.d_out + s.sel_count_off + static_cast<size_t>(cur_row / MI_VECTOR_SIZE) * 4, 4, hipMemcpyDeviceToHost));
+      out->sel_count = cnt;
+    } else {
+      out->sel_count = reinterpret_cast<const uint32_t*>(base + s.sel_count_off)[cur_row / MI_VECTOR_SIZE];
+    }
+  }
+  cur_row += n;
+}
+
+double ArrowScan::Progress() {
+  if (sources.empty()) return 100;
+  double done = static_cast<double>(std::min(cur_source, sources.size()));
+  if (cur_source < sources.size() && sources[cur_source].reader) done += sources[cur_source].reader->GetProgress() / 100.0;
+  return std::min(100.0, 100.0 * done / static_cast<double>(sources.size()));
+}
+
+}  // namespace miarrow
+
+// ------------------------------------------------------------------------------------------------ C ABI
+using namespace miarrow;
+
+namespace miarrow {
+Context* ContextOf(mi_ctx* c);
+}
+
+struct mi_scan {
+  std::unique_ptr<ArrowScan> scan;
+};
+
+extern "C" {
+
+int mi_scan_open_files(mi_ctx* ctx, const char* const* paths, int32_t n_paths, const mi_scan_options* opts, mi_scan** out) {
+  return WrapC([&] {
+    if (!ctx || !paths || n_paths <= 0 || !out) throw InvalidInputException("mi_scan_open_files: bad argument");
+    mi_scan_options o;
+    std::memset(&o, 0, sizeof(o));
+    if (opts) o = *opts;
+    std::vector<std::string> v;
+    for (int32_t i = 0; i < n_paths; i++) v.emplace_back(paths[i]);
+    auto s = std::make_unique<mi_scan>();
+    s->scan = std::make_unique<ArrowScan>(ContextOf(ctx), std::move(v), o);
+    *out = s.release();
+  });
+}
+
+int mi_scan_open_buffers(mi_ctx* ctx, const mi_ipc_buffer* buffers, int32_t n_buffers, const mi_scan_options* opts, mi_scan** out) {
+  return WrapC([&] {
+    if (!ctx || (!buffers && n_buffers) || n_buffers < 0 || !out) throw InvalidInputException("mi_scan_open_buffers: bad argument");
+    mi_scan_options o;
+    std::memset(&o, 0, sizeof(o));
+    if (opts) o = *opts;
+    std::vector<ArrowIPCBuffer> v;
+    for (int32_t i = 0; i < n_buffers; i++) v.emplace_back(buffers[i].ptr, buffers[i].size);
+    auto s = std::make_unique<mi_scan>();
+    s->scan = std::make_unique<ArrowScan>(ContextOf(ctx), std::move(v), o);
+    *out = s.release();
+  });
+}
+
+void mi_scan_close(mi_scan* s) { delete s; }
+
+int mi_scan_bind(mi_scan* s, mi_field* fields, int32_t cap, int32_t* n_fields) {
+  return WrapC([&] {
+    if (!s || !n_fields) throw InvalidInputException("mi_scan_bind: NULL argument");
+    const auto& cols = s->scan->Bind();
+    *n_fields = static_cast<int32_t>(cols.size());
+    for (size_t i = 0; i < cols.size() && fields && static_cast<int32_t>(i) < cap; i++) {
+      FillCField(cols[i].field, static_cast<int32_t>(i), &fields[i]);
+      std::snprintf(fields[i].name, sizeof(fields[i].name), "%s", cols[i].name.c_str());
+    }
+  });
+}
+
+int mi_scan_init(mi_scan* s, const char* const* projected_names, int32_t n_projected) {
+  return WrapC([&] {
+    if (!s) throw InvalidInputException("mi_scan_init: NULL scan");
+    std::vector<std::string> v;
+    for (int32_t i = 0; i < n_projected; i++) v.emplace_back(projected_names[i]);
+    s->scan->Init(v);
+  });
+}
+
+int mi_scan_set_filter_range(mi_scan* s, const char* column, int64_t lo, int64_t hi) {
+  return WrapC([&] {
+    if (!s || !column) throw InvalidInputException("mi_scan_set_filter_range: NULL argument");
+    s->scan->SetFilterRange(column, lo, hi);
+  });
+}
+
+int mi_scan_next(mi_scan* s, mi_data_chunk* out) {
+  return WrapC([&] {
+    if (!s || !out) throw InvalidInputException("mi_scan_next: NULL argument");
+    s->scan->Next(out);
+  });
+}
+
+double mi_scan_progress(mi_scan* s) { return s ? s->scan->Progress() : 0; }
+
+}  // extern "C"

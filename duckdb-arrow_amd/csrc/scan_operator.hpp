@@ -1,0 +1,134 @@
+// scan_operator.hpp -- the scan TableFunction body: read_arrow / scan_arrow_ipc on the MI355X path.
+//
+// Mirrors, for this path, what the reference wires together from DuckDB pieces:
+//   bind      ArrowFileScan::ArrowFileScan            src/file_scanner/arrow_file_scan.cpp:9-23
+//             ScanArrowIPCFunction::ScanArrowIPCBind   src/scanner/scan_arrow_ipc.cpp:20-48
+//             ArrowMultiFileInfo::BindReader           src/file_scanner/arrow_multi_file_info.cpp:54-70
+//   init      ArrowFileScan::TryInitializeScan         src/file_scanner/arrow_file_scan.cpp:30-67
+//             ArrowIPCStreamFactory::Produce (projection)  src/ipc/stream_factory.cpp:14-30
+//   scan      ArrowFileScan::Scan -> ArrowTableFunction::ArrowScanFunction   src/file_scanner/arrow_file_scan.cpp:68-72
+//             (<= 2048 rows per call, output cardinality 0 = exhausted)
+// The per-value work of ArrowToDuckDB runs in the HIP kernels; this class is the pipeline around them:
+// record-batch body -> pinned slot -> hipMemcpyAsync H2D (copy stream) -> class kernels (compute stream) ->
+// hipMemcpyAsync D2H (copy-back stream) -> DataChunks that alias the pinned output slot.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "engine.hpp"
+#include "ipc_stream_reader.hpp"
+
+namespace miarrow {
+
+void DeduplicateColumns(std::vector<std::string>& names);  // ipc_stream_reader.cpp
+
+struct ScanColumn {
+  std::string name;
+  ArrowField field;           // arrow field of the first file that has it
+  bool is_filename = false;   // `filename` option (README.md:104-107)
+  bool is_hive = false;       // hive partition key
+  std::string hive_key;
+};
+
+class ArrowScan {
+ public:
+  ArrowScan(Context* ctx, std::vector<std::string> paths, const mi_scan_options& opts);
+  ArrowScan(Context* ctx, std::vector<ArrowIPCBuffer> buffers, const mi_scan_options& opts);
+  ~ArrowScan();
+
+  //! Bind: schema of the scan (names deduplicated) -- "Provided table/dataframe must have at least one column"
+  const std::vector<ScanColumn>& Bind();
+  //! Init: projection pushdown (column names, output order)
+  void Init(const std::vector<std::string>& projected);
+  //! Range filter pushed into the scan (K6; the reference leaves filters to DuckDB: read_arrow.cpp:47-48)
+  void SetFilterRange(const std::string& column, int64_t lo, int64_t hi);
+  //! One DataChunk (<= 2048 rows); size 0 when exhausted
+  void Next(mi_data_chunk* out);
+  double Progress();
+
+ private:
+  struct Source {
+    std::string path;                          // empty for buffers
+    std::unique_ptr<IPCStreamReader> reader;
+    std::vector<int32_t> out_to_file_column;   // per output column: index in this file's projected batch, -1 = absent
+    std::map<std::string, std::string> hive;   // key -> value parsed from the path
+    bool opened = false;
+  };
+  struct DictState {
+    void* d_data = nullptr;        // decoded dictionary values (dict_len + 1 entries) on the device
+    void* d_validity = nullptr;
+    void* h_data = nullptr;        // pinned host copy (host consumers)
+    void* h_validity = nullptr;
+    void* d_heap = nullptr;        // device copy of the dictionary's IPC body (string payload lives here)
+    std::shared_ptr<void> host_body;  // keeps the host body alive: long dictionary strings point into it
+    int64_t dict_len = 0;
+    int32_t kind = 0, out_width = 0;
+  };
+  struct Slot {
+    // one record batch in flight
+    uint8_t* h_in = nullptr;   size_t h_in_cap = 0;    // pinned body
+    uint8_t* d_in = nullptr;   size_t d_in_cap = 0;    // body in HBM
+    uint8_t* d_out = nullptr;  size_t d_out_cap = 0;   // decoded vectors in HBM
+    uint8_t* h_out = nullptr;  size_t h_out_cap = 0;   // decoded vectors, pinned
+    std::unique_ptr<Plan> plan;
+    uint32_t* h_status = nullptr;                      // pinned copy of the plan's device status word
+    hipEvent_t h2d_done = nullptr, compute_done = nullptr, d2h_done = nullptr;
+    bool busy = false;
+    DecodedBatch batch;
+    int32_t source = 0;
+    int64_t batch_index = 0;
+    int64_t nrows = 0;
+    std::vector<size_t> col_data_off, col_valid_off;   // per output column, offsets into d_out / h_out
+    size_t sel_off = 0, sel_count_off = 0;             // filter outputs
+    std::shared_ptr<void> external_body;               // buffer sources: nothing to own, body is caller memory
+  };
+
+  void OpenSource(size_t i);
+  void BuildOutputSchema();
+  bool SubmitNextBatch();   // reads + enqueues one more record batch; false when all sources are exhausted
+  void EnqueueBatch(Slot& s);
+  void DecodeDictionary(Source& src, const DecodedBatch& b);
+  void EnsureSlotBuffers(Slot& s, size_t in_bytes, size_t out_bytes);
+  Slot* FreeSlot();
+
+  Context* ctx;
+  mi_scan_options opts;
+  std::vector<Source> sources;
+  std::vector<ArrowIPCBuffer> buffers;
+  bool is_buffers = false;
+  bool bound = false, initialized = false;
+  std::vector<ScanColumn> all_columns;   // bind result
+  std::vector<ScanColumn> out_columns;   // after projection
+  std::vector<std::string> projected_names;
+
+  // pipeline
+  static constexpr int kSlots = 3;
+  Slot slots[kSlots];
+  std::vector<int> inflight;             // slot indices in submission order
+  size_t cur_source = 0;
+  int64_t next_batch_ordinal = 0;        // global record-batch ordinal (sharding + order)
+  bool exhausted = false;
+  // consumer cursor
+  int cur_slot = -1;
+  int64_t cur_row = 0;
+  std::vector<mi_vector> chunk_vectors;
+  // constant columns (filename / hive): 2048 string_t each, host
+  std::vector<std::vector<mi_string_t>> const_vectors;
+  std::vector<mi_validity_t> all_valid;
+  // dictionaries by id
+  std::map<int64_t, DictState> dicts;
+  // filter
+  bool has_filter = false;
+  std::string filter_column;
+  int filter_out_col = -1;
+  int64_t filter_lo = 0, filter_hi = 0;
+  // progress
+  int64_t total_bytes = 0, consumed_bytes = 0;
+};
+
+}  // namespace miarrow

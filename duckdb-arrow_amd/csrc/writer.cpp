@@ -1,0 +1,581 @@
+// writer.cpp -- see writer.hpp.
+#include "writer.hpp"
+
+#include <fcntl.h>
+#include <hip/hip_runtime.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cctype>
+#include <cerrno>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+namespace miarrow {
+
+int WrapC(const std::function<void()>& f);  // c_api.cpp
+
+namespace {
+constexpr size_t kBufferAlign = 64;  // Arrow's recommended buffer alignment; any multiple of 8 is valid IPC
+size_t RoundUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+template <typename T>
+void GrowPinned(T** p, size_t* cap_bytes, size_t need_bytes, size_t keep_bytes) {
+  if (need_bytes <= *cap_bytes && *p) return;
+  size_t ncap = RoundUp(std::max(need_bytes, *cap_bytes + *cap_bytes / 2), 1 << 16);
+  void* np = nullptr;
+  MI_HIP_CHECK(hipHostMalloc(&np, ncap, hipHostMallocDefault));
+  if (*p) {
+    std::memcpy(np, *p, std::min(keep_bytes, *cap_bytes));
+    MI_HIP_CHECK(hipHostFree(*p));
+  }
+  *p = static_cast<T*>(np);
+  *cap_bytes = ncap;
+}
+
+void GrowDevice(uint8_t** p, size_t* cap, size_t need) {
+  if (need <= *cap && *p) return;
+  if (*p) MI_HIP_CHECK(hipFree(*p));
+  *p = nullptr;
+  *cap = RoundUp(std::max(need, *cap + *cap / 2), 1 << 16);
+  MI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(p), *cap));
+}
+
+// DuckDB logical type -> how the vector is laid out and which K7 kernel encodes it
+void EncodePlanFor(const ArrowField& f, int32_t* enc_kind, int64_t* param, int32_t* width) {
+  switch (f.type) {
+    case MI_AT_BOOL: *enc_kind = MI_K_ENC_BOOL; *param = 1; *width = 1; return;
+    case MI_AT_INT: *enc_kind = MI_K_ENC_COPY; *param = f.bit_width / 8; *width = f.bit_width / 8; return;
+    case MI_AT_FLOAT: *enc_kind = MI_K_ENC_COPY; *param = f.precision == 1 ? 4 : 8; *width = static_cast<int32_t>(*param); return;
+    case MI_AT_DATE: *enc_kind = MI_K_ENC_COPY; *param = 4; *width = 4; return;
+    case MI_AT_TIME: case MI_AT_TIMESTAMP: *enc_kind = MI_K_ENC_COPY; *param = 8; *width = 8; return;
+    case MI_AT_DECIMAL:
+      if (f.precision <= 4) { *enc_kind = MI_K_ENC_DEC128; *param = 2; *width = 2; }
+      else if (f.precision <= 9) { *enc_kind = MI_K_ENC_DEC128; *param = 4; *width = 4; }
+      else if (f.precision <= 18) { *enc_kind = MI_K_ENC_DEC128; *param = 8; *width = 8; }
+      else { *enc_kind = MI_K_ENC_COPY; *param = 16; *width = 16; }
+      return;
+    case MI_AT_UTF8: case MI_AT_BINARY: *enc_kind = MI_K_ENC_STR32; *param = 0; *width = 16; return;
+    default: throw NotImplementedException("Arrow type " + f.Format() + " is not encoded by the MI355X writer path");
+  }
+}
+
+// append `n` bits of `src` (NULL = all ones) to `dst` at bit position `pos`
+void AppendBits(uint64_t* dst, int64_t pos, const uint64_t* src, int64_t n) {
+  for (int64_t i = 0; i < n;) {
+    const int64_t dw = (pos + i) >> 6;
+    const int dsh = static_cast<int>((pos + i) & 63);
+    const int64_t take = std::min<int64_t>(64 - dsh, n - i);
+    // gather `take` bits of src starting at bit i
+    uint64_t bits;
+    if (!src) {
+      bits = ~0ull;
+    } else {
+      const int64_t sw = i >> 6;
+      const int ssh = static_cast<int>(i & 63);
+      bits = src[sw] >> ssh;
+      if (ssh && ssh + take > 64) bits |= src[sw + 1] << (64 - ssh);
+    }
+    const uint64_t mask = take == 64 ? ~0ull : ((1ull << take) - 1ull);
+    dst[dw] = (dst[dw] & ~(mask << dsh)) | ((bits & mask) << dsh);
+    i += take;
+  }
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ collection
+ChunkCollection::ChunkCollection(Context* ctx_p, const std::vector<ArrowField>& fields) : ctx(ctx_p) {
+  for (auto& f : fields) {
+    Column c;
+    EncodePlanFor(f, &c.enc_kind, &c.param, &c.width);
+    columns.push_back(c);
+  }
+}
+
+ChunkCollection::~ChunkCollection() {
+  for (auto& c : columns) {
+    if (c.data) (void)hipHostFree(c.data);
+    if (c.validity) (void)hipHostFree(c.validity);
+    if (c.heap) (void)hipHostFree(c.heap);
+  }
+}
+
+void ChunkCollection::Reserve(Column& c, int64_t rows, int64_t extra_heap) {
+  ctx->Bind();
+  GrowPinned(&c.data, &c.data_cap, static_cast<size_t>(rows) * static_cast<size_t>(c.width) + 64,
+             static_cast<size_t>(count) * static_cast<size_t>(c.width));
+  const size_t old_vcap = c.validity_cap;
+  GrowPinned(&c.validity, &c.validity_cap, static_cast<size_t>((rows + 63) / 64) * 8 + 16, static_cast<size_t>((count + 63) / 64) * 8);
+  if (c.validity_cap != old_vcap) {
+    const size_t used = static_cast<size_t>((count + 63) / 64) * 8;
+    std::memset(reinterpret_cast<uint8_t*>(c.validity) + used, 0xFF, c.validity_cap - used);
+  }
+  if (extra_heap > 0)
+    GrowPinned(&c.heap, &c.heap_cap, static_cast<size_t>(c.heap_used + extra_heap) + 64, static_cast<size_t>(c.heap_used));
+}
+
+void ChunkCollection::Append(const mi_data_chunk& chunk) {
+  if (chunk.n_columns != static_cast<int32_t>(columns.size()))
+    throw InvalidInputException("DataChunk has " + std::to_string(chunk.n_columns) + " columns, the writer expects " + std::to_string(columns.size()));
+  const int64_t n = chunk.size;
+  if (n <= 0) return;
+  if (n > MI_VECTOR_SIZE * 1024) throw InvalidInputException("DataChunk too large");
+  for (size_t ci = 0; ci < columns.size(); ci++) {
+    Column& c = columns[ci];
+    const mi_vector& v = chunk.columns[ci];
+    if (!v.data) throw InvalidInputException("DataChunk column " + std::to_string(ci) + " has no data");
+    int64_t extra_heap = 0;
+    if (c.enc_kind == MI_K_ENC_STR32) {
+      const mi_string_t* s = static_cast<const mi_string_t*>(v.data);
+      for (int64_t i = 0; i < n; i++) {
+        const bool valid = !v.validity || ((v.validity[i >> 6] >> (i & 63)) & 1);
+        if (valid && s[i].value.inlined.length > 12) extra_heap += s[i].value.inlined.length;
+      }
+    }
+    Reserve(c, count + n, extra_heap);
+    std::memcpy(c.data + static_cast<size_t>(count) * static_cast<size_t>(c.width), v.data, static_cast<size_t>(n) * static_cast<size_t>(c.width));
+    AppendBits(c.validity, count, v.validity, n);
+    if (v.validity) {
+      for (int64_t i = 0; i < n && !c.has_nulls; i += 64) {
+        uint64_t w = v.validity[i >> 6];
+        const int64_t rem = n - i;
+        if (rem < 64) w |= ~0ull << rem;
+        if (w != ~0ull) c.has_nulls = true;
+      }
+    }
+    if (c.enc_kind == MI_K_ENC_STR32) {
+      mi_string_t* dst = reinterpret_cast<mi_string_t*>(c.data) + count;
+      for (int64_t i = 0; i < n; i++) {
+        const bool valid = !v.validity || ((v.validity[i >> 6] >> (i & 63)) & 1);
+        if (!valid) {
+          std::memset(&dst[i], 0, sizeof(mi_string_t));
+          continue;
+        }
+        const uint32_t len = dst[i].value.inlined.length;
+        c.payload_bytes += len;
+        if (len > 12) {
+          // long string: move the payload into the staging heap, the pointer becomes the heap offset (ptr_base = 0)
+          std::memcpy(c.heap + c.heap_used, reinterpret_cast<const void*>(static_cast<uintptr_t>(dst[i].value.pointer.ptr)), len);
+          dst[i].value.pointer.ptr = static_cast<uint64_t>(c.heap_used);
+          c.heap_used += len;
+        }
+      }
+      size_in_bytes += extra_heap;
+    }
+    size_in_bytes += n * c.width;
+  }
+  count += n;
+}
+
+void ChunkCollection::Reset() {
+  for (auto& c : columns) {
+    c.heap_used = 0;
+    c.payload_bytes = 0;
+    c.has_nulls = false;
+    if (c.validity) std::memset(c.validity, 0xFF, c.validity_cap);
+  }
+  count = 0;
+  size_in_bytes = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ serializer
+ColumnDataCollectionSerializer::ColumnDataCollectionSerializer(Context* ctx_p) : ctx(ctx_p) {}
+
+ColumnDataCollectionSerializer::~ColumnDataCollectionSerializer() {
+  if (h_body) (void)hipHostFree(h_body);
+  if (d_body) (void)hipFree(d_body);
+  if (d_in) (void)hipFree(d_in);
+}
+
+void ColumnDataCollectionSerializer::Init(const ArrowSchemaModel* schema_p) { schema = schema_p; }
+
+void ColumnDataCollectionSerializer::SerializeSchema() {
+  header = EncodeSchemaMessage(*schema);
+  body_size = 0;
+}
+
+idx_t ColumnDataCollectionSerializer::Serialize(ChunkCollection& buffer) {
+  header.clear();
+  body_size = 0;
+  const int64_t n = buffer.Count();
+  if (n == 0) return 0;
+  ctx->Bind();
+  if (!plan) plan = std::make_unique<Plan>(ctx);
+  if (n > 0x7FFFFFFFll) throw InvalidInputException("record batch too large");
+
+  // body layout (buffers in schema order: validity, then data | offsets + data), device staging layout
+  std::vector<mi_buffer_span> spans;
+  struct InOff { size_t data, validity, heap; };
+  std::vector<InOff> in_off(buffer.columns.size());
+  size_t body_off = 0, in_bytes = 0;
+  auto add_span = [&](int64_t len) {
+    spans.push_back(mi_buffer_span{static_cast<int64_t>(body_off), len});
+    body_off += RoundUp(static_cast<size_t>(len), kBufferAlign);
+  };
+  for (size_t ci = 0; ci < buffer.columns.size(); ci++) {
+    auto& c = buffer.columns[ci];
+    add_span((n + 7) / 8);  // validity: always emitted (ArrowAppender::FinalizeChild)
+    switch (c.enc_kind) {
+      case MI_K_ENC_COPY: add_span(n * c.param); break;
+      case MI_K_ENC_DEC128: add_span(n * 16); break;
+      case MI_K_ENC_BOOL: add_span((n + 7) / 8); break;
+      case MI_K_ENC_STR32:
+        if (c.payload_bytes > 0x7FFFFFFFll) {
+          throw InvalidInputException(
+              "Arrow Appender: The maximum total string size for regular string buffers is 2147483647 but the offset of " +
+              std::to_string(c.payload_bytes) + " exceeds this.\n* SET arrow_large_buffer_size=true to use large string buffers");
+        }
+        add_span((n + 1) * 4);
+        add_span(c.payload_bytes);
+        break;
+      default: break;
+    }
+    in_off[ci].data = in_bytes;
+    in_bytes += RoundUp(static_cast<size_t>(n) * static_cast<size_t>(c.width) + 16, 256);
+    in_off[ci].validity = in_bytes;
+    in_bytes += RoundUp(static_cast<size_t>((n + 63) / 64) * 8 + 8, 256);
+    in_off[ci].heap = in_bytes;
+    in_bytes += RoundUp(static_cast<size_t>(c.heap_used) + 16, 256);
+  }
+  body_size = static_cast<int64_t>(body_off);
+  GrowDevice(&d_in, &d_in_cap, in_bytes + 256);
+  GrowDevice(&d_body, &d_body_cap, body_off + 256);
+  { size_t zero = 0; GrowPinned(&h_body, &h_body_cap, body_off + 256, zero); }
+
+  hipStream_t s = ctx->stream;
+  MI_HIP_CHECK(hipMemsetAsync(d_body, 0, body_off, s));  // the padding bytes of every buffer are zero
+  std::vector<mi_col_task> tasks;
+  size_t span_i = 0;
+  for (size_t ci = 0; ci < buffer.columns.size(); ci++) {
+    auto& c = buffer.columns[ci];
+    MI_HIP_CHECK(hipMemcpyAsync(d_in + in_off[ci].data, c.data, static_cast<size_t>(n) * static_cast<size_t>(c.width), hipMemcpyHostToDevice, s));
+    if (c.has_nulls)
+      MI_HIP_CHECK(hipMemcpyAsync(d_in + in_off[ci].validity, c.validity, static_cast<size_t>((n + 63) / 64) * 8, hipMemcpyHostToDevice, s));
+    if (c.heap_used)
+      MI_HIP_CHECK(hipMemcpyAsync(d_in + in_off[ci].heap, c.heap, static_cast<size_t>(c.heap_used), hipMemcpyHostToDevice, s));
+    mi_col_task t;
+    std::memset(&t, 0, sizeof(t));
+    t.kind = c.enc_kind;
+    t.param = c.param;
+    t.nrows = n;
+    t.validity = c.has_nulls ? d_in + in_off[ci].validity : nullptr;
+    t.buf1 = d_in + in_off[ci].data;
+    t.out_validity = d_body + spans[span_i].offset;
+    t.out_data = d_body + spans[span_i + 1].offset;
+    if (c.enc_kind == MI_K_ENC_STR32) {
+      t.buf2 = d_in + in_off[ci].heap;
+      t.buf2_len = c.payload_bytes;
+      t.ptr_base = 0;
+      t.out_aux = d_body + spans[span_i + 2].offset;
+      span_i += 3;
+    } else {
+      span_i += 2;
+    }
+    tasks.push_back(t);
+  }
+  plan->Set(tasks.data(), static_cast<int32_t>(tasks.size()), s);
+  plan->Launch(s);
+  MI_HIP_CHECK(hipMemcpyAsync(h_body, d_body, body_off, hipMemcpyDeviceToHost, s));
+  ThrowForStatus(plan->Status());  // synchronises the stream
+  std::vector<int64_t> null_counts = plan->NullCounts(/*reset*/ true);
+  std::vector<std::pair<int64_t, int64_t>> nodes;
+  for (size_t ci = 0; ci < buffer.columns.size(); ci++) nodes.emplace_back(n, null_counts[ci]);
+  header = EncodeRecordBatchMessage(n, nodes, spans, body_size);
+  return 1;
+}
+
+// ------------------------------------------------------------------------------------------------ stream writer
+ArrowStreamWriter::ArrowStreamWriter(Context* ctx_p, const std::string& file_path, const std::vector<ArrowField>& fields,
+                                     const std::vector<std::pair<std::string, std::string>>& metadata)
+    : ctx(ctx_p), serializer(ctx_p), file_name(file_path) {
+  InitSchema(fields, metadata);
+  if (!file_path.empty()) InitOutputFile(file_path);
+}
+
+ArrowStreamWriter::~ArrowStreamWriter() {
+  if (fd >= 0) ::close(fd);
+}
+
+void ArrowStreamWriter::InitSchema(const std::vector<ArrowField>& fields,
+                                   const std::vector<std::pair<std::string, std::string>>& metadata) {
+  schema.fields = fields;
+  schema.metadata = metadata;  // kv_metadata COPY option (arrow_stream_writer.cpp:26-44)
+  serializer.Init(&schema);
+}
+
+void ArrowStreamWriter::InitOutputFile(const std::string& file_path) {
+  // FILE_FLAGS_WRITE | FILE_FLAGS_FILE_CREATE_NEW (arrow_stream_writer.cpp:49-53): always a fresh file
+  fd = ::open(file_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  if (fd < 0) throw IOException("Cannot open file \"" + file_path + "\": " + std::strerror(errno));
+}
+
+void ArrowStreamWriter::WriteData(const uint8_t* p, size_t n) {
+  size_t done = 0;
+  while (done < n) {
+    ssize_t w = ::write(fd, p + done, n - done);
+    if (w < 0) {
+      if (errno == EINTR) continue;
+      throw IOException("Could not write to file \"" + file_name + "\": " + std::strerror(errno));
+    }
+    done += static_cast<size_t>(w);
+  }
+  total_written += n;
+}
+
+void ArrowStreamWriter::WriteSchema() {
+  serializer.SerializeSchema();
+  WriteData(serializer.GetHeader().data(), serializer.GetHeader().size());
+}
+
+void ArrowStreamWriter::Flush(ChunkCollection& buffer) {
+  if (serializer.Serialize(buffer) == 0) {
+    buffer.Reset();
+    ++row_group_count;  // the reference counts the flush even when the collection was empty (arrow_stream_writer.cpp:66-71)
+    return;
+  }
+  buffer.Reset();
+  WriteData(serializer.GetHeader().data(), serializer.GetHeader().size());
+  WriteData(serializer.GetBody(), static_cast<size_t>(serializer.GetBodySize()));
+  ++row_group_count;
+}
+
+void ArrowStreamWriter::Finalize() {
+  if (finalized) return;
+  const uint8_t end_of_stream[] = {0xFF, 0xFF, 0xFF, 0xFF, 0x00, 0x00, 0x00, 0x00};
+  WriteData(end_of_stream, sizeof(end_of_stream));
+  ::close(fd);
+  fd = -1;
+  finalized = true;
+}
+
+}  // namespace miarrow
+
+// ------------------------------------------------------------------------------------------------ C ABI
+using namespace miarrow;
+
+namespace miarrow {
+Context* ContextOf(mi_ctx* c);
+}
+
+struct mi_writer {
+  Context* ctx = nullptr;
+  mi_write_options opts;
+  std::vector<ArrowField> fields;
+  std::unique_ptr<ArrowStreamWriter> writer;        // COPY TO file
+  std::unique_ptr<ChunkCollection> buffer;
+  // to_arrow_ipc mode
+  ArrowSchemaModel schema;
+  std::unique_ptr<ColumnDataCollectionSerializer> serializer;
+  std::vector<uint8_t> blob;
+};
+
+namespace {
+std::string LowerStr(std::string s) {
+  for (auto& c : s) c = static_cast<char>(std::tolower(static_cast<unsigned char>(c)));
+  return s;
+}
+std::string UpperStr(std::string s) {
+  for (auto& c : s) c = static_cast<char>(std::toupper(static_cast<unsigned char>(c)));
+  return s;
+}
+
+// DBConfig::ParseMemoryLimit-style sizes: "100", "1KB", "2 MiB", "1gb"
+int64_t ParseMemory(const std::string& v) {
+  char* end = nullptr;
+  double num = std::strtod(v.c_str(), &end);
+  if (end == v.c_str() || num < 0) throw InvalidInputException("Could not parse memory size '" + v + "'");
+  std::string unit;
+  for (const char* p = end; *p; p++)
+    if (!std::isspace(static_cast<unsigned char>(*p))) unit += static_cast<char>(std::tolower(static_cast<unsigned char>(*p)));
+  double mult = 1;
+  if (unit.empty() || unit == "b" || unit == "byte" || unit == "bytes") mult = 1;
+  else if (unit == "kb" || unit == "k") mult = 1000.0;
+  else if (unit == "mb" || unit == "m") mult = 1000.0 * 1000;
+  else if (unit == "gb" || unit == "g") mult = 1000.0 * 1000 * 1000;
+  else if (unit == "tb" || unit == "t") mult = 1000.0 * 1000 * 1000 * 1000;
+  else if (unit == "kib") mult = 1024.0;
+  else if (unit == "mib") mult = 1024.0 * 1024;
+  else if (unit == "gib") mult = 1024.0 * 1024 * 1024;
+  else if (unit == "tib") mult = 1024.0 * 1024 * 1024 * 1024;
+  else throw InvalidInputException("Unknown unit for memory size: '" + unit + "'");
+  return static_cast<int64_t>(num * mult);
+}
+
+uint64_t ParseU64(const std::string& name, const std::string& v) {
+  char* end = nullptr;
+  errno = 0;
+  unsigned long long x = std::strtoull(v.c_str(), &end, 10);
+  if (end == v.c_str() || *end != 0 || errno != 0 || (!v.empty() && v[0] == '-'))
+    throw InvalidInputException("Could not convert string '" + v + "' to UINT64 for option " + UpperStr(name));
+  return x;
+}
+
+std::vector<ArrowField> FieldsFromC(const mi_field* fields, int32_t n_fields) {
+  if (!fields || n_fields <= 0) throw InvalidInputException("writer needs at least one column");
+  std::vector<ArrowField> out;
+  for (int32_t i = 0; i < n_fields; i++) out.push_back(FieldFromDuckType(fields[i].name, fields[i].duck_type));
+  return out;
+}
+}  // namespace
+
+extern "C" {
+
+int mi_write_options_init(mi_write_options* o) {
+  return WrapC([&] {
+    if (!o) throw InvalidInputException("mi_write_options_init: NULL");
+    std::memset(o, 0, sizeof(*o));
+    o->row_group_size = 122880;
+    o->preserve_insertion_order = 1;
+  });
+}
+
+int mi_write_options_set(mi_write_options* o, const char* name, const char* value) {
+  return WrapC([&] {
+    if (!o || !name) throw InvalidInputException("mi_write_options_set: NULL");
+    const std::string loption = LowerStr(name);
+    if (!value) throw BinderException(UpperStr(loption) + " requires exactly one argument");
+    if (loption == "row_group_size" || loption == "chunk_size") {
+      if (o->row_group_size_set) throw BinderException("ROW_GROUP_SIZE and ROW_GROUP_SIZE_BYTES are mutually exclusive");
+      o->row_group_size = static_cast<int64_t>(ParseU64(loption, value));
+      o->row_group_size_set = 1;
+    } else if (loption == "row_group_size_bytes") {
+      o->row_group_size_bytes = ParseMemory(value);
+      o->row_group_size_bytes_set = 1;
+    } else if (loption == "row_groups_per_file") {
+      o->row_groups_per_file = static_cast<int64_t>(ParseU64(loption, value));
+    }
+    // other options are not ours: the bind loop ignores them (write_arrow_stream.cpp:62-105)
+  });
+}
+
+int mi_write_options_add_kv(mi_write_options* o, const char* key, const char* value, int32_t value_len) {
+  return WrapC([&] {
+    if (!o || !key || !value) throw InvalidInputException("mi_write_options_add_kv: NULL");
+    if (o->n_kv_metadata >= MI_MAX_KV_METADATA) throw InvalidInputException("too many kv_metadata entries");
+    if (value_len < 0) value_len = static_cast<int32_t>(std::strlen(value));
+    if (std::strlen(key) >= sizeof(o->kv_keys[0]) || static_cast<size_t>(value_len) > sizeof(o->kv_values[0]))
+      throw InvalidInputException("kv_metadata entry too long");
+    std::snprintf(o->kv_keys[o->n_kv_metadata], sizeof(o->kv_keys[0]), "%s", key);
+    std::memcpy(o->kv_values[o->n_kv_metadata], value, static_cast<size_t>(value_len));
+    o->kv_value_lens[o->n_kv_metadata] = value_len;
+    o->n_kv_metadata++;
+  });
+}
+
+int mi_write_options_finalize(mi_write_options* o) {
+  return WrapC([&] {
+    if (!o) throw InvalidInputException("mi_write_options_finalize: NULL");
+    if (o->row_group_size_bytes_set) {
+      if (o->preserve_insertion_order) {
+        throw BinderException(
+            "ROW_GROUP_SIZE_BYTES does not work while preserving insertion order. Use \"SET "
+            "preserve_insertion_order=false;\" to disable preserving insertion order.");
+      }
+    } else {
+      // We always set a max row group size bytes so we don't use too much memory
+      o->row_group_size_bytes = o->row_group_size * 1024;
+    }
+  });
+}
+
+int mi_writer_open(mi_ctx* ctx, const char* path, const mi_field* fields, int32_t n_fields, const mi_write_options* opts,
+                   mi_writer** out) {
+  return WrapC([&] {
+    if (!ctx || !path || !out) throw InvalidInputException("mi_writer_open: NULL argument");
+    auto w = std::make_unique<mi_writer>();
+    w->ctx = ContextOf(ctx);
+    if (opts) {
+      w->opts = *opts;
+    } else {
+      mi_write_options_init(&w->opts);
+      mi_write_options_finalize(&w->opts);
+    }
+    if (w->opts.row_group_size_bytes <= 0) w->opts.row_group_size_bytes = w->opts.row_group_size * 1024;
+    w->fields = FieldsFromC(fields, n_fields);
+    std::vector<std::pair<std::string, std::string>> kv;
+    for (int32_t i = 0; i < w->opts.n_kv_metadata; i++)
+      kv.emplace_back(w->opts.kv_keys[i], std::string(w->opts.kv_values[i], static_cast<size_t>(w->opts.kv_value_lens[i])));
+    w->buffer = std::make_unique<ChunkCollection>(w->ctx, w->fields);
+    w->writer = std::make_unique<ArrowStreamWriter>(w->ctx, path, w->fields, kv);
+    w->writer->WriteSchema();
+    *out = w.release();
+  });
+}
+
+int mi_writer_sink(mi_writer* w, const mi_data_chunk* chunk) {
+  return WrapC([&] {
+    if (!w || !chunk || !w->writer) throw InvalidInputException("mi_writer_sink: bad argument");
+    // append data to the local (buffered) chunk collection; flush when it exceeds the row / byte budget
+    w->buffer->Append(*chunk);
+    if (w->buffer->Count() >= w->opts.row_group_size || w->buffer->SizeInBytes() >= w->opts.row_group_size_bytes) {
+      w->writer->Flush(*w->buffer);
+    }
+  });
+}
+
+int mi_writer_finalize(mi_writer* w) {
+  return WrapC([&] {
+    if (!w || !w->writer) throw InvalidInputException("mi_writer_finalize: bad argument");
+    if (w->buffer->Count() > 0) w->writer->Flush(*w->buffer);  // ArrowWriteCombine
+    w->writer->Finalize();                                     // ArrowWriteFinalize
+  });
+}
+
+void mi_writer_close(mi_writer* w) { delete w; }
+
+int64_t mi_writer_row_groups(const mi_writer* w) { return (w && w->writer) ? static_cast<int64_t>(w->writer->NumberOfRowGroups()) : 0; }
+int64_t mi_writer_file_size(const mi_writer* w) { return (w && w->writer) ? static_cast<int64_t>(w->writer->FileSize()) : 0; }
+
+int mi_writer_rotate_next_file(const mi_writer* w, int64_t file_size_bytes) {
+  if (!w || !w->writer) return 0;
+  if (file_size_bytes >= 0 && static_cast<int64_t>(w->writer->FileSize()) > file_size_bytes) return 1;
+  if (w->opts.row_groups_per_file > 0 && static_cast<int64_t>(w->writer->NumberOfRowGroups()) >= w->opts.row_groups_per_file) return 1;
+  return 0;
+}
+
+int mi_ipc_serializer_create(mi_ctx* ctx, const mi_field* fields, int32_t n_fields, mi_writer** out) {
+  return WrapC([&] {
+    if (!ctx || !out) throw InvalidInputException("mi_ipc_serializer_create: NULL argument");
+    auto w = std::make_unique<mi_writer>();
+    w->ctx = ContextOf(ctx);
+    mi_write_options_init(&w->opts);
+    w->fields = FieldsFromC(fields, n_fields);
+    w->schema.fields = w->fields;
+    w->buffer = std::make_unique<ChunkCollection>(w->ctx, w->fields);
+    w->serializer = std::make_unique<ColumnDataCollectionSerializer>(w->ctx);
+    w->serializer->Init(&w->schema);
+    *out = w.release();
+  });
+}
+
+int mi_ipc_serialize_schema(mi_writer* w, const uint8_t** blob, int64_t* size) {
+  return WrapC([&] {
+    if (!w || !w->serializer || !blob || !size) throw InvalidInputException("mi_ipc_serialize_schema: bad argument");
+    w->serializer->SerializeSchema();
+    w->blob = w->serializer->GetHeader();
+    *blob = w->blob.data();
+    *size = static_cast<int64_t>(w->blob.size());
+  });
+}
+
+int mi_ipc_serialize_chunks(mi_writer* w, const mi_data_chunk* chunks, int32_t n_chunks, const uint8_t** blob, int64_t* size) {
+  return WrapC([&] {
+    if (!w || !w->serializer || !blob || !size || (!chunks && n_chunks)) throw InvalidInputException("mi_ipc_serialize_chunks: bad argument");
+    w->buffer->Reset();
+    for (int32_t i = 0; i < n_chunks; i++) w->buffer->Append(chunks[i]);
+    w->blob.clear();
+    if (w->serializer->Serialize(*w->buffer)) {
+      // header || body concatenated, like SerializeArray (to_arrow_ipc.cpp:72-87)
+      const auto& h = w->serializer->GetHeader();
+      w->blob.resize(h.size() + static_cast<size_t>(w->serializer->GetBodySize()));
+      std::memcpy(w->blob.data(), h.data(), h.size());
+      std::memcpy(w->blob.data() + h.size(), w->serializer->GetBody(), static_cast<size_t>(w->serializer->GetBodySize()));
+    }
+    w->buffer->Reset();
+    *blob = w->blob.data();
+    *size = static_cast<int64_t>(w->blob.size());
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+// writer.hpp -- the encode direction: DuckDB vectors -> Arrow IPC messages.
+//
+// Mirrors the reference's writer classes (same names and call structure):
+//   ColumnDataCollectionSerializer   src/writer/column_data_collection_serializer.cpp  (Init / SerializeSchema /
+//                                    Serialize / Flush / GetHeader / GetBody)
+//   ArrowStreamWriter                src/writer/arrow_stream_writer.cpp (InitSchema / InitOutputFile / WriteSchema /
+//                                    Flush / Finalize / NumberOfRowGroups / FileSize)
+//   COPY ... (FORMAT ARROWS) sink    src/writer/write_arrow_stream.cpp:141-174 (ArrowWriteSink / Combine / Finalize)
+// ArrowConverter::ToArrowArray / ArrowAppender (DuckDB core; call site column_data_collection_serializer.cpp:85) is the
+// part that runs on the GPU: the buffered chunks are staged in pinned memory, DMA'd to HBM, encoded by the K7 kernels
+// straight into the IPC body layout (every buffer padded to 8 bytes, column_data_collection_serializer.cpp:86-92 ->
+// ArrowIpcEncoderEncodeSimpleRecordBatch) and DMA'd back as one body.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "engine.hpp"
+#include "ipc_format.hpp"
+
+namespace miarrow {
+
+//! The buffered rows of one future record batch (the reference's local ColumnDataCollection,
+//! write_arrow_stream.cpp:43-52): per column a pinned staging array in DuckDB layout.
+class ChunkCollection {
+ public:
+  ChunkCollection(Context* ctx, const std::vector<ArrowField>& fields);
+  ~ChunkCollection();
+  void Append(const mi_data_chunk& chunk);
+  void Reset();
+  int64_t Count() const { return count; }
+  int64_t SizeInBytes() const { return size_in_bytes; }
+
+  struct Column {
+    int32_t enc_kind = 0;    // MI_K_ENC_*
+    int64_t param = 0;       // vector element width (or decimal physical width)
+    int32_t width = 0;       // bytes per row of the DuckDB vector
+    uint8_t* data = nullptr;      size_t data_cap = 0;       // pinned, count * width
+    uint64_t* validity = nullptr; size_t validity_cap = 0;   // pinned words
+    uint8_t* heap = nullptr;      size_t heap_cap = 0;       // pinned payload of long strings (pointer = heap offset)
+    int64_t heap_used = 0;
+    int64_t payload_bytes = 0;    // sum of valid string lengths = size of the Arrow data buffer
+    bool has_nulls = false;
+  };
+  std::vector<Column> columns;
+
+ private:
+  void Reserve(Column& c, int64_t rows, int64_t extra_heap);
+  Context* ctx;
+  int64_t count = 0;
+  int64_t size_in_bytes = 0;
+};
+
+class ColumnDataCollectionSerializer {
+ public:
+  explicit ColumnDataCollectionSerializer(Context* ctx);
+  ~ColumnDataCollectionSerializer();
+  void Init(const ArrowSchemaModel* schema);
+  void SerializeSchema();
+  //! Serializes the collection as ONE record batch (header + body). Returns the number of messages (0 when empty).
+  idx_t Serialize(ChunkCollection& buffer);
+  const std::vector<uint8_t>& GetHeader() const { return header; }
+  const uint8_t* GetBody() const { return h_body; }
+  int64_t GetBodySize() const { return body_size; }
+  int64_t LastBytesRead() const { return plan ? plan->bytes_read : 0; }
+
+ private:
+  Context* ctx;
+  const ArrowSchemaModel* schema = nullptr;
+  std::vector<uint8_t> header;
+  uint8_t* h_body = nullptr;  size_t h_body_cap = 0;   // pinned
+  uint8_t* d_body = nullptr;  size_t d_body_cap = 0;
+  uint8_t* d_in = nullptr;    size_t d_in_cap = 0;
+  int64_t body_size = 0;
+  std::unique_ptr<Plan> plan;
+};
+
+class ArrowStreamWriter {
+ public:
+  ArrowStreamWriter(Context* ctx, const std::string& file_path, const std::vector<ArrowField>& fields,
+                    const std::vector<std::pair<std::string, std::string>>& metadata);
+  ~ArrowStreamWriter();
+  void WriteSchema();
+  void Flush(ChunkCollection& buffer);
+  void Finalize();
+  idx_t NumberOfRowGroups() const { return row_group_count; }
+  idx_t FileSize() const { return total_written; }
+  const ArrowSchemaModel& Schema() const { return schema; }
+
+ private:
+  void InitSchema(const std::vector<ArrowField>& fields, const std::vector<std::pair<std::string, std::string>>& metadata);
+  void InitOutputFile(const std::string& file_path);
+  void WriteData(const uint8_t* p, size_t n);
+
+  Context* ctx;
+  ArrowSchemaModel schema;
+  ColumnDataCollectionSerializer serializer;
+  std::string file_name;
+  int fd = -1;
+  idx_t row_group_count = 0;
+  idx_t total_written = 0;
+  bool finalized = false;
+};
+
+}  // namespace miarrow

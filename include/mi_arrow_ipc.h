@@ -1,0 +1,357 @@
+/*
+ * mi_arrow_ipc.h -- C ABI of the MI355X-native Arrow IPC scan / encode path.
+ *
+ * This is the drop-in boundary for the ONE hot path of pdet/duckdb-arrow (the DuckDB `nanoarrow` extension):
+ * Arrow IPC record-batch bodies -> DuckDB vectors (and the inverse for COPY TO / to_arrow_ipc).  The library behind
+ * it (duckdb-arrow_amd/csrc -> libmi_arrow_ipc.so) is host C++ (IPC framing, flatbuffer metadata, pinned staging,
+ * stream scheduling) plus hand-written HIP kernels for gfx950.  No C++ or torch types cross this line: plain
+ * pointers, sizes and POD structs only.  Every entry point returns an errno-style int (0 = ok) and never throws;
+ * the message of the last failure is available from mi_last_error() -- the same shape as the reference's C stream
+ * boundary (src/include/ipc/array_stream.hpp:29-48: exceptions -> EIO/EINVAL/ENOMEM + last_msg).
+ *
+ * Each section names the reference interface it replaces (file:line relative to the reference repository).
+ * INTEGRATION.md shows the DuckDB-side glue a maintainer would write on top of these calls.
+ */
+#ifndef MI_ARROW_IPC_H
+#define MI_ARROW_IPC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_ABI_VERSION 1
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Status codes.  Same errno values the reference maps its exceptions to at the Arrow C stream boundary
+ * (src/include/ipc/array_stream.hpp:33-46) plus ENODATA for end-of-stream (ipc_file_stream_reader.cpp:63-66).
+ * ------------------------------------------------------------------------------------------------------- */
+#define MI_OK 0
+#define MI_EIO 5        /* IOException: framing / file errors */
+#define MI_ENOMEM 12    /* allocation failure (host, pinned or HBM) */
+#define MI_ENODEV 19    /* no usable HIP device: the product path never falls back to the CPU */
+#define MI_EINVAL 22    /* InternalException / InvalidInputException / BinderException */
+#define MI_ENODATA 61   /* end of stream */
+#define MI_ERANGE 34    /* ConversionException: value out of range during transcode */
+#define MI_ENOTSUP 95   /* NotImplementedException: type or feature outside the path */
+
+/* Message of the last failing call on this thread ("" when none). Never NULL. */
+const char* mi_last_error(void);
+/* ABI + build info: "mi_arrow_ipc <abi> gfx950 <nanoarrow-compat-version>".  The last token is what the
+ * reference's nanoarrow_version() scalar function returns (src/nanoarrow_extension.cpp:20-31, test/sql/nanoarrow.test:15-18). */
+const char* mi_version(void);
+const char* mi_nanoarrow_version(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * DuckDB physical layouts produced / consumed by the path.
+ * ------------------------------------------------------------------------------------------------------- */
+#define MI_VECTOR_SIZE 2048 /* STANDARD_VECTOR_SIZE (src/writer/to_arrow_ipc.cpp:21) */
+
+typedef struct mi_string_t { /* duckdb::string_t, 16 bytes */
+  union {
+    struct { uint32_t length; char prefix[4]; uint64_t ptr; } pointer; /* length > 12: first 4 bytes + payload address */
+    struct { uint32_t length; char inlined[12]; } inlined;             /* length <= 12: payload, zero padded */
+  } value;
+} mi_string_t;
+
+typedef struct mi_hugeint_t { uint64_t lower; int64_t upper; } mi_hugeint_t;              /* duckdb::hugeint_t */
+typedef struct mi_interval_t { int32_t months; int32_t days; int64_t micros; } mi_interval_t; /* duckdb::interval_t */
+typedef uint64_t mi_validity_t; /* bit = 1: valid, LSB first (same polarity and order as Arrow) */
+typedef uint32_t mi_sel_t;
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Schema model.  Replaces ArrowSchema + ArrowTableFunction::PopulateArrowTableType as used by
+ * src/file_scanner/arrow_file_scan.cpp:13-22 and src/scanner/scan_arrow_ipc.cpp:34-44.
+ * ------------------------------------------------------------------------------------------------------- */
+/* Arrow type ids = Schema.fbs `Type` union tags */
+enum mi_arrow_type {
+  MI_AT_NONE = 0, MI_AT_NULL = 1, MI_AT_INT = 2, MI_AT_FLOAT = 3, MI_AT_BINARY = 4, MI_AT_UTF8 = 5, MI_AT_BOOL = 6,
+  MI_AT_DECIMAL = 7, MI_AT_DATE = 8, MI_AT_TIME = 9, MI_AT_TIMESTAMP = 10, MI_AT_INTERVAL = 11, MI_AT_LIST = 12,
+  MI_AT_STRUCT = 13, MI_AT_UNION = 14, MI_AT_FIXED_BINARY = 15, MI_AT_FIXED_LIST = 16, MI_AT_MAP = 17,
+  MI_AT_DURATION = 18, MI_AT_LARGE_BINARY = 19, MI_AT_LARGE_UTF8 = 20, MI_AT_LARGE_LIST = 21, MI_AT_RUN_END = 22,
+  MI_AT_BINARY_VIEW = 23, MI_AT_UTF8_VIEW = 24
+};
+
+/* Transcode kinds: which kernel converts a column. */
+enum mi_kind {
+  MI_K_COPY = 1,          /* K3a fixed-width direct; param = width in bytes (1,2,4,8,16) */
+  MI_K_BOOL = 2,          /* K2  bit -> byte */
+  MI_K_DEC128 = 3,        /* K3b decimal128 -> int16/32/64; param = out width (2,4,8) */
+  MI_K_DATE64 = 4,        /* K3c date64[ms] -> date32 */
+  MI_K_MUL_I32 = 5,       /* K3c int32 * param -> int64 (time32[s], time32[ms]) */
+  MI_K_MUL_I64 = 6,       /* K3c int64 * param -> int64, overflow checked (timestamp[s|ms] with tz) */
+  MI_K_DIV_I64 = 7,       /* K3c int64 / param (time64[ns], timestamp[ns] with tz) */
+  MI_K_STR32 = 8,         /* K4a utf8/binary, int32 offsets -> string_t */
+  MI_K_STR64 = 9,         /* K4b large_utf8/large_binary, int64 offsets -> string_t */
+  MI_K_DICT = 10,         /* K5  dictionary indices -> sel_t; param = idx width | signed<<8; param2 = dict_len */
+  MI_K_FIXED_BINARY = 11, /* K4c fixed_size_binary -> string_t; param = byte width */
+  MI_K_DURATION = 12,     /* K3c duration -> interval_t; param = factor (>0 multiply, <0 divide by -param) */
+  /* encode direction (K7), used by mi_encode_* plans */
+  MI_K_ENC_COPY = 32,     /* K7b fixed-width copy; param = width */
+  MI_K_ENC_DEC128 = 33,   /* K7b int16/32/64 -> decimal128 sign extension; param = in width */
+  MI_K_ENC_BOOL = 34,     /* K7c byte -> bit, bits start as 1 */
+  MI_K_ENC_STR32 = 35     /* K7d string_t -> int32 offsets + data */
+};
+
+typedef struct mi_field {
+  char name[128];
+  char timezone[64];
+  char duck_type[64];     /* DuckDB logical type as `typeof` prints it: BIGINT, DECIMAL(15,2), TIMESTAMP WITH TIME ZONE */
+  char format[32];        /* Arrow C data interface format string: "l", "u", "d:15,2", "tdD", "tsu:UTC" */
+  int32_t arrow_type;     /* enum mi_arrow_type */
+  int32_t bit_width, is_signed, precision, scale, unit, byte_width, nullable;
+  int32_t has_dictionary, dict_index_bit_width, dict_index_signed;
+  int64_t dict_id;
+  int32_t kind;           /* enum mi_kind that decodes this column, 0 when unsupported on the path */
+  int32_t out_width;      /* bytes per row of the DuckDB vector */
+  int64_t param;          /* kind parameter */
+  int32_t n_buffers;      /* buffers this field owns in a RecordBatch */
+  int32_t flat_index;     /* depth-first flattened field index (IPCStreamReader::CountFields, base_stream_reader.cpp:271-277) */
+} mi_field;
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Host IPC readers.  Replace IPCStreamReader / IPCFileStreamReader / IPCBufferStreamReader
+ * (src/ipc/stream_reader/{base,ipc_file,ipc_buffer}_stream_reader.cpp) and the stream factories
+ * (src/ipc/stream_factory.cpp:41-63).  Host only: usable without a GPU.
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct mi_reader mi_reader;
+
+/* == ArrowIPCBuffer{ptr,size} (src/include/table_function/scan_arrow_ipc.hpp:19-23); caller keeps the memory alive. */
+typedef struct mi_ipc_buffer { uint64_t ptr; uint64_t size; } mi_ipc_buffer;
+
+/* FileIPCStreamFactory::InitReader (stream_factory.cpp:57-63) */
+int mi_reader_open_file(const char* path, mi_reader** out);
+/* BufferIPCStreamFactory::InitReader (stream_factory.cpp:46-50) */
+int mi_reader_open_buffers(const mi_ipc_buffer* buffers, int32_t n_buffers, mi_reader** out);
+void mi_reader_close(mi_reader* r);
+
+/* IPCStreamReader::GetBaseSchema (base_stream_reader.cpp:52-74): reads the Schema message once.
+ * Fills up to `cap` top-level fields; *n_fields = number of top-level fields in the file. */
+int mi_reader_schema(mi_reader* r, mi_field* fields, int32_t cap, int32_t* n_fields);
+/* Schema-level custom metadata (kv_metadata COPY option, arrow_stream_writer.cpp:26-44). idx in [0, count). */
+int mi_reader_schema_metadata(mi_reader* r, int32_t idx, const char** key, int32_t* key_len, const char** value,
+                              int32_t* value_len, int32_t* count);
+/* IPCStreamReader::SetColumnProjection (base_stream_reader.cpp:146-212), same error strings:
+ * "Can't request zero fields projected from IpcStreamReader", "Field 'x' does not exist in IPC file schema",
+ * "Field 'x' refers to a duplicate column name in IPC file schema". */
+int mi_reader_set_projection(mi_reader* r, const char* const* names, int32_t n);
+
+typedef struct mi_buffer_span { int64_t offset; int64_t length; } mi_buffer_span; /* Buffer{offset,length} in the body */
+
+/* One decoded RecordBatch message: what IPCStreamReader::GetNextBatch (base_stream_reader.cpp:86-144) hands to
+ * DuckDB as an ArrowArray, flattened.  Pointers stay valid until the next mi_reader_next_batch / close. */
+typedef struct mi_batch {
+  int64_t length;               /* rows */
+  const uint8_t* body;          /* host address of the message body (file readers: an internal buffer) */
+  int64_t body_size;
+  int64_t body_file_offset;     /* position of the body in the file / buffer (for progress + sharding) */
+  int32_t n_columns;            /* projected (or all top-level) columns */
+  int32_t is_dictionary;        /* 1: this is a DictionaryBatch for dict_id */
+  int64_t dict_id;
+  int32_t is_delta;
+  int32_t compression;          /* -1 none, 0 LZ4_FRAME, 1 ZSTD */
+  const int32_t* column_field;  /* [n_columns] index into the base schema's top-level fields */
+  const int64_t* null_count;    /* [n_columns] */
+  const mi_buffer_span* buffers;/* [n_columns * 3]: validity, buf1, buf2 (length 0 when absent) */
+} mi_batch;
+
+/* Returns MI_OK and fills *out, or MI_ENODATA at end of stream (EOS marker, truncated stream, or buffers
+ * exhausted).  Framing errors are MI_EIO with the reference's messages ("Expected continuation token
+ * (0xFFFFFFFF) but got N", "Expected metadata size >= 0 but got N", "Expected RecordBatch Arrow IPC message
+ * but got Schema").  `accept_dictionaries` = 0 reproduces the reference (RecordBatch only); 1 also returns
+ * DictionaryBatch messages (BASELINE config 5, beyond the reference). */
+int mi_reader_next_batch(mi_reader* r, int32_t accept_dictionaries, mi_batch* out);
+/* IPCFileStreamReader::GetProgress (ipc_file_stream_reader.cpp:22-29): percent of the file consumed. */
+double mi_reader_progress(mi_reader* r);
+/* Batch index without reading bodies: walks message headers (stream format) or the footer (file format), so
+ * that record batches can be sharded over GPUs.  Arrays are owned by the reader. */
+typedef struct mi_batch_index_entry { int64_t prefix_offset; int32_t meta_len; int32_t type; int64_t body_offset;
+                                      int64_t body_len; int64_t n_rows; } mi_batch_index_entry;
+int mi_reader_index(mi_reader* r, const mi_batch_index_entry** entries, int32_t* n);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Device context + transcode plans.  Replace the per-value loops of DuckDB core that the reference calls:
+ * ArrowTableFunction::ArrowScanFunction -> ArrowToDuckDB (call sites src/scanner/scan_arrow_ipc.cpp:56,
+ * src/file_scanner/arrow_file_scan.cpp:68-72) and ArrowConverter::ToArrowArray / ArrowAppender (call sites
+ * src/writer/column_data_collection_serializer.cpp:85, src/writer/to_arrow_ipc.cpp:134-141).
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct mi_ctx mi_ctx;
+typedef struct mi_plan mi_plan;
+
+/* One context per (GPU, worker).  Fails with MI_ENODEV when no HIP device is present. */
+int mi_ctx_create(int32_t device_id, mi_ctx** out);
+void mi_ctx_destroy(mi_ctx* ctx);
+int mi_device_count(void);
+
+/* One column of one record batch.  All pointers are DEVICE addresses (HBM).  Arrow buffers must be 8-byte
+ * aligned and padded to a multiple of 8 bytes, as the IPC format guarantees for message bodies. */
+typedef struct mi_col_task {
+  const void* validity;   /* Arrow validity bitmap, or NULL when absent (buffer length 0) */
+  const void* buf1;       /* fixed-width data / offsets / dictionary indices / (encode) DuckDB vector data */
+  const void* buf2;       /* string data / (encode) string heap */
+  void* out_data;         /* DuckDB vector data, nrows * out_width bytes (encode: Arrow buffer 1) */
+  void* out_validity;     /* mi_validity_t[ceil(nrows/64)] or NULL to skip (encode: Arrow bitmap) */
+  void* out_aux;          /* encode: Arrow buffer 2 (string data); decode: unused */
+  uint64_t ptr_base;      /* address the consumer will see for byte 0 of buf2 (string_t long-string pointers) */
+  int64_t nrows;
+  int64_t row_offset;     /* Arrow array offset: first row inside the buffers (0 for IPC-decoded arrays) */
+  int64_t buf2_len;       /* bytes in buf2 (offset validation) */
+  int64_t param;
+  int64_t param2;
+  int64_t null_count;     /* 0: bitmap ignored, all rows valid (GetValidityMask) */
+  int32_t kind;           /* enum mi_kind */
+  int32_t flags;
+} mi_col_task;
+
+/* Error bits a plan accumulates on the device (polled by mi_plan_status). */
+#define MI_ST_BAD_OFFSETS 1u      /* offsets decreasing / negative / past the data buffer (FULL validation) */
+#define MI_ST_STRING_TOO_LARGE 2u /* "DuckDB does not support Strings over 4GB" */
+#define MI_ST_MUL_OVERFLOW 4u     /* "Could not convert ... to Microsecond" */
+#define MI_ST_INDEX_RANGE 8u      /* "DuckDB only supports indices that fit on an uint32" */
+#define MI_ST_DECIMAL_RANGE 16u   /* decimal128 value does not fit the declared precision's physical type */
+#define MI_ST_OFFSET_OVERFLOW 32u /* encode: int32 offsets exceed INT32_MAX ("SET arrow_large_buffer_size=true") */
+
+/* Uploads the task table to HBM (descriptor table + tile index) and returns a reusable plan.  One plan =
+ * any number of (batch, column) tasks = ONE fused kernel launch per mi_plan_launch. */
+int mi_plan_create(mi_ctx* ctx, const mi_col_task* tasks, int32_t n_tasks, mi_plan** out);
+void mi_plan_destroy(mi_plan* plan);
+/* Enqueues the fused transcode on `stream` (a hipStream_t; NULL = the context's own stream).  Asynchronous. */
+int mi_plan_launch(mi_plan* plan, void* stream);
+/* Waits for the stream the plan last ran on, returns the accumulated MI_ST_* bits and resets them. */
+int mi_plan_status(mi_plan* plan, uint32_t* status_bits);
+/* Algorithmic bytes of one launch: Arrow buffer bytes consumed + DuckDB vector bytes produced, and tiles. */
+int mi_plan_stats(const mi_plan* plan, int64_t* bytes_read, int64_t* bytes_written, int64_t* rows, int64_t* tiles);
+/* Encode plans: NULL count per task (FieldNode.null_count), in the order the tasks were given. Waits for the plan. */
+int mi_plan_null_counts(mi_plan* plan, int64_t* out, int32_t n_tasks);
+/* Maps a status word to the errno + message the reference would raise. Returns MI_OK for 0. */
+int mi_status_to_error(uint32_t status_bits);
+
+/* K6 (extension: the reference sets filter_pushdown=false, read_arrow.cpp:47-48): range predicate
+ * lo <= v < hi on a decoded fixed-width vector + validity -> per-2048-row-window selection vectors.
+ * sel_out[window*2048 ...] holds ascending window-relative row indices, count_out[window] their number. */
+int mi_filter_range(mi_ctx* ctx, const void* values, int32_t width, const void* validity, int64_t nrows, int64_t lo,
+                    int64_t hi, mi_sel_t* sel_out, uint32_t* count_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Scan operator.  Replaces the TableFunction bodies: read_arrow (src/scanner/read_arrow.cpp:43-86 via
+ * ArrowMultiFileInfo / ArrowFileScan, src/file_scanner/) and scan_arrow_ipc (src/scanner/scan_arrow_ipc.cpp:20-64).
+ * bind -> init -> repeated next() that yields one DataChunk (<= 2048 rows) per call, like
+ * ArrowTableFunction::ArrowScanFunction.  Record-batch bodies are staged in pinned memory, DMA'd to HBM on a copy
+ * stream, transcoded by the fused kernel, and the vectors DMA'd back into pinned chunk buffers.
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct mi_scan mi_scan;
+
+typedef struct mi_scan_options {
+  int32_t union_by_name;        /* multi-file: match columns by name (README.md:104-107) */
+  int32_t filename;             /* add a `filename` VARCHAR column */
+  int32_t hive_partitioning;    /* add key=value path components as VARCHAR columns */
+  int32_t rank;                 /* record-batch sharding: this scan takes batches with index % world == rank */
+  int32_t world;                /* 0 or 1 = no sharding */
+  int32_t device_resident;      /* 1: chunks stay in HBM (pointers are device addresses), no D2H */
+  int32_t accept_dictionaries;  /* 1: decode DictionaryBatch + dictionary-encoded columns (beyond the reference) */
+  int32_t _reserved;
+} mi_scan_options;
+
+/* read_arrow('path') / read_arrow(['a','b']) (read_arrow.cpp:78-83).  Globs are expanded by the caller. */
+int mi_scan_open_files(mi_ctx* ctx, const char* const* paths, int32_t n_paths, const mi_scan_options* opts,
+                       mi_scan** out);
+/* scan_arrow_ipc([{ptr,size},...]) (scan_arrow_ipc.cpp:24-33). */
+int mi_scan_open_buffers(mi_ctx* ctx, const mi_ipc_buffer* buffers, int32_t n_buffers, const mi_scan_options* opts,
+                         mi_scan** out);
+void mi_scan_close(mi_scan* s);
+/* Bind result: column names + DuckDB types (names deduplicated like QueryResult::DeduplicateColumns,
+ * arrow_file_scan.cpp:19). "Provided table/dataframe must have at least one column" on empty schemas. */
+int mi_scan_bind(mi_scan* s, mi_field* fields, int32_t cap, int32_t* n_fields);
+/* projection_pushdown = true (read_arrow.cpp:46): column names to produce, in output order. NULL/0 = all. */
+int mi_scan_init(mi_scan* s, const char* const* projected_names, int32_t n_projected);
+
+typedef struct mi_vector {
+  void* data;               /* out_width bytes per row */
+  mi_validity_t* validity;  /* 32 words per chunk; all ones when the column has no NULLs */
+  int32_t kind;             /* enum mi_kind that produced it */
+  int32_t out_width;
+  const void* dictionary;   /* MI_K_DICT: decoded dictionary values (dict_len + 1 entries, last = NULL) */
+  const mi_validity_t* dictionary_validity;
+  int64_t dict_len;
+} mi_vector;
+
+typedef struct mi_data_chunk {
+  int64_t size;             /* rows in this chunk, 0 = scan exhausted */
+  int32_t n_columns;
+  int32_t file_index;       /* which input file / buffer list this chunk came from */
+  int64_t batch_index;      /* global record-batch ordinal (restores order under sharding) */
+  int64_t chunk_offset;     /* first row of the chunk inside its record batch */
+  const mi_vector* columns; /* valid until the next mi_scan_next on this scan */
+  const mi_sel_t* sel;      /* pushed-down filter: ascending chunk-relative row indices, NULL when no filter is set */
+  int64_t sel_count;        /* rows selected (== size when no filter is set) */
+} mi_data_chunk;
+
+/* Pushed-down range filter lo <= column < hi on a fixed-width integer/date/decimal(<=18) column (K6; the reference
+ * sets filter_pushdown=false, read_arrow.cpp:47-48, so this is an extension: DuckDB's own filter above the scan
+ * yields the same rows).  Chunks then carry a selection vector. Call between bind and the first next. */
+int mi_scan_set_filter_range(mi_scan* s, const char* column, int64_t lo, int64_t hi);
+int mi_scan_next(mi_scan* s, mi_data_chunk* out);
+double mi_scan_progress(mi_scan* s);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Writer.  Replaces ColumnDataCollectionSerializer (src/writer/column_data_collection_serializer.cpp),
+ * ArrowStreamWriter (src/writer/arrow_stream_writer.cpp), the COPY ... (FORMAT ARROWS) sink
+ * (src/writer/write_arrow_stream.cpp:54-272) and to_arrow_ipc (src/writer/to_arrow_ipc.cpp:72-182).
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct mi_writer mi_writer;
+
+#define MI_MAX_KV_METADATA 16
+typedef struct mi_write_options {
+  int64_t row_group_size;        /* ROW_GROUP_SIZE / CHUNK_SIZE, default 122880 (write_arrow_stream.cpp:28-33) */
+  int64_t row_group_size_bytes;  /* default row_group_size * 1024 (write_arrow_stream.cpp:36,114-118) */
+  int64_t row_groups_per_file;   /* 0 = unlimited (write_arrow_stream.cpp:198-219) */
+  int32_t row_group_size_set, row_group_size_bytes_set;
+  int32_t preserve_insertion_order; /* DuckDB's setting of the same name; default 1 */
+  int32_t n_kv_metadata;         /* kv_metadata STRUCT (write_arrow_stream.cpp:87-104) */
+  char kv_keys[MI_MAX_KV_METADATA][64];
+  char kv_values[MI_MAX_KV_METADATA][256]; /* BLOB values are written raw, others as their string form */
+  int32_t kv_value_lens[MI_MAX_KV_METADATA];
+} mi_write_options;
+
+/* ArrowWriteBind (write_arrow_stream.cpp:54-125): _init fills the defaults; _set parses one COPY option (name is
+ * matched case-insensitively: row_group_size | chunk_size | row_group_size_bytes | row_groups_per_file; a NULL value
+ * is "<NAME> requires exactly one argument"); _add_kv appends one kv_metadata entry; _finalize applies the cross-option
+ * rules.  Errors are MI_EINVAL with the reference's BinderException texts: "ROW_GROUP_SIZE and ROW_GROUP_SIZE_BYTES are
+ * mutually exclusive", "ROW_GROUP_SIZE_BYTES does not work while preserving insertion order. Use \"SET
+ * preserve_insertion_order=false;\" to disable preserving insertion order.". */
+int mi_write_options_init(mi_write_options* o);
+int mi_write_options_set(mi_write_options* o, const char* name, const char* value);
+int mi_write_options_add_kv(mi_write_options* o, const char* key, const char* value, int32_t value_len);
+int mi_write_options_finalize(mi_write_options* o);
+
+/* ArrowWriteInitializeGlobal (write_arrow_stream.cpp:127-139): creates the file (fails if it exists, like
+ * FILE_FLAGS_FILE_CREATE_NEW, arrow_stream_writer.cpp:49-53) and writes the Schema message.
+ * `fields`: name + duck_type (e.g. "BIGINT", "DECIMAL(15,2)", "VARCHAR", "DATE", "BOOLEAN") per column. */
+int mi_writer_open(mi_ctx* ctx, const char* path, const mi_field* fields, int32_t n_fields,
+                   const mi_write_options* opts, mi_writer** out);
+/* ArrowWriteSink (write_arrow_stream.cpp:141-159): appends one DataChunk (host vectors, DuckDB layout); flushes
+ * a record batch through the encode kernels when row_group_size / row_group_size_bytes is reached. */
+int mi_writer_sink(mi_writer* w, const mi_data_chunk* chunk);
+/* ArrowWriteCombine + ArrowWriteFinalize (write_arrow_stream.cpp:161-174): flush the tail, write EOS
+ * {FF FF FF FF 00 00 00 00} (arrow_stream_writer.cpp:78-82), close. */
+int mi_writer_finalize(mi_writer* w);
+void mi_writer_close(mi_writer* w);
+int64_t mi_writer_row_groups(const mi_writer* w);  /* ArrowStreamWriter::NumberOfRowGroups */
+int64_t mi_writer_file_size(const mi_writer* w);   /* ArrowStreamWriter::FileSize */
+/* ArrowWriteRotateNextFile (write_arrow_stream.cpp:204-219) */
+int mi_writer_rotate_next_file(const mi_writer* w, int64_t file_size_bytes /* <0: unset */);
+
+/* to_arrow_ipc: serialise to memory instead of a file.  mi_ipc_serialize_schema == SerializeSchema
+ * (column_data_collection_serializer.cpp:57-64); mi_ipc_serialize_chunks == Serialize + header||body concat
+ * (to_arrow_ipc.cpp:72-87).  Output blobs are owned by the writer until the next call. */
+int mi_ipc_serializer_create(mi_ctx* ctx, const mi_field* fields, int32_t n_fields, mi_writer** out);
+int mi_ipc_serialize_schema(mi_writer* w, const uint8_t** blob, int64_t* size);
+int mi_ipc_serialize_chunks(mi_writer* w, const mi_data_chunk* chunks, int32_t n_chunks, const uint8_t** blob,
+                            int64_t* size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_ARROW_IPC_H */

@@ -93,8 +93,9 @@ typedef struct { int64_t offset, length; } orc_buf;
 
 /* ---- framing -------------------------------------------------------------------------------------- */
 /* Walk an in-memory IPC stream (or the stream embedded in an IPC file: the ARROW1 magic at offset 0 is
- * skipped like ipc_file_stream_reader.cpp:116-119).  Stops at EOS (metadata size 0), at a truncated
- * message (treated as end of stream, :126-129) or at `max` messages.  Returns ORC_OK or ORC_EIO with
+ * skipped like ipc_file_stream_reader.cpp:116-119).  Stops at EOS (metadata size 0), at an input that ends where a
+ * prefix should start (treated as end of stream, :126-129) or at `max` messages; an input cut INSIDE a message is
+ * ORC_EIO ("not enough data in file to deserialize result": DecodeMessage runs outside the try block, :131).  Returns ORC_OK or ORC_EIO with
  * `err` filled ("Expected continuation token (0xFFFFFFFF) but got N", "Expected metadata size >= 0 ..."). */
 int orc_walk_stream(const uint8_t* buf, int64_t size, orc_msg* out, int32_t max, int32_t* n_out,
                     char* err, int32_t err_cap);

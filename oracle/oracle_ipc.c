@@ -119,7 +119,10 @@ int orc_walk_stream(const uint8_t* buf, int64_t size, orc_msg* out, int32_t max,
       return ORC_EIO;
     }
     if (meta_len == 0) break; /* EOS: DecodeHeader returns ENODATA, ipc_file_stream_reader.cpp:63-66 */
-    if (pos + 8 + meta_len > size) break; /* truncated header => end of stream */
+    if (pos + 8 + meta_len > size) { /* the prefix was read, so DecodeMessage runs outside the try block (:131): error */
+      if (err) snprintf(err, (size_t)err_cap, "not enough data in file to deserialize result");
+      return ORC_EIO;
+    }
     orc_msg m;
     memset(&m, 0, sizeof(m));
     m.prefix_off = pos;
@@ -134,7 +137,10 @@ int orc_walk_stream(const uint8_t* buf, int64_t size, orc_msg* out, int32_t max,
     pos = m.meta_off + meta_len;
     if (m.body_len > 0) {
       pos = (pos + 7) & ~(int64_t)7; /* DecodeBody aligns first, ipc_file_stream_reader.cpp:72-73 */
-      if (pos + m.body_len > size) break; /* truncated body => end of stream */
+      if (pos + m.body_len > size) { /* BufferedFileReader::ReadData throws inside DecodeBody (:80) */
+        if (err) snprintf(err, (size_t)err_cap, "not enough data in file to deserialize result");
+        return ORC_EIO;
+      }
     }
     m.body_off = pos;
     pos += m.body_len;

@@ -1,0 +1,85 @@
+"""The C-ABI library loads and exports every symbol include/*.h declares (no compute calls: CPU only)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+import duckdb_arrow_amd as da
+from duckdb_arrow_amd import _ffi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    names = set()
+    for h in ("mi_arrow_ipc.h", "mi_synth.h"):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", text))
+    return names
+
+
+def test_header_symbols_are_exported():
+    out = subprocess.run(["nm", "-D", "--defined-only", _ffi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\bT (mi_[a-z0-9_]+)", out))
+    missing = declared_symbols() - exported
+    assert not missing, "declared in include/*.h but not exported: %s" % sorted(missing)
+
+
+def test_binding_covers_every_declared_symbol():
+    assert declared_symbols() == set(_ffi.SIGNATURES), set(_ffi.SIGNATURES) ^ declared_symbols()
+    L = _ffi.lib()
+    for name in _ffi.SIGNATURES:
+        assert getattr(L, name) is not None
+
+
+def test_struct_sizes_match_header():
+    """ctypes mirrors vs the C compiler's view of include/mi_arrow_ipc.h."""
+    src = r'''
+#include <stdio.h>
+#include "mi_arrow_ipc.h"
+#include "mi_synth.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(mi_field), sizeof(mi_ipc_buffer), sizeof(mi_batch),
+         sizeof(mi_batch_index_entry), sizeof(mi_col_task), sizeof(mi_scan_options), sizeof(mi_vector),
+         sizeof(mi_data_chunk), sizeof(mi_write_options), sizeof(mi_synth_options), sizeof(mi_string_t));
+  return 0;
+}'''
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "s.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "s")
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
+        sizes = [int(x) for x in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
+    import ctypes as C
+    mine = [C.sizeof(x) for x in (_ffi.Field, _ffi.IpcBuffer, _ffi.Batch, _ffi.BatchIndexEntry, _ffi.ColTask,
+                                  _ffi.ScanOptions, _ffi.Vector, _ffi.DataChunk, _ffi.WriteOptions, _ffi.SynthOptions)] + [16]
+    assert sizes == mine
+
+
+def test_versions():
+    assert da.nanoarrow_version() == "0.7.0-SNAPSHOT"  # test/sql/nanoarrow.test:15-18
+    assert da.version().startswith("mi_arrow_ipc 1 gfx950")
+
+
+def test_no_cpu_fallback_without_device():
+    """The product path fails loudly when there is no HIP device."""
+    if da.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(da.MiError) as e:
+        da.Context(0)
+    assert e.value.code == _ffi.MI_ENODEV and "no CPU fallback" in str(e.value)
+
+
+def test_product_does_not_import_the_oracle():
+    """oracle/ is test infrastructure: nothing under the product package may reference it."""
+    pkg = os.path.join(ROOT, "duckdb-arrow_amd")
+    for root, _, files in os.walk(pkg):
+        if "build" in root.split(os.sep):
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or f == "Makefile":
+                text = open(os.path.join(root, f), errors="replace").read()
+                assert "pyoracle" not in text and "liboracle" not in text and "oracle.h" not in text, os.path.join(root, f)

@@ -1,0 +1,217 @@
+"""Host half of the product path (IPC framing, flatbuffer metadata, projection, index, encoder) -- CPU only.
+Checked against pyarrow (the reference's own test oracle) and against the CPU oracle's independent parser."""
+import os
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.ipc as ipc
+import pytest
+
+import duckdb_arrow_amd as da
+from duckdb_arrow_amd import _ffi
+from oracle import pyoracle as po
+
+from test_oracle_golden import STREAM_FILES, load
+
+
+@pytest.mark.parametrize("rel", STREAM_FILES)
+def test_reader_matches_oracle_and_pyarrow_metadata(golden_dir, rel):
+    buf = load(golden_dir, rel)
+    rd = da.Reader(buffers=[buf])
+    fields = rd.schema()
+    ofields, _, _ = po.decode_schema(buf[po.walk_stream(buf)[0]["meta_off"]:][: po.walk_stream(buf)[0]["meta_len"]])
+    assert [f["name"] for f in fields] == [f["name"] for f in ofields]
+    try:
+        t = ipc.open_stream(pa.py_buffer(buf)).read_all()
+    except pa.ArrowInvalid:
+        t = ipc.open_file(pa.py_buffer(buf)).read_all()
+    assert [f["name"] for f in fields] == t.column_names
+    msgs = [m for m in po.walk_stream(buf) if m["type"] != po.MSG_SCHEMA]
+    n = 0
+    for m in msgs:
+        b = rd.next_batch(accept_dictionaries=True)
+        assert b is not None
+        rb = po.decode_record_batch(buf[m["meta_off"]: m["meta_off"] + m["meta_len"]])
+        assert b["length"] == rb["length"] and b["body_file_offset"] == m["body_off"] and b["body_size"] == m["body_len"]
+        assert bool(b["is_dictionary"]) == (m["type"] == po.MSG_DICTIONARY_BATCH)
+        if not b["is_dictionary"]:
+            n += b["length"]
+            # every span the product slices equals the oracle's (flat schemas: <=3 buffers per column, in order)
+            flat = [s for s in b["buffers"] if True]
+            k = 0
+            for ci, f in enumerate(fields):
+                nb = 3 if f["kind"] in (_ffi.K_STR32, _ffi.K_STR64) else 2
+                assert [tuple(x) for x in flat[3 * ci: 3 * ci + nb]] == [tuple(x) for x in rb["buffers"][k: k + nb]]
+                assert b["null_count"][ci] == rb["nodes"][ci][1]
+                k += nb
+    assert rd.next_batch(accept_dictionaries=True) is None
+    assert n == t.num_rows
+
+
+def test_duck_types_like_typeof(golden_dir):
+    """multifile_reading.test:96-114 reads typeof(): VARCHAR / DOUBLE / BIGINT for the fruit files."""
+    types = lambda rel: {f["name"]: f["duck_type"] for f in da.Reader(path=os.path.join(golden_dir, rel)).schema()}
+    assert types("ref_data/multifile/glob/f1.arrow") == {"fruit": "VARCHAR", "variety": "VARCHAR", "weight": "DOUBLE"}
+    assert types("ref_data/multifile/different_type.arrows")["weight"] == "VARCHAR"
+    assert types("ref_data/multifile/different_type_int.arrows")["weight"] == "BIGINT"
+    assert types("ref_data/test.arrows") == {"commit": "VARCHAR", "time": "TIMESTAMP WITH TIME ZONE", "files": "INTEGER",
+                                             "merge": "BOOLEAN", "message": "VARCHAR"}
+    t = types("edge_types.arrows")
+    assert t["dec4"] == "DECIMAL(4,1)" and t["dec38"] == "DECIMAL(38,5)" and t["ts_s"] == "TIMESTAMP_S"
+    assert t["tz_ns"] == "TIMESTAMP WITH TIME ZONE" and t["t32ms"] == "TIME" and t["fsb"] == "BLOB" and t["u16"] == "USMALLINT"
+
+
+def test_file_reader_equals_buffer_reader(golden_dir):
+    p = os.path.join(golden_dir, "ref_data/test.arrows")
+    a, b = da.Reader(path=p), da.Reader(buffers=[load(golden_dir, "ref_data/test.arrows")])
+    assert a.schema() == b.schema()
+    while True:
+        x, y = a.next_batch(), b.next_batch()
+        assert (x is None) == (y is None)
+        if x is None:
+            break
+        assert x["length"] == y["length"] and x["buffers"] == y["buffers"] and (x["body"] == y["body"]).all()
+    assert a.progress() == pytest.approx(100.0, abs=0.01)
+
+
+def test_ipc_file_format_magic_is_skipped(golden_dir):
+    """ipc_file_stream_reader.cpp:107-119; read_arrow_file.test:9-17 (data/fruit.arrow has 6 rows)."""
+    rd = da.Reader(path=os.path.join(golden_dir, "ref_data/fruit.arrow"))
+    assert [f["name"] for f in rd.schema()] == ["fruit", "variety", "weight"]
+    rows = 0
+    while True:
+        b = rd.next_batch()
+        if b is None:
+            break
+        rows += b["length"]
+    assert rows == 6
+
+
+def test_projection_and_its_errors(golden_dir):
+    """IPCStreamReader::SetColumnProjection (base_stream_reader.cpp:146-212)"""
+    buf = load(golden_dir, "ref_data/test.arrows")
+    rd = da.Reader(buffers=[buf])
+    rd.set_projection(["message", "files"])
+    b = rd.next_batch()
+    assert b["column_field"] == [4, 2]
+    full = da.Reader(buffers=[buf]).next_batch()
+    assert b["buffers"][0:3] == full["buffers"][12:15] and b["buffers"][3:6] == full["buffers"][6:9]
+    with pytest.raises(da.MiError, match="Can't request zero fields projected from IpcStreamReader"):
+        da.Reader(buffers=[buf]).set_projection([])
+    with pytest.raises(da.MiError, match="Field 'nope' does not exist in IPC file schema"):
+        da.Reader(buffers=[buf]).set_projection(["nope"])
+
+
+def test_duplicate_column_names_are_deduplicated():
+    """QueryResult::DeduplicateColumns as used at base_stream_reader.cpp:177: a, a -> a, a_1"""
+    b = pa.record_batch([pa.array([1]), pa.array([2]), pa.array([3])], names=["a", "A", "a"])
+    sink = pa.BufferOutputStream()
+    with ipc.new_stream(sink, b.schema) as w:
+        w.write_batch(b)
+    buf = sink.getvalue().to_pybytes()
+    rd = da.Reader(buffers=[buf])
+    rd.set_projection(["A_1", "a_2"])
+    assert rd.next_batch()["column_field"] == [1, 2]
+
+
+def test_framing_errors_match_the_reference(golden_dir):
+    bad = np.zeros(64, np.uint8)
+    bad[:4] = [1, 2, 3, 4]
+    with pytest.raises(da.MiError, match=r"Expected continuation token \(0xFFFFFFFF\) but got 67305985") as e:
+        da.Reader(buffers=[bad]).schema()
+    assert e.value.code == _ffi.MI_EIO
+    neg = np.zeros(64, np.uint8)
+    neg[:4] = 0xFF
+    neg[4:8] = np.frombuffer(np.int32(-5).tobytes(), np.uint8)
+    with pytest.raises(da.MiError, match="Expected metadata size >= 0 but got -5"):
+        da.Reader(buffers=[neg]).schema()
+    # a stream whose first message is not a Schema (base_stream_reader.cpp:238-269)
+    buf = load(golden_dir, "ref_data/test.arrows")
+    msgs = po.walk_stream(buf)
+    with pytest.raises(da.MiError, match="Expected Schema Arrow IPC message but got RecordBatch"):
+        da.Reader(buffers=[buf[msgs[1]["prefix_off"]:]]).schema()
+    # empty input: "Expected Schema Arrow IPC message but got end of stream"
+    with pytest.raises(da.MiError, match="Expected Schema Arrow IPC message but got end of stream"):
+        da.Reader(buffers=[]).schema()
+    # a second Schema message where a RecordBatch is expected
+    two = np.concatenate([buf[: msgs[1]["prefix_off"]], buf[: msgs[1]["prefix_off"]]])
+    rd = da.Reader(buffers=[two])
+    rd.schema()
+    with pytest.raises(da.MiError, match="Expected RecordBatch Arrow IPC message but got Schema"):
+        rd.next_batch()
+
+
+def test_truncated_file_ends_the_stream(golden_dir, tmp_path):
+    """ipc_file_stream_reader.cpp:126-129: a file that ends where a prefix should start is end-of-stream; a file cut
+    inside a message is an error (BufferedFileReader throws while DecodeMessage runs outside the try block)."""
+    buf = load(golden_dir, "ref_data/test.arrows")
+    msgs = po.walk_stream(buf)
+    p = tmp_path / "no_eos.arrows"
+    p.write_bytes(buf[: msgs[3]["body_off"] + msgs[3]["body_len"]].tobytes())
+    rd = da.Reader(path=str(p))
+    n = 0
+    while rd.next_batch() is not None:
+        n += 1
+    assert n == 3
+    p2 = tmp_path / "cut.arrows"
+    p2.write_bytes(buf[: msgs[3]["body_off"] + 100].tobytes())
+    rd = da.Reader(path=str(p2))
+    assert rd.next_batch() is not None and rd.next_batch() is not None
+    with pytest.raises(da.MiError):
+        rd.next_batch()
+
+
+def test_batch_index_for_sharding(golden_dir):
+    buf = load(golden_dir, "ref_data/test.arrows")
+    idx = da.Reader(buffers=[buf]).index()
+    msgs = [m for m in po.walk_stream(buf) if m["type"] == po.MSG_RECORD_BATCH]
+    assert [(e["prefix_offset"], e["meta_len"], e["body_offset"], e["body_len"]) for e in idx] == \
+        [(m["prefix_off"], m["meta_len"], m["body_off"], m["body_len"]) for m in msgs]
+    assert sum(e["n_rows"] for e in idx) == 15487
+    idx2 = da.Reader(path=os.path.join(golden_dir, "ref_data/test.arrows")).index()
+    assert idx2 == idx
+
+
+def test_size_validation_rejects_short_buffers(golden_dir):
+    """NANOARROW_VALIDATION_LEVEL_FULL size checks: a RecordBatch whose body is shorter than its buffers claim."""
+    buf = load(golden_dir, "ref_data/test.arrows").copy()
+    msgs = po.walk_stream(buf)
+    # shrink bodyLength of the first record batch by rewriting the stream with a truncated body
+    m = msgs[1]
+    cut = np.concatenate([buf[: m["body_off"] + 1000], buf[m["body_off"] + m["body_len"]:]])
+    rd = da.Reader(buffers=[cut])
+    with pytest.raises(da.MiError):
+        while rd.next_batch() is not None:
+            pass
+
+
+def test_compressed_and_big_endian_are_reported_not_misread():
+    t = pa.table({"a": list(range(1000))})
+    sink = pa.BufferOutputStream()
+    with ipc.new_stream(sink, t.schema, options=ipc.IpcWriteOptions(compression="zstd")) as w:
+        w.write_table(t)
+    rd = da.Reader(buffers=[sink.getvalue().to_pybytes()])
+    with pytest.raises(da.MiError) as e:
+        rd.next_batch()
+    assert e.value.code == _ffi.MI_ENOTSUP and "Compressed" in str(e.value)
+
+
+def test_synthetic_lineitem_stream_is_valid_arrow():
+    """The generator goes through the product's own flatbuffer encoder; pyarrow must accept it (its verifier runs on
+    every message) and the data must be TPC-H shaped and reproducible."""
+    buf, info = da.synth_lineitem_stream(scale_factor=0.01, seed=7, rows_per_batch=20000)
+    buf2, _ = da.synth_lineitem_stream(scale_factor=0.01, seed=7, rows_per_batch=20000, n_threads=1)
+    assert (buf == buf2).all()
+    t = ipc.open_stream(pa.py_buffer(buf)).read_all()
+    assert t.num_rows == info["n_rows"] == 60012 and info["n_batches"] == 4
+    assert t.schema.field("l_extendedprice").type == pa.decimal128(15, 2) and t.schema.field("l_shipdate").type == pa.date32()
+    ship = np.array(t["l_shipdate"].cast(pa.int32()))
+    assert ship.min() >= 8036 and ship.max() <= 10561
+    assert set(t["l_returnflag"].to_pylist()) <= {"A", "N", "R"} and set(t["l_linestatus"].to_pylist()) == {"F", "O"}
+    ok = np.array(t["l_orderkey"])
+    assert (np.diff(ok) >= 0).all()
+    # DuckDB-writer style: validity bitmaps present, ~174.85 B/row
+    assert 172 < info["stream_size"] / info["n_rows"] < 178
+    nov, info2 = da.synth_lineitem_stream(scale_factor=0.01, seed=7, rows_per_batch=20000, with_validity=False)
+    assert ipc.open_stream(pa.py_buffer(nov)).read_all().equals(t)
+    assert info2["stream_size"] < info["stream_size"]

@@ -127,15 +127,18 @@ def test_negative_metadata_size():
 
 
 def test_truncated_stream_is_end_of_stream(golden_dir):
-    """ipc_file_stream_reader.cpp:126-129: a stream cut anywhere (no EOS marker) just ends."""
+    """ipc_file_stream_reader.cpp:126-131: an input that ends where a prefix should start (no EOS marker) just ends;
+    an input cut inside a message is an error (DecodeMessage runs outside the try block)."""
     buf = load(golden_dir, "ref_data/test.arrows")
     full = po.walk_stream(buf)
-    cut_in_body = po.walk_stream(buf[: full[3]["body_off"] + 100])
-    assert len(cut_in_body) == 3
-    cut_in_header = po.walk_stream(buf[: full[3]["meta_off"] + 10])
-    assert len(cut_in_header) == 3
     no_eos = po.walk_stream(buf[: full[-1]["body_off"] + full[-1]["body_len"]])
     assert len(no_eos) == len(full)
+    three = po.walk_stream(buf[: full[2]["body_off"] + full[2]["body_len"]])
+    assert len(three) == 3
+    with pytest.raises(IOError, match="not enough data in file to deserialize result"):
+        po.walk_stream(buf[: full[3]["body_off"] + 100])
+    with pytest.raises(IOError, match="not enough data in file to deserialize result"):
+        po.walk_stream(buf[: full[3]["meta_off"] + 10])
 
 
 def test_offset_validation():
