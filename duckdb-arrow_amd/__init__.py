@@ -193,6 +193,23 @@ class Plan:
         _ffi.check(_ffi.lib().mi_plan_stats(self._h, C.byref(r), C.byref(w), C.byref(rows), C.byref(tiles)))
         return dict(bytes_read=r.value, bytes_written=w.value, rows=rows.value, tiles=tiles.value)
 
+    def class_stats(self):
+        """Per kernel class: algorithmic bytes read / written, rows, tiles and the kernel's name."""
+        out = []
+        for cls in range(6):
+            r, w, rows, tiles, name = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64(), C.c_char_p()
+            _ffi.check(_ffi.lib().mi_plan_class_stats(self._h, cls, C.byref(r), C.byref(w), C.byref(rows), C.byref(tiles),
+                                                      C.byref(name)))
+            out.append(dict(kernel=name.value.decode(), bytes_read=r.value, bytes_written=w.value, rows=rows.value,
+                            tiles=tiles.value))
+        return out
+
+    def launch_timed(self, stream=0):
+        """One launch with HIP events around every kernel class; returns [ms per class] after synchronising."""
+        ms = (C.c_float * 6)()
+        _ffi.check(_ffi.lib().mi_plan_launch_timed(self._h, C.c_void_p(stream or None), ms))
+        return list(ms)
+
     def null_counts(self):
         out = (C.c_int64 * max(self.n_tasks, 1))()
         _ffi.check(_ffi.lib().mi_plan_null_counts(self._h, out, self.n_tasks))
@@ -602,11 +619,12 @@ class Connection:
 
 
 # ---------------------------------------------------------------------------------------------------- synthetic input
-def synth_lineitem_stream(scale_factor=1.0, seed=42, n_rows=0, rows_per_batch=0, with_validity=True, n_threads=0, out=None):
+def synth_lineitem_stream(scale_factor=1.0, seed=42, n_rows=0, rows_per_batch=0, with_validity=True, n_threads=0, out=None,
+                          first_row=0):
     """Seeded TPC-H-shaped lineitem as an Arrow IPC stream (include/mi_synth.h).  Returns (uint8 ndarray, info)."""
     L = _ffi.lib()
     o = _ffi.SynthOptions(scale_factor=scale_factor, seed=seed, rows_per_batch=rows_per_batch, n_rows=n_rows,
-                          with_validity=int(with_validity), n_threads=n_threads)
+                          first_row=first_row, with_validity=int(with_validity), n_threads=n_threads)
     rows, nb, size = C.c_int64(), C.c_int64(), C.c_int64()
     _ffi.check(L.mi_synth_lineitem_layout(C.byref(o), C.byref(rows), C.byref(nb), C.byref(size), None, 0))
     offs = (C.c_int64 * (nb.value + 1))()

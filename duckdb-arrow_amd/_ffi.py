@@ -89,7 +89,7 @@ class WriteOptions(C.Structure):
 
 class SynthOptions(C.Structure):
     _fields_ = [("scale_factor", C.c_double), ("seed", C.c_uint64), ("rows_per_batch", C.c_int64),
-                ("n_rows", C.c_int64), ("with_validity", C.c_int32), ("n_threads", C.c_int32)]
+                ("n_rows", C.c_int64), ("first_row", C.c_int64), ("with_validity", C.c_int32), ("n_threads", C.c_int32)]
 
 
 # every symbol include/mi_arrow_ipc.h and include/mi_synth.h declare: name -> (restype, argtypes)
@@ -118,6 +118,9 @@ SIGNATURES = {
     "mi_plan_status": (C.c_int, [P, C.POINTER(C.c_uint32)]),
     "mi_plan_stats": (C.c_int, [P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                 C.POINTER(C.c_int64)]),
+    "mi_plan_class_stats": (C.c_int, [P, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                      C.POINTER(C.c_int64), C.POINTER(C.c_char_p)]),
+    "mi_plan_launch_timed": (C.c_int, [P, P, C.POINTER(C.c_float)]),
     "mi_plan_null_counts": (C.c_int, [P, C.POINTER(C.c_int64), C.c_int32]),
     "mi_status_to_error": (C.c_int, [C.c_uint32]),
     "mi_filter_range": (C.c_int, [P, P, C.c_int32, P, C.c_int64, C.c_int64, C.c_int64, P, P, P]),

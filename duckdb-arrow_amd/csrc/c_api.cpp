@@ -211,6 +211,27 @@ int mi_plan_stats(const mi_plan* plan, int64_t* bytes_read, int64_t* bytes_writt
   });
 }
 
+int mi_plan_class_stats(const mi_plan* plan, int32_t cls, int64_t* bytes_read, int64_t* bytes_written, int64_t* rows,
+                        int64_t* tiles, const char** kernel_name) {
+  return Wrap([&] {
+    if (!plan || cls < 0 || cls >= device::kNumClasses) throw InvalidInputException("mi_plan_class_stats: bad argument");
+    static const char* names[device::kNumClasses] = {"transcode_copy", "transcode_dec128", "transcode_string", "transcode_misc",
+                                                    "encode_fixed", "encode_string"};
+    if (bytes_read) *bytes_read = plan->plan->class_bytes_read[cls];
+    if (bytes_written) *bytes_written = plan->plan->class_bytes_written[cls];
+    if (rows) *rows = plan->plan->class_rows[cls];
+    if (tiles) *tiles = plan->plan->classes[cls].total_tiles;
+    if (kernel_name) *kernel_name = names[cls];
+  });
+}
+
+int mi_plan_launch_timed(mi_plan* plan, void* stream, float* ms_per_class) {
+  return Wrap([&] {
+    if (!plan || !ms_per_class) throw InvalidInputException("mi_plan_launch_timed: NULL argument");
+    plan->plan->LaunchTimed(static_cast<hipStream_t>(stream), ms_per_class);
+  });
+}
+
 int mi_plan_null_counts(mi_plan* plan, int64_t* out, int32_t n_tasks) {
   return Wrap([&] {
     if (!plan || !out) throw InvalidInputException("mi_plan_null_counts: NULL argument");

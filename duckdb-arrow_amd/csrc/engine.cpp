@@ -184,6 +184,7 @@ void Plan::Set(const mi_col_task* in_tasks, int32_t n_tasks, hipStream_t upload_
   tile_begin.clear();
   total_tiles = 0;
   bytes_read = bytes_written = rows = 0;
+  for (int c = 0; c < device::kNumClasses; c++) class_bytes_read[c] = class_bytes_written[c] = class_rows[c] = 0;
   is_encode = false;
   // group by kernel class, stable inside a class
   std::vector<std::vector<mi_col_task>> by_class(device::kNumClasses);
@@ -199,6 +200,9 @@ void Plan::Set(const mi_col_task* in_tasks, int32_t n_tasks, hipStream_t upload_
     bytes_read += TaskBytesRead(t);
     bytes_written += TaskBytesWritten(t);
     rows += t.nrows;
+    class_bytes_read[cls] += TaskBytesRead(t);
+    class_bytes_written[cls] += TaskBytesWritten(t);
+    class_rows[cls] += t.nrows;
     order.push_back({cls, static_cast<int32_t>(by_class[static_cast<size_t>(cls)].size())});
     by_class[static_cast<size_t>(cls)].push_back(t);
   }
@@ -266,30 +270,51 @@ Plan::~Plan() {
   if (h_tile_begin) (void)hipHostFree(h_tile_begin);
 }
 
+void Plan::LaunchClass(int c, hipStream_t s) {
+  const int grid = ctx->GridBlocks();
+  const ClassSlice& cs = classes[c];
+  if (cs.total_tiles == 0) return;
+  const mi_col_task* t = d_tasks + cs.first_task;
+  const uint32_t* tb = d_tile_begin + cs.tile_begin_at;
+  switch (c) {
+    case device::kClassEncFixed:
+      MI_HIP_CHECK(device::LaunchEncodeFixed(t, tb, cs.n_tasks, cs.total_tiles, d_null_counts, grid, s));
+      break;
+    case device::kClassEncString:
+      MI_HIP_CHECK(device::LaunchEncodeStringTileSums(t, tb, cs.n_tasks, cs.total_tiles, d_tile_sums, grid, s));
+      MI_HIP_CHECK(device::LaunchEncodeStringScan(t, tb, cs.n_tasks, d_tile_sums, d_status, s));
+      MI_HIP_CHECK(device::LaunchEncodeString(t, tb, cs.n_tasks, cs.total_tiles, d_tile_sums, d_null_counts, grid, s));
+      break;
+    default:
+      MI_HIP_CHECK(device::LaunchTranscode(c, t, tb, cs.n_tasks, cs.total_tiles, d_status, grid, s));
+      break;
+  }
+}
+
 void Plan::Launch(hipStream_t s) {
   ctx->Bind();
   if (!s) s = ctx->stream;
   last_stream = s;
-  const int grid = ctx->GridBlocks();
+  for (int c = 0; c < device::kNumClasses; c++) LaunchClass(c, s);
+}
+
+void Plan::LaunchTimed(hipStream_t s, float* ms_per_class) {
+  ctx->Bind();
+  if (!s) s = ctx->stream;
+  last_stream = s;
+  hipEvent_t ev[device::kNumClasses + 1];
+  for (auto& e : ev) MI_HIP_CHECK(hipEventCreate(&e));
+  MI_HIP_CHECK(hipEventRecord(ev[0], s));
   for (int c = 0; c < device::kNumClasses; c++) {
-    const ClassSlice& cs = classes[c];
-    if (cs.total_tiles == 0) continue;
-    const mi_col_task* t = d_tasks + cs.first_task;
-    const uint32_t* tb = d_tile_begin + cs.tile_begin_at;
-    switch (c) {
-      case device::kClassEncFixed:
-        MI_HIP_CHECK(device::LaunchEncodeFixed(t, tb, cs.n_tasks, cs.total_tiles, d_null_counts, grid, s));
-        break;
-      case device::kClassEncString:
-        MI_HIP_CHECK(device::LaunchEncodeStringTileSums(t, tb, cs.n_tasks, cs.total_tiles, d_tile_sums, grid, s));
-        MI_HIP_CHECK(device::LaunchEncodeStringScan(t, tb, cs.n_tasks, d_tile_sums, d_status, s));
-        MI_HIP_CHECK(device::LaunchEncodeString(t, tb, cs.n_tasks, cs.total_tiles, d_tile_sums, d_null_counts, grid, s));
-        break;
-      default:
-        MI_HIP_CHECK(device::LaunchTranscode(c, t, tb, cs.n_tasks, cs.total_tiles, d_status, grid, s));
-        break;
-    }
+    LaunchClass(c, s);
+    MI_HIP_CHECK(hipEventRecord(ev[c + 1], s));
   }
+  MI_HIP_CHECK(hipStreamSynchronize(s));
+  for (int c = 0; c < device::kNumClasses; c++) {
+    ms_per_class[c] = 0;
+    if (classes[c].total_tiles) MI_HIP_CHECK(hipEventElapsedTime(&ms_per_class[c], ev[c], ev[c + 1]));
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
 }
 
 uint32_t Plan::Status() {

@@ -76,6 +76,11 @@ struct Plan {
   Plan(const Plan&) = delete;
   Plan& operator=(const Plan&) = delete;
   void Launch(hipStream_t stream);
+  void LaunchClass(int cls, hipStream_t stream);
+  //! Launch with hipEvents around each class; returns milliseconds per class after synchronising the stream
+  void LaunchTimed(hipStream_t stream, float* ms_per_class);
+  int64_t class_bytes_read[device::kNumClasses] = {0}, class_bytes_written[device::kNumClasses] = {0},
+          class_rows[device::kNumClasses] = {0};
   uint32_t Status();
   std::vector<int64_t> NullCounts(bool reset);
 };

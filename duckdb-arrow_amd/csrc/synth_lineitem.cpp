@@ -40,7 +40,7 @@ enum Stream : uint32_t { S_PART = 1, S_SUPP, S_QTY, S_DISC, S_TAX, S_ORDERDATE, 
 struct Opts {
   double sf;
   uint64_t seed;
-  int64_t rows_per_batch, n_rows, n_batches;
+  int64_t rows_per_batch, n_rows, n_batches, first_row;
   bool with_validity;
   int n_threads;
 };
@@ -57,6 +57,9 @@ Opts Resolve(const mi_synth_options* o) {
   else if (r.sf == 100.0) r.n_rows = 600037902;
   else r.n_rows = static_cast<int64_t>(6001215.0 * r.sf);
   r.n_batches = (r.n_rows + r.rows_per_batch - 1) / r.rows_per_batch;
+  r.first_row = o->first_row;
+  if (r.first_row < 0 || r.first_row % r.rows_per_batch != 0)
+    throw InvalidInputException("mi_synth: first_row must be a non-negative multiple of rows_per_batch");
   r.with_validity = o->with_validity != 0;
   int hw = static_cast<int>(std::thread::hardware_concurrency());
   r.n_threads = o->n_threads > 0 ? o->n_threads : std::max(1, std::min(hw, 32));
@@ -88,8 +91,9 @@ size_t Pad8(size_t v) { return (v + 7) & ~static_cast<size_t>(7); }
 
 BatchLayout LayoutOf(const Opts& o, int64_t batch) {
   BatchLayout L;
-  const int64_t row0 = batch * o.rows_per_batch;
-  L.nrows = std::min(o.rows_per_batch, o.n_rows - row0);
+  const int64_t local0 = batch * o.rows_per_batch;
+  const int64_t row0 = o.first_row + local0;
+  L.nrows = std::min(o.rows_per_batch, o.n_rows - local0);
   int64_t instr = 0, mode = 0, comment = 0;
   static const int instr_len[4] = {17, 11, 4, 16};
   static const int mode_len[7] = {7, 3, 4, 4, 5, 4, 3};
@@ -123,7 +127,7 @@ std::vector<uint8_t> HeaderOf(const BatchLayout& L) {
 }
 
 void FillBatch(const Opts& o, int64_t batch, const BatchLayout& L, uint8_t* body) {
-  const int64_t row0 = batch * o.rows_per_batch;
+  const int64_t row0 = o.first_row + batch * o.rows_per_batch;
   const int64_t n = L.nrows;
   std::memset(body, 0, static_cast<size_t>(L.body_size));
   size_t si = 0;

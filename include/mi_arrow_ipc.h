@@ -223,6 +223,14 @@ int mi_plan_launch(mi_plan* plan, void* stream);
 int mi_plan_status(mi_plan* plan, uint32_t* status_bits);
 /* Algorithmic bytes of one launch: Arrow buffer bytes consumed + DuckDB vector bytes produced, and tiles. */
 int mi_plan_stats(const mi_plan* plan, int64_t* bytes_read, int64_t* bytes_written, int64_t* rows, int64_t* tiles);
+/* Kernel classes of a plan (one launch each): 0 copy, 1 dec128, 2 string, 3 misc, 4 encode-fixed, 5 encode-string. */
+#define MI_NUM_KERNEL_CLASSES 6
+/* Per-class share of mi_plan_stats (0 for classes the plan does not use) + the kernel's name as rocprof prints it. */
+int mi_plan_class_stats(const mi_plan* plan, int32_t kernel_class, int64_t* bytes_read, int64_t* bytes_written,
+                        int64_t* rows, int64_t* tiles, const char** kernel_name);
+/* Like mi_plan_launch, but brackets every class launch with HIP events on `stream` and, after synchronising,
+ * returns the device time of each class in milliseconds (0 for unused classes).  Measurement aid for bench.py. */
+int mi_plan_launch_timed(mi_plan* plan, void* stream, float* ms_per_class /* [MI_NUM_KERNEL_CLASSES] */);
 /* Encode plans: NULL count per task (FieldNode.null_count), in the order the tasks were given. Waits for the plan. */
 int mi_plan_null_counts(mi_plan* plan, int64_t* out, int32_t n_tasks);
 /* Maps a status word to the errno + message the reference would raise. Returns MI_OK for 0. */

@@ -23,6 +23,8 @@ typedef struct mi_synth_options {
   uint64_t seed;
   int64_t rows_per_batch;  /* 0 -> 122880 */
   int64_t n_rows;          /* 0 -> derived from scale_factor */
+  int64_t first_row;       /* global row number of this stream's first row (a multiple of rows_per_batch): lets every
+                              rank generate its own row-group shard of one big table */
   int32_t with_validity;   /* 1: every column carries an all-ones bitmap (DuckDB's writer always emits them) */
   int32_t n_threads;       /* 0 -> hardware concurrency (capped at 32) */
 } mi_synth_options;
