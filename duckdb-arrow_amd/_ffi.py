@@ -170,6 +170,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s not found: build it with `make -C %s/csrc` (the product path has no fallback)"
                               % (LIB_PATH, _HERE))
+        # One HIP/HSA runtime per process: PyTorch-ROCm bundles its own libamdhip64 / libhsa-runtime64 and a second
+        # runtime cannot open the GPU ("No HIP GPUs are available").  When torch is used for device memory (tests,
+        # bench), load it first so that this library binds to the runtime torch already brought in.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
