@@ -1,0 +1,252 @@
+"""The scan operator (read_arrow / scan_arrow_ipc) end to end on the GPU, written after the reference's own tests:
+test/sql/read_arrow.test, test/sql/read_arrow_file.test, test/sql/multifile_reading.test,
+test/python/test_arrow_ipc_scan.py.  Expected values are the reference's known answers (tests/golden/expected.json)."""
+import os
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.ipc as ipc
+import pytest
+
+import duckdb_arrow_amd as da
+from duckdb_arrow_amd import _ffi
+
+from helpers import column_digest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def con():
+    return da.Connection(0)
+
+
+def g(golden_dir, rel):
+    return os.path.join(golden_dir, rel)
+
+
+# ---------------------------------------------------------------------------------------- read_arrow.test
+def test_count_star_test_arrows(con, golden_dir):
+    rel = con.read_arrow(g(golden_dir, "ref_data/test.arrows"))
+    assert rel.columns == ["commit", "time", "files", "merge", "message"]
+    assert rel.types == ["VARCHAR", "TIMESTAMP WITH TIME ZONE", "INTEGER", "BOOLEAN", "VARCHAR"]
+    assert rel.count() == 15487
+
+
+def test_unknown_named_parameter(con, golden_dir):
+    with pytest.raises(da.MiError, match='Invalid named parameter "made_up_option" for function read_arrow'):
+        con.read_arrow(g(golden_dir, "ref_data/test.arrows"), made_up_option=False)
+
+
+def test_filter_and_projection(con, golden_dir):
+    """SELECT message FROM read_arrow(...) WHERE "commit" = 'fa5f0299...'"""
+    rel = con.read_arrow(g(golden_dir, "ref_data/test.arrows")).project(["message", "commit"])
+    rows = [m for m, c in rel.fetchall() if c == "fa5f0299f046c46e1b2f671e5e3b4f1956522711"]
+    assert rows == ["ARROW-1: Initial Arrow Code Commit"]
+
+
+def test_filter_over_multiple_batches(con, golden_dir):
+    """SELECT count(*) ... WHERE dayname(time::TIMESTAMP) = 'Wednesday' -> 2927"""
+    (times,) = con.read_arrow(g(golden_dir, "ref_data/test.arrows")).project(["time"]).fetch_columns()
+    days = np.floor_divide(np.array(times, dtype=np.int64), 86400000000)
+    assert int(np.sum((days + 3) % 7 == 2)) == 2927
+
+
+def test_all_columns_match_pyarrow(con, golden_dir, expected):
+    for rel_path in ("ref_data/test.arrows", "edge_types.arrows", "edge_empty.arrows", "lineitem_sf0_01_head.arrows"):
+        rel = con.read_arrow(g(golden_dir, rel_path))
+        cols = rel.fetch_columns()
+        exp = expected[rel_path]
+        for name, dt, values in zip(rel.columns, rel.types, cols):
+            assert len(values) == exp["rows"]
+            canon = values
+            if dt in ("FLOAT", "DOUBLE"):
+                canon = [None if v is None else repr(v) for v in values]
+            elif dt == "BLOB":
+                canon = [None if v is None else "b:" + v.hex() for v in values]
+            assert column_digest(canon) == exp["columns"][name], (rel_path, name)
+
+
+# ---------------------------------------------------------------------------------------- read_arrow_file.test
+def test_ipc_file_format(con, golden_dir):
+    rows = con.read_arrow(g(golden_dir, "ref_data/fruit.arrow")).fetchall()
+    assert len(rows) == 6 and sum(r[2] is None for r in rows) == 2
+
+
+# ---------------------------------------------------------------------------------------- multifile_reading.test
+GLOB_ROWS = [("apple", "gala", 134.2), ("orange", "navel", 142.1), ("apple", "honeycrisp", 158.6),
+             ("orange", "valencia", 96.7), ("apple", "fuji", None), ("orange", "cara cara", None)]
+
+
+def test_file_list(con, golden_dir):
+    p = g(golden_dir, "ref_data/test.arrows")
+    assert con.read_arrow([p, p]).count() == 30974
+
+
+def test_glob(con, golden_dir):
+    assert con.read_arrow(g(golden_dir, "ref_data/multifile/glob/*.arrow")).fetchall() == GLOB_ROWS
+
+
+def test_glob_projection(con, golden_dir):
+    rel = con.read_arrow(g(golden_dir, "ref_data/multifile/glob/*.arrow")).project(["weight", "variety"])
+    assert rel.fetchall() == [(w, v) for _, v, w in GLOB_ROWS]
+
+
+def test_mismatching_schemas(con, golden_dir):
+    for a, b in (("ref_data/test.arrows", "ref_data/multifile/glob/f1.arrow"),
+                 ("ref_data/multifile/fruit_extra.arrows", "ref_data/multifile/glob/f1.arrow")):
+        with pytest.raises(da.MiError, match="If you are trying to read files with different schemas, try setting union_by_name=True"):
+            con.read_arrow([g(golden_dir, a), g(golden_dir, b)]).fetchall()
+
+
+def test_union_by_name(con, golden_dir):
+    rel = con.read_arrow([g(golden_dir, "ref_data/multifile/fruit_extra.arrows"), g(golden_dir, "ref_data/multifile/glob/f1.arrow")],
+                         union_by_name=True)
+    assert rel.columns == ["fruit", "variety", "weight", "tasteness"]
+    assert rel.fetchall() == [("apple", "pink lady", 2.2, 10.0), ("orange", "jiha", None, None),
+                              ("apple", "gala", 134.2, None), ("orange", "navel", 142.1, None)]
+
+
+def test_different_column_order(con, golden_dir):
+    rel = con.read_arrow([g(golden_dir, "ref_data/multifile/different_order.arrows"), g(golden_dir, "ref_data/multifile/glob/f1.arrow")])
+    assert rel.columns == ["fruit", "weight", "variety"]
+    assert sorted(rel.fetchall(), key=lambda r: (r[0], r[1] is None, r[1] or 0)) == \
+        [("apple", 2.2, "pink lady"), ("apple", 134.2, "gala"), ("orange", 142.1, "navel"), ("orange", None, "jiha")]
+
+
+def test_different_types_are_left_to_duckdb(con, golden_dir):
+    """Cross-file casts (VARCHAR '2.2' -> DOUBLE) are MultiFileReader::FinalizeChunk's job above the path; the scan
+    reports them instead of guessing.  The first file still decides the bound type (typeof(#3) checks)."""
+    rel = con.read_arrow([g(golden_dir, "ref_data/multifile/different_type.arrows"), g(golden_dir, "ref_data/multifile/glob/f1.arrow")])
+    assert rel.types[2] == "VARCHAR"
+    rel2 = con.read_arrow([g(golden_dir, "ref_data/multifile/glob/f1.arrow"), g(golden_dir, "ref_data/multifile/different_type.arrows")])
+    assert rel2.types[2] == "DOUBLE"
+    with pytest.raises(da.MiError, match="cross-file casts") as e:
+        rel2.fetchall()
+    assert e.value.code == _ffi.MI_ENOTSUP
+
+
+def test_filename_option(con, golden_dir):
+    rel = con.read_arrow(g(golden_dir, "ref_data/multifile/glob/*.arrow"), filename=True)
+    assert rel.columns == ["fruit", "variety", "weight", "filename"]
+    rows = rel.fetchall()
+    assert [r[:3] for r in rows] == GLOB_ROWS
+    assert [os.path.basename(r[3]) for r in rows] == ["f1.arrow", "f1.arrow", "f2.arrow", "f2.arrow", "f3.arrow", "f3.arrow"]
+    assert all(r[3].endswith("ref_data/multifile/glob/" + os.path.basename(r[3])) for r in rows)
+
+
+def test_hive_partitioning(con, golden_dir):
+    rel = con.read_arrow(g(golden_dir, "ref_data/multifile/hive/*/*.arrow"), hive_partitioning=True)
+    assert rel.columns == ["fruit", "variety", "weight", "part"]
+    assert rel.fetchall() == [("apple", "gala", 134.2, "a"), ("orange", "navel", 142.1, "a"), ("apple", "honeycrisp", 158.6, "a"),
+                              ("orange", "valencia", 96.7, "a"), ("apple", "gala", 134.2, "b"), ("orange", "navel", 142.1, "b"),
+                              ("apple", "fuji", None, "b"), ("orange", "cara cara", None, "b")]
+
+
+# ---------------------------------------------------------------------------------------- test_arrow_ipc_scan.py
+def get_record_batch():
+    data = [pa.array([1, 2, 3, 4]), pa.array(["foo", "bar", "baz", None]), pa.array([True, None, False, True])]
+    return pa.record_batch(data, names=["f0", "f1", "f2"])
+
+
+EXPECTED_5 = [(1, "foo", True), (2, "bar", None), (3, "baz", False), (4, None, True)] * 5
+
+
+def stream_of(n):
+    batch = get_record_batch()
+    sink = pa.BufferOutputStream()
+    with pa.ipc.new_stream(sink, batch.schema) as writer:
+        for _ in range(n):
+            writer.write_batch(batch)
+    return sink.getvalue()
+
+
+def test_single_buffer(con):
+    buffer = stream_of(5)
+    with pa.BufferReader(buffer) as buf_reader:
+        msg_reader = ipc.MessageReader.open_stream(buf_reader)
+        assert con.from_arrow(msg_reader).fetchall() == EXPECTED_5
+
+
+def test_multi_buffers(con):
+    """scan_arrow_ipc over several {ptr, size} buffers: schema in the first, batches spread over the rest."""
+    buffer = stream_of(5).to_pybytes()
+    with pa.BufferReader(buffer) as buf_reader:
+        msg_reader = ipc.MessageReader.open_stream(buf_reader)
+        parts = []
+        while True:
+            try:
+                parts.append(msg_reader.read_next_message().serialize().to_pybytes())
+            except StopIteration:
+                break
+    rel = con.scan_arrow_ipc([parts[0] + parts[1]] + parts[2:])
+    assert rel.columns == ["f0", "f1", "f2"] and rel.types == ["BIGINT", "VARCHAR", "BOOLEAN"]
+    assert rel.fetchall() == EXPECTED_5
+
+
+def test_empty_schema_is_rejected(con):
+    sink = pa.BufferOutputStream()
+    with pa.ipc.new_stream(sink, pa.schema([])):
+        pass
+    with pytest.raises(da.MiError, match="Provided table/dataframe must have at least one column"):
+        con.scan_arrow_ipc([sink.getvalue().to_pybytes()])
+
+
+# ---------------------------------------------------------------------------------------- beyond the reference
+def test_row_group_sharding_covers_every_batch_once(con, golden_dir):
+    """record batches shard over ranks with no collective; the union of the shards is the table."""
+    p = g(golden_dir, "ref_data/test.arrows")
+    whole = con.read_arrow(p).project(["commit", "files"]).fetchall()
+    shards = [con.read_arrow(p, rank=r, world=3).project(["commit", "files"]) for r in range(3)]
+    per_rank = []
+    for s in shards:
+        rows, idx = [], set()
+        for ch in s.chunks():
+            idx.add(ch.batch_index)
+            cols = da.chunk_to_columns(ch, s._out_fields)
+            rows.extend(zip(*cols))
+        per_rank.append((rows, idx))
+    assert [sorted(i) for _, i in per_rank] == [[0, 3, 6, 9, 12, 15], [1, 4, 7, 10, 13], [2, 5, 8, 11, 14]]
+    assert sorted(r for rows, _ in per_rank for r in rows) == sorted(whole)
+
+
+def test_filter_pushdown_selection_vector(con, golden_dir, expected):
+    """K6 inside the scan: 1994-01-01 <= l_shipdate < 1995-01-01 selects the rows DuckDB's filter would keep."""
+    rel = con.read_arrow(g(golden_dir, "lineitem_sf0_01_q6.arrows")).filter_range("l_shipdate", 8766, 9131)
+    qty, price, disc, ship = rel.fetch_columns()
+    assert len(ship) == expected["kat"]["shipdate_1994_selected"] and min(ship) >= 8766 and max(ship) < 9131
+    keep = [(p, d) for q, p, d in zip(qty, price, disc) if 5 <= d <= 7 and q < 2400]
+    assert len(keep) == 1191 and sum(p * d for p, d in keep) == 11930532253  # Q6 = 1193053.2253
+
+
+def test_dictionary_encoded_columns(con, golden_dir, expected):
+    """BASELINE config 5 (the reference cannot read these: base_stream_reader.cpp:86-96)."""
+    with pytest.raises(da.MiError, match="dictionary-encoded"):
+        con.read_arrow(g(golden_dir, "edge_dict.arrows")).fetchall()
+    rel = con.read_arrow(g(golden_dir, "edge_dict.arrows"), accept_dictionaries=True)
+    assert rel.types == ["VARCHAR", "BIGINT", "INTEGER"]
+    for name, values in zip(rel.columns, rel.fetch_columns()):
+        assert column_digest(values) == expected["edge_dict.arrows"]["columns"][name], name
+
+
+def test_device_resident_chunks(con, golden_dir):
+    """device_resident = 1: vectors stay in HBM for a GPU consumer (no D2H); pointers are device addresses."""
+    import torch
+    rel = con.read_arrow(g(golden_dir, "ref_data/test.arrows"), device_resident=True).project(["files"])
+    host = con.read_arrow(g(golden_dir, "ref_data/test.arrows")).project(["files"]).fetch_columns()[0]
+    got = []
+    for ch in rel.chunks():
+        n = ch.size
+        t = torch.empty(n, dtype=torch.int32, device="cuda")
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+        assert hip.hipMemcpy(C.c_void_p(t.data_ptr()), C.c_void_p(ch.columns[0].data), C.c_size_t(4 * n), 3) == 0  # D2D
+        got.extend(t.cpu().tolist())
+    assert got == host
+
+
+def test_progress_reaches_100(con, golden_dir):
+    rel = con.read_arrow(g(golden_dir, "ref_data/test.arrows"))
+    assert rel.progress() < 100
+    rel.count()
+    assert rel.progress() == pytest.approx(100.0, abs=0.5)

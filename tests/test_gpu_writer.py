@@ -1,0 +1,289 @@
+"""The encode direction on the GPU: K7 kernels vs the oracle, COPY ... (FORMAT ARROWS) and to_arrow_ipc end to end.
+Written after test/sql/write_arrow_stream.test, test/sql/test_copy_to.test, test/sql/to_arrow_ipc.test and
+test/python/test_arrow_ipc_writer.py; pyarrow (the reference's own oracle) reads everything the writer produces."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.ipc as ipc
+import pytest
+
+import duckdb_arrow_amd as da
+from duckdb_arrow_amd import _ffi
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def con():
+    return da.Connection(0)
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    return torch
+
+
+def read_any(path):
+    return ipc.open_stream(path).read_all()
+
+
+# ---------------------------------------------------------------------------------------- kernel level
+def test_encode_is_the_inverse_of_decode_on_lineitem(con, torch):
+    """encode(decode(body)) reproduces every Arrow buffer of a DuckDB-writer-style lineitem batch bit for bit
+    (validity present, decimal128 sign extension, int32 offsets + payload), i.e. the K7 kernels invert K1-K4."""
+    from duckdb_arrow_amd.hbm import HbmStream
+    buf, info = da.synth_lineitem_stream(scale_factor=0.05, seed=9, rows_per_batch=70000)
+    hs = HbmStream(con.ctx, buf)
+    hs.launch()
+    assert hs.status() == 0
+    torch.cuda.synchronize()
+    in_base, out_base = hs.d_in.data_ptr(), hs.d_out.data_ptr()
+    tasks, outs = [], []
+    enc_kind = {_ffi.K_COPY: _ffi.K_ENC_COPY, _ffi.K_DEC128: _ffi.K_ENC_DEC128, _ffi.K_STR32: _ffi.K_ENC_STR32}
+    for lay in hs.layout:
+        n = lay["nrows"]
+        for e in lay["columns"]:
+            spans = e["buffers"]
+            nb = 3 if e["kind"] == _ffi.K_STR32 else 2
+            o_valid = torch.zeros((n + 7) // 8 + 16, dtype=torch.uint8, device="cuda")
+            o_b1 = torch.zeros(spans[1][1] + 16, dtype=torch.uint8, device="cuda")
+            o_b2 = torch.zeros(spans[2][1] + 16, dtype=torch.uint8, device="cuda") if nb == 3 else None
+            outs.append((lay, e, o_valid, o_b1, o_b2))
+            tasks.append(da.make_task(enc_kind[e["kind"]], n, out_base + e["data_off"], o_b1.data_ptr(),
+                                      validity=out_base + e["valid_off"], out_validity=o_valid.data_ptr(),
+                                      out_aux=o_b2.data_ptr() if nb == 3 else 0, buf2=in_base, ptr_base=0,
+                                      buf2_len=spans[2][1] if nb == 3 else 0, param=e["param"] if e["kind"] != _ffi.K_STR32 else 0))
+    # string_t pointers produced by the decode hold absolute stream positions (ptr_base = position of the data buffer),
+    # so the "heap" of the encode tasks is the resident stream itself
+    plan = da.Plan(con.ctx, tasks)
+    plan.launch(torch.cuda.current_stream().cuda_stream)
+    assert plan.status() == 0
+    assert plan.null_counts() == [0] * len(tasks)
+    host = buf
+    for lay, e, o_valid, o_b1, o_b2 in outs:
+        body = lay["body_off"]
+        spans = e["buffers"]
+        n = lay["nrows"]
+        want_valid = host[body + spans[0][0]: body + spans[0][0] + (n + 7) // 8].copy()
+        if n & 7:
+            want_valid[-1] |= (0xFF << (n & 7)) & 0xFF  # ArrowAppender pads with 1s (ResizeValidity 0xFF)
+        assert np.array_equal(o_valid.cpu().numpy()[: (n + 7) // 8], want_valid), e["name"]
+        assert np.array_equal(o_b1.cpu().numpy()[: spans[1][1]], host[body + spans[1][0]: body + spans[1][0] + spans[1][1]]), e["name"]
+        if o_b2 is not None:
+            assert np.array_equal(o_b2.cpu().numpy()[: spans[2][1]], host[body + spans[2][0]: body + spans[2][0] + spans[2][1]]), e["name"]
+
+
+def test_encode_kernels_match_oracle_with_nulls(con, torch):
+    rng = np.random.default_rng(11)
+    n = 5000
+    ok = rng.random(n) < 0.8
+    valid = np.packbits(np.concatenate([ok, np.ones((-n) % 64, bool)]), bitorder="little").view(np.uint64).copy()
+    d_valid = torch.from_numpy(valid.view(np.uint8).copy()).cuda()
+
+    def run(kind, src, out_bytes, param=0, aux_bytes=0, heap=None, buf2_len=0):
+        d_src = torch.from_numpy(np.ascontiguousarray(src).view(np.uint8).copy()).cuda()
+        d_heap = torch.from_numpy(heap.copy()).cuda() if heap is not None else None
+        o_valid = torch.zeros((n + 7) // 8 + 16, dtype=torch.uint8, device="cuda")
+        o_data = torch.zeros(out_bytes + 16, dtype=torch.uint8, device="cuda")
+        o_aux = torch.zeros(aux_bytes + 16, dtype=torch.uint8, device="cuda")
+        t = da.make_task(kind, n, d_src.data_ptr(), o_data.data_ptr(), validity=d_valid.data_ptr(), out_validity=o_valid.data_ptr(),
+                         out_aux=o_aux.data_ptr(), buf2=d_heap.data_ptr() if d_heap is not None else 0, ptr_base=0, param=param,
+                         buf2_len=buf2_len)
+        plan = da.Plan(con.ctx, [t])
+        plan.launch(torch.cuda.current_stream().cuda_stream)
+        assert plan.status() == 0
+        return (o_valid.cpu().numpy()[: (n + 7) // 8], o_data.cpu().numpy()[:out_bytes], o_aux.cpu().numpy()[:aux_bytes],
+                plan.null_counts()[0])
+
+    want_bitmap = np.full((n + 7) // 8, 0xFF, np.uint8)
+    nulls = C.c_int64(0)
+    po.lib().orc_enc_validity(valid.ctypes.data, n, 0, want_bitmap.ctypes.data, C.byref(nulls))
+    # decimal widen
+    for w, dt in ((2, np.int16), (4, np.int32), (8, np.int64)):
+        src = rng.integers(np.iinfo(dt).min, np.iinfo(dt).max, n).astype(dt)
+        bitmap, data, _, nc = run(_ffi.K_ENC_DEC128, src, 16 * n, param=w)
+        want = np.zeros(16 * n, np.uint8)
+        po.lib().orc_enc_decimal_widen(src.ctypes.data, w, n, want.ctypes.data)
+        assert np.array_equal(data, want) and np.array_equal(bitmap, want_bitmap) and nc == nulls.value
+    # bool pack
+    src = (rng.random(n) < 0.5).astype(np.uint8)
+    bitmap, data, _, nc = run(_ffi.K_ENC_BOOL, src, (n + 7) // 8)
+    want = np.full((n + 7) // 8, 0xFF, np.uint8)
+    po.lib().orc_enc_bool(src.ctypes.data, valid.ctypes.data, n, 0, want.ctypes.data)
+    assert np.array_equal(data, want)
+    # varchar: inline + long strings, NULLs repeat the previous offset
+    lens = rng.integers(0, 40, n)
+    heap = rng.integers(32, 127, int(lens.sum()) + 16, dtype=np.uint8)
+    str16 = np.zeros((n, 16), np.uint8)
+    pos = 0
+    for i in range(n):
+        ln = int(lens[i])
+        str16[i, :4] = np.frombuffer(np.uint32(ln).tobytes(), np.uint8)
+        if ln <= 12:
+            str16[i, 4: 4 + ln] = heap[pos: pos + ln]
+        else:
+            str16[i, 4:8] = heap[pos: pos + 4]
+            str16[i, 8:16] = np.frombuffer(np.uint64(pos).tobytes(), np.uint8)
+        pos += ln
+    payload = int(lens[ok].sum())
+    bitmap, off, data, nc = run(_ffi.K_ENC_STR32, str16.reshape(-1), 4 * (n + 1), aux_bytes=payload, heap=heap, buf2_len=payload)
+    want_off = np.zeros(n + 1, np.int32)
+    want_data = np.zeros(payload + 1, np.uint8)
+    rc = po.lib().orc_enc_varchar32(str16.ctypes.data, valid.ctypes.data, n, 0, 0, heap.ctypes.data, want_off.ctypes.data,
+                                    want_data.ctypes.data)
+    assert rc == 0 and np.array_equal(off.view(np.int32), want_off) and np.array_equal(data, want_data[:payload])
+    assert nc == nulls.value
+
+
+# ---------------------------------------------------------------------------------------- test_arrow_ipc_writer.py
+def create_table():
+    return da.Table(["f0", "f1", "f2"], ["INTEGER", "VARCHAR", "BOOLEAN"],
+                    [[1, 2, 3, 4], ["foo", "bar", "baz", None], [True, None, False, True]])
+
+
+ROWS = [(1, "foo", True), (2, "bar", None), (3, "baz", False), (4, None, True)]
+
+
+def test_round_trip(con):
+    buffers = con.to_arrow_ipc(create_table())
+    buffer = pa.py_buffer(buffers[0][0] + buffers[1][0])
+    with pa.BufferReader(buffer) as buf_reader:
+        msg_reader = ipc.MessageReader.open_stream(buf_reader)
+        assert con.from_arrow(msg_reader).fetchall() == ROWS
+
+
+def test_arrow_read_duck_buffers(con):
+    buffers = con.to_arrow_ipc(create_table())
+    assert buffers[0][1] is True and buffers[1][1] is False and len(buffers) == 2
+    with pa.BufferReader(pa.py_buffer(buffers[0][0] + buffers[1][0])) as reader:
+        stream_reader = ipc.RecordBatchStreamReader(reader)
+        schema = stream_reader.schema
+        batches = list(stream_reader)
+    t = pa.Table.from_batches(batches, schema=schema)
+    assert t.schema.types == [pa.int32(), pa.string(), pa.bool_()]
+    assert t.to_pylist() == [dict(f0=a, f1=b, f2=c) for a, b, c in ROWS]
+    # ArrowAppender always emits the validity bitmap and counts NULLs
+    assert [c.null_count for c in t.columns] == [0, 1, 1]
+
+
+def test_to_arrow_ipc_chunks_of_120_vectors(con):
+    """to_arrow_ipc.test: one blob per 120 x 2048 rows (+ the schema blob)."""
+    n = 2 * 120 * 2048 + 5
+    t = da.Table(["a"], ["BIGINT"], [list(range(n))])
+    blobs = con.to_arrow_ipc(t)
+    assert [h for _, h in blobs] == [True, False, False, False]
+    table = ipc.open_stream(pa.py_buffer(b"".join(b for b, _ in blobs))).read_all()
+    assert table.num_rows == n and table["a"].to_pylist() == list(range(n))
+    assert [len(b) for b in table["a"].chunks] == [245760, 245760, 5]
+
+
+# ---------------------------------------------------------------------------------------- write_arrow_stream.test / test_copy_to.test
+def commits_table(con, golden_dir):
+    rel = con.read_arrow(os.path.join(golden_dir, "ref_data/test.arrows"))
+    cols = rel.fetch_columns()
+    return da.Table(rel.columns, rel.types, cols)
+
+
+def test_copy_roundtrip_basic(con, tmp_path):
+    p = str(tmp_path / "test.arrows")
+    con.copy_to(da.Table(["foofy", "stringy"], ["INTEGER", "VARCHAR"], [[42], ["string"]]), p)
+    assert con.read_arrow(p).fetchall() == [(42, "string")]
+    assert con.read_arrow(p).project(["stringy"]).fetchall() == [("string",)]
+    assert read_any(p).to_pylist() == [{"foofy": 42, "stringy": "string"}]
+
+
+def test_write_then_read_equals_source(con, golden_dir, tmp_path):
+    """write_arrow_stream.test:11-25: every row of the rewritten file equals the original."""
+    t = commits_table(con, golden_dir)
+    p = str(tmp_path / "rewritten.arrows")
+    assert con.copy_to(t, p) == [p]
+    back = con.read_arrow(p)
+    assert back.types == t.types and back.fetch_columns() == t.columns
+    orig = read_any(os.path.join(golden_dir, "ref_data/test.arrows"))
+    mine = read_any(p)
+    assert mine.num_rows == 15487 and mine.equals(orig.cast(mine.schema))
+    assert mine.schema.field("time").type == pa.timestamp("us", tz="UTC")
+
+
+def test_copy_options(con, golden_dir, tmp_path):
+    t = commits_table(con, golden_dir)
+    for opts in ({"row_group_size": 10}, {"chunk_size": 10}):
+        p = str(tmp_path / ("rg_%s.arrow" % list(opts)[0]))
+        con.copy_to(t, p, **opts)
+        assert con.read_arrow(p).count() == 15487
+        # "This actually has a minimum of 2048": one record batch per sunk DataChunk
+        assert [b.num_rows for b in ipc.open_stream(p)] == [2048] * 7 + [1151]
+    with pytest.raises(da.MiError, match="ROW_GROUP_SIZE and ROW_GROUP_SIZE_BYTES are mutually exclusive"):
+        con.copy_to(t, str(tmp_path / "x.arrow"), row_group_size=100, chunk_size=10)
+    with pytest.raises(da.MiError, match="ROW_GROUP_SIZE_BYTES does not work while preserving insertion order"):
+        con.copy_to(t, str(tmp_path / "x.arrow"), row_group_size_bytes=100)
+    p = str(tmp_path / "rgb.arrow")
+    con.copy_to(t, p, preserve_insertion_order=False, row_group_size_bytes=100)
+    assert con.read_arrow(p).count() == 15487
+
+
+def test_row_groups_per_file_rotation(con, golden_dir, tmp_path):
+    t = commits_table(con, golden_dir)
+    d = str(tmp_path / "folder")
+    files = con.copy_to(t, d, chunk_size=10, row_groups_per_file=1, format="ARROW")
+    assert sorted(files) == sorted(glob.glob(os.path.join(d, "*")))
+    assert len(files) == 9  # 8 data-bearing files + the one opened by the last rotation (test_copy_to.test:66-75 counts 9)
+    assert con.read_arrow(os.path.join(d, "*")).count() == 15487
+
+
+def test_kv_metadata(con, golden_dir, tmp_path):
+    t = commits_table(con, golden_dir)
+    p = str(tmp_path / "data_kv.arrow")
+    con.copy_to(t, p, kv_metadata={"test": "works", "blob": b"\x00\x01"})
+    assert con.read_arrow(p).count() == 15487
+    assert read_any(p).schema.metadata == {b"test": b"works", b"blob": b"\x00\x01"}
+    assert dict(da.Reader(path=p).schema_metadata()) == {"test": b"works", "blob": b"\x00\x01"}
+
+
+def test_every_writable_type_roundtrips_through_pyarrow(con, tmp_path):
+    n = 3000
+    rng = np.random.default_rng(4)
+
+    def nullable(vals):
+        return [None if rng.random() < 0.15 else v for v in vals]
+
+    cols = {
+        ("b", "BOOLEAN"): nullable([bool(x) for x in rng.integers(0, 2, n)]),
+        ("i8", "TINYINT"): nullable(rng.integers(-128, 127, n).tolist()),
+        ("u16", "USMALLINT"): nullable(rng.integers(0, 65535, n).tolist()),
+        ("i32", "INTEGER"): nullable(rng.integers(-2**31, 2**31 - 1, n).tolist()),
+        ("i64", "BIGINT"): nullable(rng.integers(-2**63, 2**63 - 1, n).tolist()),
+        ("u64", "UBIGINT"): nullable((rng.integers(0, 2**63 - 1, n) * 2).tolist()),
+        ("f64", "DOUBLE"): nullable(rng.standard_normal(n).tolist()),
+        ("d4", "DECIMAL(4,1)"): nullable(rng.integers(-9999, 9999, n).tolist()),
+        ("d15", "DECIMAL(15,2)"): nullable(rng.integers(-10**15 + 1, 10**15 - 1, n).tolist()),
+        ("d38", "DECIMAL(38,5)"): nullable([int(x) * 10**15 + 7 for x in rng.integers(-10**18, 10**18, n)]),
+        ("dt", "DATE"): nullable(rng.integers(-10000, 20000, n).tolist()),
+        ("ts", "TIMESTAMP"): nullable(rng.integers(-10**15, 2 * 10**15, n).tolist()),
+        ("s", "VARCHAR"): nullable([("x" * int(k)) + str(i) for i, k in enumerate(rng.integers(0, 30, n))]),
+        ("bl", "BLOB"): nullable([bytes(rng.integers(0, 255, int(k)).astype(np.uint8)) for k in rng.integers(0, 30, n)]),
+    }
+    t = da.Table([k[0] for k in cols], [k[1] for k in cols], list(cols.values()))
+    p = str(tmp_path / "types.arrows")
+    con.copy_to(t, p, row_group_size=1000)
+    back = con.read_arrow(p)
+    assert back.types == t.types
+    assert back.fetch_columns() == t.columns
+    pt = read_any(p)
+    assert pt.num_rows == n
+    import decimal
+    for (name, dt), vals in cols.items():
+        got = pt[name].to_pylist()
+        if dt.startswith("DECIMAL"):
+            scale = int(dt[dt.index(",") + 1: -1])
+            got = [None if v is None else int(v.scaleb(scale)) for v in got]
+        elif dt == "DATE":
+            got = pt[name].cast(pa.int32()).to_pylist()
+        elif dt == "TIMESTAMP":
+            got = pt[name].cast(pa.int64()).to_pylist()
+        assert got == vals, name
