@@ -258,7 +258,7 @@ def test_every_writable_type_roundtrips_through_pyarrow(con, tmp_path):
         ("u16", "USMALLINT"): nullable(rng.integers(0, 65535, n).tolist()),
         ("i32", "INTEGER"): nullable(rng.integers(-2**31, 2**31 - 1, n).tolist()),
         ("i64", "BIGINT"): nullable(rng.integers(-2**63, 2**63 - 1, n).tolist()),
-        ("u64", "UBIGINT"): nullable((rng.integers(0, 2**63 - 1, n) * 2).tolist()),
+        ("u64", "UBIGINT"): nullable((rng.integers(0, 2**63 - 1, n).astype(np.uint64) * np.uint64(2)).tolist()),
         ("f64", "DOUBLE"): nullable(rng.standard_normal(n).tolist()),
         ("d4", "DECIMAL(4,1)"): nullable(rng.integers(-9999, 9999, n).tolist()),
         ("d15", "DECIMAL(15,2)"): nullable(rng.integers(-10**15 + 1, 10**15 - 1, n).tolist()),
