@@ -182,6 +182,8 @@ void Plan::Set(const mi_col_task* in_tasks, int32_t n_tasks, hipStream_t upload_
   tasks.clear();
   order.clear();
   tile_begin.clear();
+  tile_task.clear();
+  class_tile_task_at.assign(device::kNumClasses, 0);
   total_tiles = 0;
   bytes_read = bytes_written = rows = 0;
   for (int c = 0; c < device::kNumClasses; c++) class_bytes_read[c] = class_bytes_written[c] = class_rows[c] = 0;
@@ -213,10 +215,15 @@ void Plan::Set(const mi_col_task* in_tasks, int32_t n_tasks, hipStream_t upload_
     s.n_tasks = static_cast<int32_t>(by_class[static_cast<size_t>(c)].size());
     s.tile_begin_at = static_cast<int32_t>(tile_begin.size());
     uint64_t tiles = 0;
+    class_tile_task_at[static_cast<size_t>(c)] = tile_task.size();
+    uint32_t local_task = 0;
     for (auto& t : by_class[static_cast<size_t>(c)]) {
       tile_begin.push_back(static_cast<uint32_t>(tiles));
-      tiles += static_cast<uint64_t>((t.nrows + device::kTileRows - 1) / device::kTileRows);
+      const uint64_t nt = static_cast<uint64_t>((t.nrows + device::kTileRows - 1) / device::kTileRows);
+      tiles += nt;
       if (tiles > 0xFFFFFFF0ull) throw InvalidInputException("plan has too many tiles");
+      if (c < device::kClassEncFixed) tile_task.insert(tile_task.end(), static_cast<size_t>(nt), local_task);
+      local_task++;
       tasks.push_back(t);
     }
     tile_begin.push_back(static_cast<uint32_t>(tiles));
@@ -227,6 +234,8 @@ void Plan::Set(const mi_col_task* in_tasks, int32_t n_tasks, hipStream_t upload_
   const size_t old_cap_tasks = cap_tasks, old_cap_tb = cap_tile_begin;
   EnsureDevice(&d_tasks, &cap_tasks, tasks.size());
   EnsureDevice(&d_tile_begin, &cap_tile_begin, tile_begin.size());
+  const size_t old_cap_tt = cap_tile_task;
+  EnsureDevice(&d_tile_task, &cap_tile_task, tile_task.size());
   if (!d_status) {
     MI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_status), 64));
     MI_HIP_CHECK(hipMemset(d_status, 0, 64));
@@ -253,10 +262,20 @@ void Plan::Set(const mi_col_task* in_tasks, int32_t n_tasks, hipStream_t upload_
     }
     std::memcpy(h_tile_begin, tile_begin.data(), tile_begin.size() * sizeof(uint32_t));
     MI_HIP_CHECK(hipMemcpyAsync(d_tile_begin, h_tile_begin, tile_begin.size() * sizeof(uint32_t), hipMemcpyHostToDevice, upload_stream));
+    if (cap_tile_task != old_cap_tt || !h_tile_task) {
+      if (h_tile_task) MI_HIP_CHECK(hipHostFree(h_tile_task));
+      MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_tile_task), cap_tile_task * sizeof(uint32_t), hipHostMallocDefault));
+    }
+    if (!tile_task.empty()) {
+      std::memcpy(h_tile_task, tile_task.data(), tile_task.size() * sizeof(uint32_t));
+      MI_HIP_CHECK(hipMemcpyAsync(d_tile_task, h_tile_task, tile_task.size() * sizeof(uint32_t), hipMemcpyHostToDevice, upload_stream));
+    }
   } else {
     if (!tasks.empty())
       MI_HIP_CHECK(hipMemcpy(d_tasks, tasks.data(), tasks.size() * sizeof(mi_col_task), hipMemcpyHostToDevice));
     MI_HIP_CHECK(hipMemcpy(d_tile_begin, tile_begin.data(), tile_begin.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (!tile_task.empty())
+      MI_HIP_CHECK(hipMemcpy(d_tile_task, tile_task.data(), tile_task.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
 }
 
@@ -268,6 +287,8 @@ Plan::~Plan() {
   if (d_null_counts) (void)hipFree(d_null_counts);
   if (h_tasks) (void)hipHostFree(h_tasks);
   if (h_tile_begin) (void)hipHostFree(h_tile_begin);
+  if (d_tile_task) (void)hipFree(d_tile_task);
+  if (h_tile_task) (void)hipHostFree(h_tile_task);
 }
 
 void Plan::LaunchClass(int c, hipStream_t s) {
@@ -286,7 +307,8 @@ void Plan::LaunchClass(int c, hipStream_t s) {
       MI_HIP_CHECK(device::LaunchEncodeString(t, tb, cs.n_tasks, cs.total_tiles, d_tile_sums, d_null_counts, grid, s));
       break;
     default:
-      MI_HIP_CHECK(device::LaunchTranscode(c, t, tb, cs.n_tasks, cs.total_tiles, d_status, grid, s));
+      MI_HIP_CHECK(device::LaunchTranscode(c, t, tb, d_tile_task + class_tile_task_at[static_cast<size_t>(c)], cs.n_tasks,
+                                           cs.total_tiles, d_status, ctx->num_cus, s));
       break;
   }
 }

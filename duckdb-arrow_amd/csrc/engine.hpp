@@ -53,6 +53,11 @@ struct Plan {
   ClassSlice classes[device::kNumClasses];
   mi_col_task* d_tasks = nullptr;
   uint32_t* d_tile_begin = nullptr;
+  uint32_t* d_tile_task = nullptr;   // per class slice: task index (within the slice) of every tile
+  uint32_t* h_tile_task = nullptr;
+  size_t cap_tile_task = 0;
+  std::vector<uint32_t> tile_task;
+  std::vector<size_t> class_tile_task_at;
   uint32_t* d_status = nullptr;
   int64_t* d_tile_sums = nullptr;    // encode plans with string columns
   int64_t* d_null_counts = nullptr;  // encode plans: one counter per task

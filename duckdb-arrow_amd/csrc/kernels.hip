@@ -23,6 +23,9 @@
 
 #include "kernels.hpp"
 
+#include <cstdlib>
+#include <string>
+
 namespace miarrow {
 namespace device {
 
@@ -66,8 +69,11 @@ __device__ __forceinline__ int find_task(const uint32_t* __restrict__ tile_begin
   return lo;
 }
 
+// tile_task (optional): task index of every tile, so the owner of a tile is one scalar load instead of a ~13-step
+// dependent binary search
 #define MI_TILE_PROLOGUE()                                                                          \
-  const int ti = __builtin_amdgcn_readfirstlane(find_task(tile_begin, n_tasks, tile));             \
+  const int ti = __builtin_amdgcn_readfirstlane(                                                    \
+      tile_task ? static_cast<int>(tile_task[tile]) : find_task(tile_begin, n_tasks, tile));       \
   const mi_col_task& t = tasks[ti];                                                                 \
   const int64_t row0 = static_cast<int64_t>(tile - tile_begin[ti]) * kTileRows;                     \
   const int64_t left = t.nrows - row0;                                                              \
@@ -124,42 +130,86 @@ __device__ __forceinline__ void copy_vec(gptr<const uint8_t> src, gptr<uint8_t> 
   for (int j = nvec * VB + threadIdx.x; j < bytes; j += kBlockThreads) dst[j] = src[j];
 }
 
-__device__ __forceinline__ void copy_bytes(gptr<const uint8_t> src, gptr<uint8_t> dst, int bytes) {
+// 16-byte vector whose loads may sit on any 4-byte boundary: gfx950 runs global memory in unaligned-access mode, so a
+// global_load_dwordx4 from an 8-mod-16 address is legal; IPC buffers are only 8-byte aligned (after an odd-length
+// offsets buffer every following buffer of the body is 8 mod 16), the destination vectors are always 16-byte aligned.
+typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
+
+template <bool NT>
+__device__ __forceinline__ u32x4 ld16(gptr<const u32x4_a4> p) {
+  if (NT) return __builtin_nontemporal_load(p);
+  return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st16(gptr<u32x4> p, u32x4 v) {
+  if (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
+template <bool NT>
+__device__ __forceinline__ void copy_vec16_unaligned_src(gptr<const uint8_t> src, gptr<uint8_t> dst, int bytes) {
+  const int nvec = bytes / 16;
+  gptr<const u32x4_a4> s = (gptr<const u32x4_a4>)src;
+  gptr<u32x4> d = (gptr<u32x4>)dst;
+  int i = threadIdx.x;
+#pragma clang loop unroll(disable)
+  for (; i + 3 * kBlockThreads < nvec; i += 4 * kBlockThreads) {
+    u32x4 a = ld16<NT>(s + i), b = ld16<NT>(s + i + kBlockThreads), c = ld16<NT>(s + i + 2 * kBlockThreads),
+          e = ld16<NT>(s + i + 3 * kBlockThreads);
+    st16<NT>(d + i, a);
+    st16<NT>(d + i + kBlockThreads, b);
+    st16<NT>(d + i + 2 * kBlockThreads, c);
+    st16<NT>(d + i + 3 * kBlockThreads, e);
+  }
+#pragma clang loop unroll(disable)
+  for (; i < nvec; i += kBlockThreads) st16<NT>(d + i, ld16<NT>(s + i));
+#pragma clang loop unroll(disable) vectorize(disable)
+  for (int j = nvec * 16 + threadIdx.x; j < bytes; j += kBlockThreads) dst[j] = src[j];
+}
+
+__device__ __forceinline__ void copy_bytes(gptr<const uint8_t> src, gptr<uint8_t> dst, int bytes, int variant = 0) {
   const uintptr_t a = reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst);
+  if (variant >= 1 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0) {
+    if (variant == 2) copy_vec16_unaligned_src<true>(src, dst, bytes);
+    else copy_vec16_unaligned_src<false>(src, dst, bytes);
+    return;
+  }
   if ((a & 15) == 0) copy_vec<u32x4>(src, dst, bytes);
   else if ((a & 7) == 0) copy_vec<u32x2>(src, dst, bytes);
   else if ((a & 3) == 0) copy_vec<uint32_t>(src, dst, bytes);
   else copy_vec<uint8_t>(src, dst, bytes);
 }
 
+template <int VARIANT>
 __global__ __launch_bounds__(kBlockThreads) void transcode_copy(const mi_col_task* __restrict__ tasks,
-                                                                const uint32_t* __restrict__ tile_begin, int n_tasks,
+                                                                const uint32_t* __restrict__ tile_begin,
+                                                                const uint32_t* __restrict__ tile_task, int n_tasks,
                                                                 uint32_t total_tiles, uint32_t* __restrict__ status) {
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     MI_TILE_PROLOGUE();
     tile_validity(t, row0, n);
     const int w = static_cast<int>(t.param);
-    copy_bytes(GC<uint8_t>(t.buf1) + (t.row_offset + row0) * w, GM<uint8_t>(t.out_data) + row0 * w, n * w);
+    copy_bytes(GC<uint8_t>(t.buf1) + (t.row_offset + row0) * w, GM<uint8_t>(t.out_data) + row0 * w, n * w, VARIANT);
   }
 }
 
 // ---------------------------------------------------------------------------------------------------- K3b
 // decimal128 {u64 lower, i64 upper} -> int16/32/64 for valid rows (Hugeint::TryCast: value fits by precision);
 // NULL rows canonical 0.  Each lane reads the whole 16-byte value (the upper half is what proves the range).
-template <typename OUT>
+template <typename OUT, int VARIANT>
 __device__ __forceinline__ void tile_dec128(const mi_col_task& t, int64_t row0, int n, uint32_t* status) {
   gptr<const uint8_t> src = GC<uint8_t>(t.buf1) + (t.row_offset + row0) * 16;
   gptr<OUT> out = GM<OUT>(t.out_data) + row0;
   gptr<const uint8_t> bitmap = GC<uint8_t>(t.validity);
   const bool has_nulls = t.validity != nullptr && t.null_count != 0;
-  const bool a16 = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+  const bool a16 = VARIANT == 1 || (reinterpret_cast<uintptr_t>(src) & 15) == 0;
   uint32_t err = 0;
 #pragma unroll 4
   for (int r = threadIdx.x; r < n; r += kBlockThreads) {
     uint64_t lower;
     int64_t upper;
     if (a16) {
-      const u32x4 v = *(gptr<const u32x4>)(src + 16 * static_cast<int64_t>(r));
+      const u32x4 v = *(gptr<const u32x4_a4>)(src + 16 * static_cast<int64_t>(r));
       lower = static_cast<uint64_t>(v.x) | (static_cast<uint64_t>(v.y) << 32);
       upper = static_cast<int64_t>(static_cast<uint64_t>(v.z) | (static_cast<uint64_t>(v.w) << 32));
     } else {
@@ -178,15 +228,17 @@ __device__ __forceinline__ void tile_dec128(const mi_col_task& t, int64_t row0, 
   raise(status, err);
 }
 
+template <int VARIANT>
 __global__ __launch_bounds__(kBlockThreads) void transcode_dec128(const mi_col_task* __restrict__ tasks,
-                                                                  const uint32_t* __restrict__ tile_begin, int n_tasks,
+                                                                  const uint32_t* __restrict__ tile_begin,
+                                                                  const uint32_t* __restrict__ tile_task, int n_tasks,
                                                                   uint32_t total_tiles, uint32_t* __restrict__ status) {
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     MI_TILE_PROLOGUE();
     tile_validity(t, row0, n);
-    if (t.param == 8) tile_dec128<int64_t>(t, row0, n, status);
-    else if (t.param == 4) tile_dec128<int32_t>(t, row0, n, status);
-    else tile_dec128<int16_t>(t, row0, n, status);
+    if (t.param == 8) tile_dec128<int64_t, VARIANT>(t, row0, n, status);
+    else if (t.param == 4) tile_dec128<int32_t, VARIANT>(t, row0, n, status);
+    else tile_dec128<int16_t, VARIANT>(t, row0, n, status);
   }
 }
 
@@ -252,6 +304,58 @@ __device__ __forceinline__ void tile_string(const mi_col_task& t, int64_t row0, 
   raise(status, err);
 }
 
+// Variant 1: every lane owns the 8 rows {tid + 256k} of the tile and issues all its loads before the first store
+// (8 independent offset loads, then up to 8 x 4 payload dwords), so one wave has 8 rows in flight instead of 2.
+// off[r+1] comes from the neighbouring lane (one DPP/permute) except at the wave edge and at the last row.
+template <typename OFF>
+__device__ __forceinline__ void tile_string_deep(const mi_col_task& t, int64_t row0, int n, uint32_t* status) {
+  constexpr int R = kTileRows / kBlockThreads;
+  gptr<const OFF> off = GC<OFF>(t.buf1) + t.row_offset + row0;
+  gptr<const uint8_t> data = GC<uint8_t>(t.buf2);
+  gptr<u32x4> out = GM<u32x4>(t.out_data) + row0;
+  gptr<const uint8_t> bitmap = GC<uint8_t>(t.validity);
+  const bool has_nulls = t.validity != nullptr && t.null_count != 0;
+  const int64_t data_len = t.buf2_len;
+  const int lane = threadIdx.x & 63;
+  OFF a[R], b[R];
+#pragma unroll
+  for (int k = 0; k < R; k++) {
+    const int r = threadIdx.x + k * kBlockThreads;
+    a[k] = r < n ? off[r] : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < R; k++) {
+    const int r = threadIdx.x + k * kBlockThreads;
+    const OFF from_neighbour = __shfl_down(a[k], 1, 64);
+    const bool edge = lane == 63 || r == n - 1;
+    b[k] = (r < n && edge) ? off[r + 1] : from_neighbour;
+  }
+  uint32_t err = 0;
+  u32x4 s[R];
+#pragma unroll
+  for (int k = 0; k < R; k++) {
+    const int r = threadIdx.x + k * kBlockThreads;
+    s[k] = u32x4{0u, 0u, 0u, 0u};
+    if (r < n) {
+      const int64_t aa = static_cast<int64_t>(a[k]), bb = static_cast<int64_t>(b[k]);
+      const bool sane = aa >= 0 && bb >= aa && bb <= data_len;
+      if (!sane) {
+        err |= MI_ST_BAD_OFFSETS;
+      } else if (sizeof(OFF) == 8 && bb > 0xFFFFFFFFll) {
+        err |= MI_ST_STRING_TOO_LARGE;
+      } else if (row_valid(bitmap, has_nulls, t.row_offset + row0 + r)) {
+        s[k] = make_string_t(data, aa, static_cast<uint32_t>(bb - aa), t.ptr_base);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < R; k++) {
+    const int r = threadIdx.x + k * kBlockThreads;
+    if (r < n) out[r] = s[k];
+  }
+  raise(status, err);
+}
+
 // fixed_size_binary(width) -> string_t
 __device__ __forceinline__ void tile_fixed_binary(const mi_col_task& t, int64_t row0, int n) {
   gptr<const uint8_t> data = GC<uint8_t>(t.buf1);
@@ -268,15 +372,23 @@ __device__ __forceinline__ void tile_fixed_binary(const mi_col_task& t, int64_t 
   }
 }
 
+template <int VARIANT>
 __global__ __launch_bounds__(kBlockThreads) void transcode_string(const mi_col_task* __restrict__ tasks,
-                                                                  const uint32_t* __restrict__ tile_begin, int n_tasks,
+                                                                  const uint32_t* __restrict__ tile_begin,
+                                                                  const uint32_t* __restrict__ tile_task, int n_tasks,
                                                                   uint32_t total_tiles, uint32_t* __restrict__ status) {
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     MI_TILE_PROLOGUE();
     tile_validity(t, row0, n);
-    if (t.kind == MI_K_STR32) tile_string<int32_t>(t, row0, n, status);
-    else if (t.kind == MI_K_STR64) tile_string<int64_t>(t, row0, n, status);
-    else tile_fixed_binary(t, row0, n);
+    if (VARIANT == 1) {
+      if (t.kind == MI_K_STR32) tile_string_deep<int32_t>(t, row0, n, status);
+      else if (t.kind == MI_K_STR64) tile_string_deep<int64_t>(t, row0, n, status);
+      else tile_fixed_binary(t, row0, n);
+    } else {
+      if (t.kind == MI_K_STR32) tile_string<int32_t>(t, row0, n, status);
+      else if (t.kind == MI_K_STR64) tile_string<int64_t>(t, row0, n, status);
+      else tile_fixed_binary(t, row0, n);
+    }
   }
 }
 
@@ -415,7 +527,8 @@ __device__ __forceinline__ void tile_dict(const mi_col_task& t, int64_t row0, in
 }
 
 __global__ __launch_bounds__(kBlockThreads) void transcode_misc(const mi_col_task* __restrict__ tasks,
-                                                                const uint32_t* __restrict__ tile_begin, int n_tasks,
+                                                                const uint32_t* __restrict__ tile_begin,
+                                                                const uint32_t* __restrict__ tile_task, int n_tasks,
                                                                 uint32_t total_tiles, uint32_t* __restrict__ status) {
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     MI_TILE_PROLOGUE();
@@ -549,6 +662,7 @@ __device__ __forceinline__ void enc_tile_bool(const mi_col_task& t, int64_t row0
 __global__ __launch_bounds__(kBlockThreads) void encode_fixed(const mi_col_task* __restrict__ tasks,
                                                               const uint32_t* __restrict__ tile_begin, int n_tasks,
                                                               uint32_t total_tiles, int64_t* __restrict__ null_counts) {
+  const uint32_t* tile_task = nullptr;
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     MI_TILE_PROLOGUE();
     enc_tile_validity(t, row0, n, null_counts);
@@ -596,6 +710,7 @@ __global__ __launch_bounds__(kBlockThreads) void encode_string_tile_sums(const m
                                                                          int n_tasks, uint32_t total_tiles,
                                                                          int64_t* __restrict__ tile_sums) {
   __shared__ int64_t lds4[kBlockThreads / 64];
+  const uint32_t* tile_task = nullptr;
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     MI_TILE_PROLOGUE();
     gptr<const uint32_t> lens = GC<uint32_t>(t.buf1) + 4 * row0;  // string_t.length every 16 B
@@ -640,6 +755,7 @@ __global__ __launch_bounds__(kBlockThreads) void encode_string(const mi_col_task
                                                                uint32_t total_tiles, const int64_t* __restrict__ tile_sums,
                                                                int64_t* __restrict__ null_counts) {
   __shared__ int64_t lds4[kBlockThreads / 64];
+  const uint32_t* tile_task = nullptr;
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     MI_TILE_PROLOGUE();
     enc_tile_validity(t, row0, n, null_counts);
@@ -703,26 +819,67 @@ int ClassOfKind(int32_t kind) {
   }
 }
 
-hipError_t LaunchTranscode(int cls, const mi_col_task* d_tasks, const uint32_t* d_tile_begin, int32_t n_tasks,
-                           uint32_t total_tiles, uint32_t* d_status, int grid_blocks, hipStream_t stream) {
+// Measurement knobs (A/B of kernel variants inside one process; see tools/ab_bench.py).  Defaults are the shipped
+// configuration; MI_TUNE_* environment variables or SetTune() override them.
+struct Tune {
+  int copy_variant = 1;    // 1: 16-byte loads from 8-byte aligned IPC buffers (unaligned-access mode)
+  int dec_variant = 1;
+  int string_variant = 1;  // 1: 8 rows per lane in flight
+  int blocks_per_cu = 0;   // 0: one workgroup per tile (the hardware dispatcher balances the tiles)
+  int use_tile_table = 1;
+};
+static Tune& TuneRef() {
+  static Tune t = [] {
+    Tune x;
+    auto env = [](const char* n, int d) { const char* v = std::getenv(n); return v ? std::atoi(v) : d; };
+    x.copy_variant = env("MI_TUNE_COPY", x.copy_variant);
+    x.dec_variant = env("MI_TUNE_DEC128", x.dec_variant);
+    x.string_variant = env("MI_TUNE_STRING", x.string_variant);
+    x.blocks_per_cu = env("MI_TUNE_GRID", x.blocks_per_cu);
+    x.use_tile_table = env("MI_TUNE_TILE_TABLE", x.use_tile_table);
+    return x;
+  }();
+  return t;
+}
+bool SetTune(const char* knob, int value) {
+  Tune& t = TuneRef();
+  const std::string k = knob ? knob : "";
+  if (k == "copy") t.copy_variant = value;
+  else if (k == "dec128") t.dec_variant = value;
+  else if (k == "string") t.string_variant = value;
+  else if (k == "grid") t.blocks_per_cu = value;
+  else if (k == "tile_table") t.use_tile_table = value;
+  else return false;
+  return true;
+}
+
+hipError_t LaunchTranscode(int cls, const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
+                           int32_t n_tasks, uint32_t total_tiles, uint32_t* d_status, int num_cus, hipStream_t stream) {
   if (total_tiles == 0) return hipSuccess;
-  const dim3 grid(grid_for(total_tiles, grid_blocks)), block(kBlockThreads);
+  const Tune& tune = TuneRef();
+  const uint32_t blocks = tune.blocks_per_cu > 0 ? grid_for(total_tiles, num_cus * tune.blocks_per_cu) : total_tiles;
+  const dim3 grid(blocks), block(kBlockThreads);
+  const uint32_t* tt = tune.use_tile_table ? d_tile_task : nullptr;
+#define MI_LAUNCH(KERNEL) hipLaunchKernelGGL(KERNEL, grid, block, 0, stream, d_tasks, d_tile_begin, tt, n_tasks, total_tiles, d_status)
   switch (cls) {
     case kClassCopy:
-      hipLaunchKernelGGL(transcode_copy, grid, block, 0, stream, d_tasks, d_tile_begin, n_tasks, total_tiles, d_status);
+      if (tune.copy_variant == 2) MI_LAUNCH(transcode_copy<2>);
+      else if (tune.copy_variant == 1) MI_LAUNCH(transcode_copy<1>);
+      else MI_LAUNCH(transcode_copy<0>);
       break;
     case kClassDec128:
-      hipLaunchKernelGGL(transcode_dec128, grid, block, 0, stream, d_tasks, d_tile_begin, n_tasks, total_tiles, d_status);
+      if (tune.dec_variant == 1) MI_LAUNCH(transcode_dec128<1>); else MI_LAUNCH(transcode_dec128<0>);
       break;
     case kClassString:
-      hipLaunchKernelGGL(transcode_string, grid, block, 0, stream, d_tasks, d_tile_begin, n_tasks, total_tiles, d_status);
+      if (tune.string_variant == 1) MI_LAUNCH(transcode_string<1>); else MI_LAUNCH(transcode_string<0>);
       break;
     case kClassMisc:
-      hipLaunchKernelGGL(transcode_misc, grid, block, 0, stream, d_tasks, d_tile_begin, n_tasks, total_tiles, d_status);
+      MI_LAUNCH(transcode_misc);
       break;
     default:
       return hipErrorInvalidValue;
   }
+#undef MI_LAUNCH
   return hipGetLastError();
 }
 

@@ -22,8 +22,12 @@ int ClassOfKind(int32_t kind);  // -1 for an unknown kind
 
 // One launch over a device-resident task table slice.  `tile_begin[i]` = first tile of task i within the slice,
 // tile_begin[n_tasks] = total_tiles.  `status` accumulates MI_ST_* bits.
-hipError_t LaunchTranscode(int cls, const mi_col_task* d_tasks, const uint32_t* d_tile_begin, int32_t n_tasks,
-                           uint32_t total_tiles, uint32_t* d_status, int grid_blocks, hipStream_t stream);
+// `tile_task[tile]` = task index of every tile of the slice (optional, NULL = binary search over tile_begin).
+hipError_t LaunchTranscode(int cls, const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
+                           int32_t n_tasks, uint32_t total_tiles, uint32_t* d_status, int num_cus, hipStream_t stream);
+// measurement knobs: "copy" | "dec128" | "string" = kernel variant, "grid" = workgroups per CU (0 = one per tile),
+// "tile_table" = 0/1
+bool SetTune(const char* knob, int value);
 
 // K6: range filter -> selection vector, one workgroup per 2048-row window.
 hipError_t LaunchFilterRange(const void* values, int32_t width, const void* validity, int64_t nrows, int64_t lo,
