@@ -202,14 +202,14 @@ __device__ __forceinline__ void tile_dec128(const mi_col_task& t, int64_t row0, 
   gptr<OUT> out = GM<OUT>(t.out_data) + row0;
   gptr<const uint8_t> bitmap = GC<uint8_t>(t.validity);
   const bool has_nulls = t.validity != nullptr && t.null_count != 0;
-  const bool a16 = VARIANT == 1 || (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+  const bool a16 = VARIANT >= 1 || (reinterpret_cast<uintptr_t>(src) & 15) == 0;
   uint32_t err = 0;
 #pragma unroll 4
   for (int r = threadIdx.x; r < n; r += kBlockThreads) {
     uint64_t lower;
     int64_t upper;
     if (a16) {
-      const u32x4 v = *(gptr<const u32x4_a4>)(src + 16 * static_cast<int64_t>(r));
+      const u32x4 v = ld16<VARIANT == 2>((gptr<const u32x4_a4>)(src + 16 * static_cast<int64_t>(r)));
       lower = static_cast<uint64_t>(v.x) | (static_cast<uint64_t>(v.y) << 32);
       upper = static_cast<int64_t>(static_cast<uint64_t>(v.z) | (static_cast<uint64_t>(v.w) << 32));
     } else {
@@ -223,7 +223,8 @@ __device__ __forceinline__ void tile_dec128(const mi_col_task& t, int64_t row0, 
       const int64_t sext = static_cast<int64_t>(o);
       if (static_cast<uint64_t>(sext) != lower || upper != (sext >> 63)) err = MI_ST_DECIMAL_RANGE;
     }
-    out[r] = o;
+    if (VARIANT == 2) __builtin_nontemporal_store(o, out + r);
+    else out[r] = o;
   }
   raise(status, err);
 }
@@ -307,7 +308,7 @@ __device__ __forceinline__ void tile_string(const mi_col_task& t, int64_t row0, 
 // Variant 1: every lane owns the 8 rows {tid + 256k} of the tile and issues all its loads before the first store
 // (8 independent offset loads, then up to 8 x 4 payload dwords), so one wave has 8 rows in flight instead of 2.
 // off[r+1] comes from the neighbouring lane (one DPP/permute) except at the wave edge and at the last row.
-template <typename OFF>
+template <typename OFF, int NT>
 __device__ __forceinline__ void tile_string_deep(const mi_col_task& t, int64_t row0, int n, uint32_t* status) {
   constexpr int R = kTileRows / kBlockThreads;
   gptr<const OFF> off = GC<OFF>(t.buf1) + t.row_offset + row0;
@@ -321,7 +322,7 @@ __device__ __forceinline__ void tile_string_deep(const mi_col_task& t, int64_t r
 #pragma unroll
   for (int k = 0; k < R; k++) {
     const int r = threadIdx.x + k * kBlockThreads;
-    a[k] = r < n ? off[r] : 0;
+    a[k] = r < n ? (NT >= 2 ? __builtin_nontemporal_load(off + r) : off[r]) : 0;
   }
 #pragma unroll
   for (int k = 0; k < R; k++) {
@@ -351,7 +352,10 @@ __device__ __forceinline__ void tile_string_deep(const mi_col_task& t, int64_t r
 #pragma unroll
   for (int k = 0; k < R; k++) {
     const int r = threadIdx.x + k * kBlockThreads;
-    if (r < n) out[r] = s[k];
+    if (r < n) {
+      if (NT >= 1) __builtin_nontemporal_store(s[k], out + r);
+      else out[r] = s[k];
+    }
   }
   raise(status, err);
 }
@@ -380,9 +384,9 @@ __global__ __launch_bounds__(kBlockThreads) void transcode_string(const mi_col_t
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     MI_TILE_PROLOGUE();
     tile_validity(t, row0, n);
-    if (VARIANT == 1) {
-      if (t.kind == MI_K_STR32) tile_string_deep<int32_t>(t, row0, n, status);
-      else if (t.kind == MI_K_STR64) tile_string_deep<int64_t>(t, row0, n, status);
+    if (VARIANT >= 1) {
+      if (t.kind == MI_K_STR32) tile_string_deep<int32_t, VARIANT - 1>(t, row0, n, status);
+      else if (t.kind == MI_K_STR64) tile_string_deep<int64_t, VARIANT - 1>(t, row0, n, status);
       else tile_fixed_binary(t, row0, n);
     } else {
       if (t.kind == MI_K_STR32) tile_string<int32_t>(t, row0, n, status);
@@ -868,10 +872,15 @@ hipError_t LaunchTranscode(int cls, const mi_col_task* d_tasks, const uint32_t* 
       else MI_LAUNCH(transcode_copy<0>);
       break;
     case kClassDec128:
-      if (tune.dec_variant == 1) MI_LAUNCH(transcode_dec128<1>); else MI_LAUNCH(transcode_dec128<0>);
+      if (tune.dec_variant == 2) MI_LAUNCH(transcode_dec128<2>);
+      else if (tune.dec_variant == 1) MI_LAUNCH(transcode_dec128<1>);
+      else MI_LAUNCH(transcode_dec128<0>);
       break;
     case kClassString:
-      if (tune.string_variant == 1) MI_LAUNCH(transcode_string<1>); else MI_LAUNCH(transcode_string<0>);
+      if (tune.string_variant == 3) MI_LAUNCH(transcode_string<3>);
+      else if (tune.string_variant == 2) MI_LAUNCH(transcode_string<2>);
+      else if (tune.string_variant == 1) MI_LAUNCH(transcode_string<1>);
+      else MI_LAUNCH(transcode_string<0>);
       break;
     case kClassMisc:
       MI_LAUNCH(transcode_misc);
