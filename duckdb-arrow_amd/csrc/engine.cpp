@@ -219,7 +219,8 @@ void Plan::Set(const mi_col_task* in_tasks, int32_t n_tasks, hipStream_t upload_
     uint32_t local_task = 0;
     for (auto& t : by_class[static_cast<size_t>(c)]) {
       tile_begin.push_back(static_cast<uint32_t>(tiles));
-      const uint64_t nt = static_cast<uint64_t>((t.nrows + device::kTileRows - 1) / device::kTileRows);
+      const int64_t tile_rows = device::TileRowsOfClass(c);
+      const uint64_t nt = static_cast<uint64_t>((t.nrows + tile_rows - 1) / tile_rows);
       tiles += nt;
       if (tiles > 0xFFFFFFF0ull) throw InvalidInputException("plan has too many tiles");
       if (c < device::kClassEncFixed) tile_task.insert(tile_task.end(), static_cast<size_t>(nt), local_task);

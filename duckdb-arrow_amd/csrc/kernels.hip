@@ -71,37 +71,38 @@ __device__ __forceinline__ int find_task(const uint32_t* __restrict__ tile_begin
 
 // tile_task (optional): task index of every tile, so the owner of a tile is one scalar load instead of a ~13-step
 // dependent binary search
-#define MI_TILE_PROLOGUE()                                                                          \
+#define MI_TILE_PROLOGUE() MI_TILE_PROLOGUE_ROWS(kTileRows)
+#define MI_TILE_PROLOGUE_ROWS(TILE_ROWS)                                                            \
   const int ti = __builtin_amdgcn_readfirstlane(                                                    \
       tile_task ? static_cast<int>(tile_task[tile]) : find_task(tile_begin, n_tasks, tile));       \
   const mi_col_task& t = tasks[ti];                                                                 \
-  const int64_t row0 = static_cast<int64_t>(tile - tile_begin[ti]) * kTileRows;                     \
+  const int64_t row0 = static_cast<int64_t>(tile - tile_begin[ti]) * (TILE_ROWS);                   \
   const int64_t left = t.nrows - row0;                                                              \
-  const int n = left < kTileRows ? static_cast<int>(left) : kTileRows;
+  const int n = left < (TILE_ROWS) ? static_cast<int>(left) : (TILE_ROWS);
 
 // ---------------------------------------------------------------------------------------------------- K1
 // Validity bitmap -> DuckDB validity_t words for one tile.  Word w of the tile holds rows [64w, 64w+64); the source
 // bit position is row_offset + row0 + 64w, realigned with a 64-bit funnel shift when it is not word aligned (the CPU
-// path's "copy n+1 bytes and shift right by o%8").  The first ceil(n/64) <= 32 lanes do the work.
+// path's "copy n+1 bytes and shift right by o%8").  One lane per output word.
 __device__ __forceinline__ void tile_validity(const mi_col_task& t, int64_t row0, int n) {
   if (t.out_validity == nullptr) return;
-  const int lane = threadIdx.x;
   const int nwords = (n + 63) >> 6;
-  if (lane >= nwords) return;
-  uint64_t w = ~0ull;
-  if (t.validity != nullptr && t.null_count != 0) {
-    gptr<const uint64_t> W = GC<uint64_t>(t.validity);
-    const int64_t bit = t.row_offset + row0 + 64 * lane;
-    const int64_t q = bit >> 6;
-    const int sh = static_cast<int>(bit & 63);
-    const int64_t last_q = (t.row_offset + t.nrows - 1) >> 6;  // last 8-byte word that holds a bit of this column
-    const uint64_t lo = W[q];
-    const uint64_t hi = (sh != 0 && q + 1 <= last_q) ? W[q + 1] : 0ull;
-    w = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+  for (int lane = threadIdx.x; lane < nwords; lane += kBlockThreads) {
+    uint64_t w = ~0ull;
+    if (t.validity != nullptr && t.null_count != 0) {
+      gptr<const uint64_t> W = GC<uint64_t>(t.validity);
+      const int64_t bit = t.row_offset + row0 + 64 * lane;
+      const int64_t q = bit >> 6;
+      const int sh = static_cast<int>(bit & 63);
+      const int64_t last_q = (t.row_offset + t.nrows - 1) >> 6;  // last 8-byte word that holds a bit of this column
+      const uint64_t lo = W[q];
+      const uint64_t hi = (sh != 0 && q + 1 <= last_q) ? W[q + 1] : 0ull;
+      w = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+    }
+    const int rem = n - 64 * lane;
+    if (rem < 64) w |= ~0ull << rem;  // canonical pad bits
+    GM<uint64_t>(t.out_validity)[(row0 >> 6) + lane] = w;
   }
-  const int rem = n - 64 * lane;
-  if (rem < 64) w |= ~0ull << rem;  // canonical pad bits
-  GM<uint64_t>(t.out_validity)[(row0 >> 6) + lane] = w;
 }
 
 // ---------------------------------------------------------------------------------------------------- K3a
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(kBlockThreads) void transcode_copy(const mi_col_tas
                                                                 const uint32_t* __restrict__ tile_task, int n_tasks,
                                                                 uint32_t total_tiles, uint32_t* __restrict__ status) {
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
-    MI_TILE_PROLOGUE();
+    MI_TILE_PROLOGUE_ROWS(kCopyTileRows);
     tile_validity(t, row0, n);
     const int w = static_cast<int>(t.param);
     copy_bytes(GC<uint8_t>(t.buf1) + (t.row_offset + row0) * w, GM<uint8_t>(t.out_data) + row0 * w, n * w, VARIANT);
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(kBlockThreads) void transcode_dec128(const mi_col_t
                                                                   const uint32_t* __restrict__ tile_task, int n_tasks,
                                                                   uint32_t total_tiles, uint32_t* __restrict__ status) {
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
-    MI_TILE_PROLOGUE();
+    MI_TILE_PROLOGUE_ROWS(kDecTileRows);
     tile_validity(t, row0, n);
     if (t.param == 8) tile_dec128<int64_t, VARIANT>(t, row0, n, status);
     else if (t.param == 4) tile_dec128<int32_t, VARIANT>(t, row0, n, status);
@@ -810,6 +811,14 @@ inline uint32_t grid_for(uint32_t total_tiles, int grid_blocks) {
 
 }  // namespace
 
+int TileRowsOfClass(int cls) {
+  switch (cls) {
+    case kClassCopy: return kCopyTileRows;
+    case kClassDec128: return kDecTileRows;
+    default: return kTileRows;
+  }
+}
+
 int ClassOfKind(int32_t kind) {
   switch (kind) {
     case MI_K_COPY: return kClassCopy;
@@ -826,9 +835,9 @@ int ClassOfKind(int32_t kind) {
 // Measurement knobs (A/B of kernel variants inside one process; see tools/ab_bench.py).  Defaults are the shipped
 // configuration; MI_TUNE_* environment variables or SetTune() override them.
 struct Tune {
-  int copy_variant = 1;    // 1: 16-byte loads from 8-byte aligned IPC buffers (unaligned-access mode)
-  int dec_variant = 1;
-  int string_variant = 1;  // 1: 8 rows per lane in flight
+  int copy_variant = 2;    // 1: 16-byte loads from 8-byte aligned IPC buffers (unaligned-access mode); 2: + nontemporal
+  int dec_variant = 2;
+  int string_variant = 2;  // 1: 8 rows per lane in flight; 2: + nontemporal stores
   int blocks_per_cu = 0;   // 0: one workgroup per tile (the hardware dispatcher balances the tiles)
   int use_tile_table = 1;
 };

@@ -12,6 +12,15 @@ namespace device {
 
 constexpr int kBlockThreads = 256;   // 4 waves of 64
 constexpr int kTileRows = 2048;      // rows per tile == DuckDB STANDARD_VECTOR_SIZE: one tile is one output vector
+#ifndef MI_COPY_TILE_ROWS
+#define MI_COPY_TILE_ROWS 2048
+#endif
+#ifndef MI_DEC_TILE_ROWS
+#define MI_DEC_TILE_ROWS 2048
+#endif
+constexpr int kCopyTileRows = MI_COPY_TILE_ROWS;  // copy / dec128 tiles may span several vectors (multiples of 2048)
+constexpr int kDecTileRows = MI_DEC_TILE_ROWS;
+int TileRowsOfClass(int cls);
 
 // Persistent grid: at most this many workgroups per CU (256 threads each => 8 x 4 waves = 32 waves/CU = full).
 constexpr int kBlocksPerCU = 8;

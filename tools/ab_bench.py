@@ -27,7 +27,7 @@ def main():
     hs = HbmStream(da.Context(0), buf)
     stream = torch.cuda.current_stream().cuda_stream
     cs = hs.plan.class_stats()
-    defaults = dict(copy=1, dec128=1, string=1, grid=0, tile_table=1)
+    defaults = dict(copy=2, dec128=2, string=2, grid=0, tile_table=1)
 
     def apply(cfg):
         knobs = dict(defaults)
