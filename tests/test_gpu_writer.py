@@ -281,7 +281,11 @@ def test_every_writable_type_roundtrips_through_pyarrow(con, tmp_path):
         got = pt[name].to_pylist()
         if dt.startswith("DECIMAL"):
             scale = int(dt[dt.index(",") + 1: -1])
-            got = [None if v is None else int(v.scaleb(scale)) for v in got]
+            def unscaled(v):  # exact: Decimal.scaleb would round to the context's 28 digits
+                sign, digits, exp = v.as_tuple()
+                m = int("".join(map(str, digits))) * 10 ** (exp + scale)
+                return -m if sign else m
+            got = [None if v is None else unscaled(v) for v in got]
         elif dt == "DATE":
             got = pt[name].cast(pa.int32()).to_pylist()
         elif dt == "TIMESTAMP":
