@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""BASELINE config 4 at kernel level: DuckDB vectors resident in HBM (the output of the decode) -> Arrow buffers with the
+K7 encode kernels, one plan for the whole table.  Prints per-kernel-class HIP-event times and algorithmic GB/s.
+usage: python tools/encode_bench.py [--sf 1] [--rounds 5]"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sf", type=float, default=1.0)
+    ap.add_argument("--rounds", type=int, default=5)
+    args = ap.parse_args()
+    import torch
+    import duckdb_arrow_amd as da
+    from duckdb_arrow_amd import _ffi
+    from duckdb_arrow_amd.hbm import HbmStream
+    torch.cuda.set_device(0)
+    buf, info = da.synth_lineitem_stream(scale_factor=args.sf, seed=42)
+    ctx = da.Context(0)
+    hs = HbmStream(ctx, buf)
+    hs.launch()
+    assert hs.status() == 0
+    torch.cuda.synchronize()
+    in_base, out_base = hs.d_in.data_ptr(), hs.d_out.data_ptr()
+    enc_kind = {_ffi.K_COPY: _ffi.K_ENC_COPY, _ffi.K_DEC128: _ffi.K_ENC_DEC128, _ffi.K_STR32: _ffi.K_ENC_STR32}
+    total = 0
+    spans = []
+    for lay in hs.layout:
+        n = lay["nrows"]
+        for e in lay["columns"]:
+            nb = 3 if e["kind"] == _ffi.K_STR32 else 2
+            sz = [(n + 7) // 8, e["buffers"][1][1], e["buffers"][2][1] if nb == 3 else 0]
+            offs = []
+            for s in sz:
+                offs.append(total)
+                total += (s + 63) // 64 * 64 + 64
+            spans.append((lay, e, offs, sz))
+    arena = torch.zeros(total + 256, dtype=torch.uint8, device="cuda")
+    ab = arena.data_ptr()
+    tasks = []
+    for lay, e, offs, sz in spans:
+        n = lay["nrows"]
+        is_str = e["kind"] == _ffi.K_STR32
+        tasks.append(da.make_task(enc_kind[e["kind"]], n, out_base + e["data_off"], ab + offs[1], validity=out_base + e["valid_off"],
+                                  out_validity=ab + offs[0], out_aux=(ab + offs[2]) if is_str else 0, buf2=in_base, ptr_base=0,
+                                  buf2_len=sz[2] if is_str else 0, param=0 if is_str else e["param"]))
+    plan = da.Plan(ctx, tasks)
+    stream = torch.cuda.current_stream().cuda_stream
+    plan.launch(stream)
+    assert plan.status() == 0
+    times = np.array([plan.launch_timed(stream) for _ in range(args.rounds)])
+    med = np.median(times, axis=0)
+    cs = plan.class_stats()
+    out = {"rows": info["n_rows"], "ms_total": float(np.median(times.sum(axis=1))), "kernels": []}
+    for i, c in enumerate(cs):
+        if c["tiles"]:
+            b = c["bytes_read"] + c["bytes_written"]
+            out["kernels"].append({"kernel": c["kernel"], "ms": float(med[i]), "algorithmic_bytes": b, "GBps": b / (med[i] * 1e-3) / 1e9})
+    out["rows_per_s"] = info["n_rows"] / (out["ms_total"] * 1e-3)
+    # spot check: first batch, every buffer equals the source stream's buffer
+    lay, e, offs, sz = spans[15]
+    got = arena[offs[2]: offs[2] + sz[2]].cpu().numpy()
+    body = lay["body_off"]
+    want = buf[body + e["buffers"][2][0]: body + e["buffers"][2][0] + sz[2]]
+    out["payload_matches_source"] = bool(np.array_equal(got, want))
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive numbers of the operator path (never bench.py's `value`): read_arrow over a lineitem.arrows FILE with a
+host consumer (pinned staging -> H2D -> kernels -> D2H -> 2048-row chunks), with a device-resident consumer (no D2H),
+and COPY ... TO 'out.arrows' of the scanned table.  usage: python tools/scan_bench.py [--sf 1] [--dir /dev/shm]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sf", type=float, default=1.0)
+    ap.add_argument("--dir", default="/dev/shm")
+    ap.add_argument("--repeat", type=int, default=3)
+    args = ap.parse_args()
+    import duckdb_arrow_amd as da
+    buf, info = da.synth_lineitem_stream(scale_factor=args.sf, seed=42)
+    path = os.path.join(args.dir, "mi_lineitem_sf%g.arrows" % args.sf)
+    buf.tofile(path)
+    con = da.Connection(0)
+    out = {"rows": info["n_rows"], "file_bytes": int(buf.size), "sf": args.sf}
+    try:
+        for mode, opts in (("host_consumer", {}), ("device_resident", {"device_resident": True})):
+            best = None
+            for _ in range(args.repeat):
+                t0 = time.perf_counter()
+                rel = con.read_arrow(path, **opts)
+                n = 0
+                for ch in rel.chunks():
+                    n += ch.size
+                dt = time.perf_counter() - t0
+                rel.close()
+                assert n == info["n_rows"]
+                best = dt if best is None else min(best, dt)
+            out[mode] = {"seconds": best, "rows_per_s": info["n_rows"] / best, "file_GBps": buf.size / best / 1e9}
+        # filter pushdown: only the selection vector matters to the consumer
+        t0 = time.perf_counter()
+        rel = con.read_arrow(path).project(["l_shipdate", "l_extendedprice", "l_discount", "l_quantity"]).filter_range("l_shipdate", 8766, 9131)
+        sel = sum(ch.sel_count for ch in rel.chunks())
+        out["q6_columns_filter_pushdown"] = {"seconds": time.perf_counter() - t0, "selected": sel,
+                                             "selectivity": sel / info["n_rows"]}
+    finally:
+        os.unlink(path)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
