@@ -320,6 +320,7 @@ class Relation:
         _ffi.check(_ffi.lib().mi_scan_bind(self._h, fields, n.value, C.byref(n)))
         self.fields = [_field_dict(f) for f in fields[: n.value]]
         self._out_fields = self.fields
+        self._projection = None
         self._initialised = False
 
     @property
@@ -331,12 +332,13 @@ class Relation:
         return [f["duck_type"] for f in self._out_fields]
 
     def project(self, names):
-        """projection_pushdown = true (read_arrow.cpp:46)."""
-        arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
-        _ffi.check(_ffi.lib().mi_scan_init(self._h, arr, len(names)))
+        """projection_pushdown = true (read_arrow.cpp:46).  Applied lazily at the first pull, like init_global."""
         by_name = {f["name"]: f for f in self.fields}
+        missing = [n for n in names if n not in by_name]
+        if missing:
+            raise MiError(_ffi.MI_EINVAL, "Field '%s' does not exist in IPC file schema" % missing[0])
+        self._projection = list(names)
         self._out_fields = [by_name[n] for n in names]
-        self._initialised = True
         return self
 
     def filter_range(self, column, lo, hi):
@@ -345,7 +347,11 @@ class Relation:
 
     def chunks(self):
         if not self._initialised:
-            _ffi.check(_ffi.lib().mi_scan_init(self._h, None, 0))
+            if self._projection:
+                arr = (C.c_char_p * len(self._projection))(*[n.encode() for n in self._projection])
+                _ffi.check(_ffi.lib().mi_scan_init(self._h, arr, len(self._projection)))
+            else:
+                _ffi.check(_ffi.lib().mi_scan_init(self._h, None, 0))
             self._initialised = True
         ch = _ffi.DataChunk()
         while True:

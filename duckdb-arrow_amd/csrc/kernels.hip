@@ -752,14 +752,19 @@ __global__ __launch_bounds__(kBlockThreads) void encode_string_scan(const mi_col
   }
 }
 
-// K7d pass 3: offsets + payload.  Lane i owns rows [8i, 8i+8) of the tile so one block scan orders the whole tile;
-// off[r+1] = tile base + inclusive length sum, NULL rows repeat the previous offset, payload bytes are gathered from
-// the inline field or from the heap behind the string_t pointer.
+// K7d pass 3: offsets + payload.  The tile is processed as 8 sub-blocks of 256 rows (lane r = row, so the 16-byte
+// string_t loads and the 4-byte offset stores are coalesced); per sub-block a wave scan + 4-wave LDS combine gives every
+// row its output position, the payload bytes of the sub-block are assembled in LDS (inline bytes come from the string_t
+// registers, long strings from the heap behind the pointer) and leave as coalesced 16-byte stores.  A sub-block whose
+// payload exceeds the LDS stage falls back to direct byte stores.
+constexpr int kEncStage = 16 * 1024;  // bytes of payload staged per 256-row sub-block (16 KB x 8 workgroups per CU)
+
 __global__ __launch_bounds__(kBlockThreads) void encode_string(const mi_col_task* __restrict__ tasks,
                                                                const uint32_t* __restrict__ tile_begin, int n_tasks,
                                                                uint32_t total_tiles, const int64_t* __restrict__ tile_sums,
                                                                int64_t* __restrict__ null_counts) {
   __shared__ int64_t lds4[kBlockThreads / 64];
+  __shared__ __attribute__((aligned(16))) uint8_t stage[kEncStage + 16];
   const uint32_t* tile_task = nullptr;
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     MI_TILE_PROLOGUE();
@@ -770,37 +775,70 @@ __global__ __launch_bounds__(kBlockThreads) void encode_string(const mi_col_task
     gptr<const uint8_t> heap = GC<uint8_t>(t.buf2);
     gptr<int32_t> off = GM<int32_t>(t.out_data);
     gptr<uint8_t> data = GM<uint8_t>(t.out_aux);
-    const int r0 = 8 * threadIdx.x;
-    int64_t local = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const int r = r0 + k;
-      if (r < n && enc_row_valid(valid, has, row0 + r)) local += ((gptr<const uint32_t>)(str + r))[0];
-    }
-    int64_t total;
-    int64_t pos = tile_sums[tile] + block_exclusive_scan(local, &total, lds4);
+    int64_t base = tile_sums[tile];
     if (row0 == 0 && threadIdx.x == 0) off[0] = 0;
-#pragma clang loop unroll(disable)
-    for (int k = 0; k < 8; k++) {
-      const int r = r0 + k;
-      if (r >= n) break;
-      if (enc_row_valid(valid, has, row0 + r)) {
-        const u32x4 s = str[r];
-        const uint32_t l = s.x;
-        gptr<uint8_t> dst = data + pos;
-        if (l <= 12) {
-          const uint32_t w[3] = {s.y, s.z, s.w};
-#pragma clang loop unroll(disable) vectorize(disable)
-          for (uint32_t j = 0; j < l; j++) dst[j] = static_cast<uint8_t>(w[j >> 2] >> (8 * (j & 3)));
+    for (int k = 0; k < kTileRows / kBlockThreads; k++) {
+      const int r = threadIdx.x + k * kBlockThreads;
+      if (k * kBlockThreads >= n) break;  // uniform
+      u32x4 s = {0u, 0u, 0u, 0u};
+      uint32_t len = 0;
+      if (r < n) {
+        s = str[r];
+        len = enc_row_valid(valid, has, row0 + r) ? s.x : 0u;
+      }
+      int64_t total;
+      const int64_t ex = block_exclusive_scan(static_cast<int64_t>(len), &total, lds4);
+      const int64_t pos = base + ex;
+      if (r < n) off[row0 + r + 1] = static_cast<int32_t>(pos + len);
+      // LDS image: byte i of the sub-block's payload lives at stage[shift + i], shift = base mod 16, so that 16-byte
+      // aligned global addresses are 16-byte aligned LDS addresses
+      const int shift = static_cast<int>(base & 15);
+      const bool staged = total + shift <= kEncStage;
+      uint8_t* dst_l = stage + shift + static_cast<int>(ex);
+      gptr<uint8_t> dst_g = data + pos;
+      if (len != 0) {
+        if (s.x <= 12) {
+          const uint32_t w0 = s.y, w1 = s.z, w2 = s.w;
+          for (uint32_t j = 0; j < len; j++) {
+            const uint32_t w = j < 4 ? w0 : (j < 8 ? w1 : w2);
+            const uint8_t byte = static_cast<uint8_t>(w >> (8 * (j & 3)));
+            if (staged) dst_l[j] = byte; else dst_g[j] = byte;
+          }
         } else {
           const uint64_t p = static_cast<uint64_t>(s.z) | (static_cast<uint64_t>(s.w) << 32);
           gptr<const uint8_t> src = heap + (p - t.ptr_base);
-#pragma clang loop unroll(disable) vectorize(disable)
-          for (uint32_t j = 0; j < l; j++) dst[j] = src[j];
+          const uint32_t mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(src) & 3);
+          gptr<const uint32_t> q = (gptr<const uint32_t>)(src - mis);
+          const uint32_t ndw = (mis + len + 3) >> 2;
+          uint32_t j = 0;
+          for (uint32_t d = 0; d < ndw; d++) {
+            const uint32_t w = q[d];
+            const uint32_t first = d == 0 ? mis : 0;
+            for (uint32_t bidx = first; bidx < 4 && j < len; bidx++, j++) {
+              const uint8_t byte = static_cast<uint8_t>(w >> (8 * bidx));
+              if (staged) dst_l[j] = byte; else dst_g[j] = byte;
+            }
+          }
         }
-        pos += l;
       }
-      off[row0 + r + 1] = static_cast<int32_t>(pos);
+      if (staged) {
+        __syncthreads();
+        // stage[shift .. shift+total) -> data[base .. base+total): unaligned head and tail bytewise, the middle as 16-byte rows
+        const int64_t g0 = base, g1 = base + total;
+        const int64_t a0 = (g0 + 15) & ~static_cast<int64_t>(15), a1 = g1 & ~static_cast<int64_t>(15);
+        if (a0 >= a1) {
+          for (int64_t i = g0 + threadIdx.x; i < g1; i += kBlockThreads) data[i] = stage[shift + (i - g0)];
+        } else {
+          for (int64_t i = g0 + threadIdx.x; i < a0; i += kBlockThreads) data[i] = stage[shift + (i - g0)];
+          for (int64_t i = a1 + threadIdx.x; i < g1; i += kBlockThreads) data[i] = stage[shift + (i - g0)];
+          const int nvec = static_cast<int>((a1 - a0) >> 4);
+          const u32x4* ls = reinterpret_cast<const u32x4*>(stage + shift + (a0 - g0));
+          gptr<u32x4> gd = (gptr<u32x4>)(data + a0);
+          for (int i = threadIdx.x; i < nvec; i += kBlockThreads) __builtin_nontemporal_store(ls[i], gd + i);
+        }
+        __syncthreads();
+      }
+      base += total;
     }
   }
 }
