@@ -1,6 +1,7 @@
 // ipc_stream_reader.cpp -- see ipc_stream_reader.hpp.
 #include "ipc_stream_reader.hpp"
 
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -42,6 +43,20 @@ void DeduplicateColumns(std::vector<std::string>& names) {
     seen[Lower(candidate)] = 1;
   }
 }
+
+// ------------------------------------------------------------------------------------------------ helpers
+namespace {
+struct SerializationException : std::runtime_error {
+  SerializationException() : std::runtime_error("not enough data in file to deserialize result") {}
+};
+
+std::shared_ptr<void> DefaultBodyAlloc(size_t bytes, MessageType, uint8_t** ptr) {
+  void* p = nullptr;
+  if (posix_memalign(&p, 256, bytes ? bytes : 8) != 0) throw std::bad_alloc();
+  *ptr = static_cast<uint8_t*>(p);
+  return std::shared_ptr<void>(p, [](void* q) { std::free(q); });
+}
+}  // namespace
 
 // ------------------------------------------------------------------------------------------------ base reader
 const ArrowSchemaModel& IPCStreamReader::GetBaseSchema() {
@@ -170,8 +185,99 @@ bool IPCStreamReader::GetNextBatch(DecodedBatch* out, bool accept_dictionaries, 
     out->body_file_offset = cur_body_offset;
     return true;
   }
+  if (meta.compression != -1 && cur_size > 0) DecompressBody(&meta);
   SliceBatch(meta, out);
   return true;
+}
+
+// ------------------------------------------------------------------------------------------------ compression
+// Body compression (Message.fbs BodyCompression, method BUFFER): every buffer is `int64 uncompressed_length` (-1 = the
+// bytes that follow are stored raw) + one frame.  The reference decompresses ZSTD on the CPU with DuckDB's bundled zstd
+// (DuckDBDecompressZstd, base_stream_reader.cpp:11-32) and registers no LZ4 function (:37-50); here the system's
+// libzstd.so.1 is bound at run time (no headers in the image), LZ4_FRAME stays unsupported like in the reference.
+namespace {
+struct ZstdApi {
+  size_t (*decompress)(void*, size_t, const void*, size_t) = nullptr;
+  unsigned (*is_error)(size_t) = nullptr;
+  const char* (*error_name)(size_t) = nullptr;
+  bool ok = false;
+};
+const ZstdApi& Zstd() {
+  static ZstdApi api = [] {
+    ZstdApi a;
+    void* h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("libzstd.so", RTLD_NOW | RTLD_LOCAL);
+    if (h) {
+      a.decompress = reinterpret_cast<size_t (*)(void*, size_t, const void*, size_t)>(dlsym(h, "ZSTD_decompress"));
+      a.is_error = reinterpret_cast<unsigned (*)(size_t)>(dlsym(h, "ZSTD_isError"));
+      a.error_name = reinterpret_cast<const char* (*)(size_t)>(dlsym(h, "ZSTD_getErrorName"));
+      a.ok = a.decompress && a.is_error && a.error_name;
+    }
+    return a;
+  }();
+  return api;
+}
+}  // namespace
+
+void IPCStreamReader::DecompressBody(RecordBatchMeta* meta) {
+  if (meta->compression == 0) {
+    throw NotImplementedException("LZ4_FRAME compressed IPC bodies are not supported (the reference registers a ZSTD decompressor only)");
+  }
+  if (meta->compression != 1) throw IOException("Unknown BodyCompression codec " + std::to_string(meta->compression));
+  const ZstdApi& z = Zstd();
+  if (!z.ok) throw NotImplementedException("ZSTD compressed IPC body but libzstd.so.1 is not available on this host");
+  // pass 1: uncompressed sizes -> layout of the new body (every buffer 64-byte aligned)
+  std::vector<int64_t> ulen(meta->buffers.size(), 0);
+  int64_t total = 0;
+  for (size_t i = 0; i < meta->buffers.size(); i++) {
+    const mi_buffer_span& b = meta->buffers[i];
+    if (b.length == 0) continue;
+    if (b.offset < 0 || b.length < 8 || b.offset + b.length > cur_size)
+      throw InternalException("Compressed buffer " + std::to_string(i) + " lies outside the message body");
+    int64_t n;
+    std::memcpy(&n, cur_ptr + b.offset, 8);
+    if (n == -1) n = b.length - 8;
+    if (n < 0) throw IOException("Compressed buffer " + std::to_string(i) + " declares a negative uncompressed length");
+    ulen[i] = n;
+    total += (n + 63) & ~static_cast<int64_t>(63);
+  }
+  uint8_t* out = nullptr;
+  std::shared_ptr<void> owner = body_allocator ? body_allocator(static_cast<size_t>(total + 64), message.type, &out)
+                                               : DefaultBodyAlloc(static_cast<size_t>(total + 64), message.type, &out);
+  int64_t pos = 0;
+  for (size_t i = 0; i < meta->buffers.size(); i++) {
+    mi_buffer_span& b = meta->buffers[i];
+    if (b.length == 0) {
+      b.offset = pos;
+      continue;
+    }
+    const uint8_t* src = cur_ptr + b.offset;
+    int64_t declared;
+    std::memcpy(&declared, src, 8);
+    const int64_t n = ulen[i];
+    if (declared == -1) {
+      std::memcpy(out + pos, src + 8, static_cast<size_t>(n));
+    } else {
+      const size_t code = z.decompress(out + pos, static_cast<size_t>(n), src + 8, static_cast<size_t>(b.length - 8));
+      if (z.is_error(code)) {
+        throw IOException("ZSTD_decompress([buffer with " + std::to_string(b.length - 8) + " bytes] -> [buffer with " +
+                          std::to_string(n) + " bytes]) failed with error '" + z.error_name(code) + "'");
+      }
+      if (static_cast<int64_t>(code) != n) {
+        throw IOException("Expected decompressed size of " + std::to_string(n) + " bytes but got " + std::to_string(code) + " bytes");
+      }
+    }
+    const int64_t padded = (n + 63) & ~static_cast<int64_t>(63);
+    std::memset(out + pos + n, 0, static_cast<size_t>(padded - n));
+    b.offset = pos;
+    b.length = n;
+    pos += padded;
+  }
+  compressed_owner = cur_owner;  // released with the next message
+  cur_owner = owner;
+  cur_ptr = out;
+  cur_size = total;
+  meta->compression = -1;
 }
 
 static std::string BufferSizeError(const std::string& column, int buffer, int64_t need, int64_t have) {
@@ -193,11 +299,7 @@ void IPCStreamReader::SliceBatch(const RecordBatchMeta& meta, DecodedBatch* out)
   out->null_count.clear();
   out->column_length.clear();
   out->buffers.clear();
-  if (meta.compression != -1) {
-    // The reference decompresses zstd buffers on the CPU (base_stream_reader.cpp:11-50); SURVEY 8f ranks that "next".
-    throw NotImplementedException("Compressed IPC bodies (BodyCompression codec " + std::to_string(meta.compression) +
-                                  ") are not supported by the MI355X scan path yet");
-  }
+  if (meta.compression != -1 && cur_size > 0) throw InternalException("compressed body reached SliceBatch");
 
   auto check_span = [&](const mi_buffer_span& s) {
     if (s.offset < 0 || s.length < 0 || s.offset + s.length > cur_size) {
@@ -292,18 +394,6 @@ void IPCStreamReader::SliceBatch(const RecordBatchMeta& meta, DecodedBatch* out)
 }
 
 // ------------------------------------------------------------------------------------------------ file reader
-namespace {
-struct SerializationException : std::runtime_error {
-  SerializationException() : std::runtime_error("not enough data in file to deserialize result") {}
-};
-
-std::shared_ptr<void> DefaultBodyAlloc(size_t bytes, MessageType, uint8_t** ptr) {
-  void* p = nullptr;
-  if (posix_memalign(&p, 256, bytes ? bytes : 8) != 0) throw std::bad_alloc();
-  *ptr = static_cast<uint8_t*>(p);
-  return std::shared_ptr<void>(p, [](void* q) { std::free(q); });
-}
-}  // namespace
 
 IPCFileStreamReader::IPCFileStreamReader(const std::string& path_p) : path(path_p) {
   fd = ::open(path.c_str(), O_RDONLY);
@@ -404,8 +494,11 @@ void IPCFileStreamReader::DecodeBody() {
       return;
     }
     uint8_t* p = nullptr;
-    cur_owner = body_allocator ? body_allocator(static_cast<size_t>(message.body_length), message.type, &p)
-                               : DefaultBodyAlloc(static_cast<size_t>(message.body_length), message.type, &p);
+    bool compressed = false;
+    if (message.type == MessageType::RECORD_BATCH || message.type == MessageType::DICTIONARY_BATCH)
+      compressed = DecodeRecordBatch(message_meta, message_meta_len).compression != -1;
+    cur_owner = (body_allocator && !compressed) ? body_allocator(static_cast<size_t>(message.body_length), message.type, &p)
+                                                : DefaultBodyAlloc(static_cast<size_t>(message.body_length), message.type, &p);
     ReadData(p, static_cast<idx_t>(message.body_length));
     cur_ptr = p;
     cur_size = message.body_length;

@@ -105,6 +105,10 @@ class IPCStreamReader {
   //! Slices cur_ptr/cur_size into per-column buffers, with the size checks of NANOARROW_VALIDATION_LEVEL_FULL that do
   //! not need the data (offset monotonicity is checked on the device by the string kernel)
   void SliceBatch(const RecordBatchMeta& meta, DecodedBatch* out);
+  //! Replaces cur_ptr/cur_size with the decompressed body and rewrites meta->buffers (ZSTD, per buffer; the CPU step the
+  //! reference performs in DuckDBDecompressZstd, base_stream_reader.cpp:11-32)
+  void DecompressBody(RecordBatchMeta* meta);
+  std::shared_ptr<void> compressed_owner;
 
   MessageHeader message;               // the decoder's message_type / body_size_bytes
   const uint8_t* message_meta = nullptr;  // flatbuffer of the current message

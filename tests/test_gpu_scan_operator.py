@@ -245,6 +245,18 @@ def test_device_resident_chunks(con, golden_dir):
     assert got == host
 
 
+def test_zstd_compressed_file(con, golden_dir, tmp_path):
+    """arrow_testing.test:60-64 reads zstd IPC files: CPU decompression (like the reference), then the GPU path."""
+    t = ipc.open_stream(g(golden_dir, "ref_data/test.arrows")).read_all()
+    p = str(tmp_path / "zstd.arrows")
+    with ipc.new_stream(p, t.schema, options=ipc.IpcWriteOptions(compression="zstd")) as w:
+        w.write_table(t, max_chunksize=4000)
+    assert os.path.getsize(p) < os.path.getsize(g(golden_dir, "ref_data/test.arrows"))
+    a = con.read_arrow(p).fetch_columns()
+    b = con.read_arrow(g(golden_dir, "ref_data/test.arrows")).fetch_columns()
+    assert a == b
+
+
 def test_progress_reaches_100(con, golden_dir):
     rel = con.read_arrow(g(golden_dir, "ref_data/test.arrows"))
     assert rel.progress() < 100

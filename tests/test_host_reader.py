@@ -185,15 +185,54 @@ def test_size_validation_rejects_short_buffers(golden_dir):
             pass
 
 
-def test_compressed_and_big_endian_are_reported_not_misread():
-    t = pa.table({"a": list(range(1000))})
+def _stream(table, **opts):
     sink = pa.BufferOutputStream()
-    with ipc.new_stream(sink, t.schema, options=ipc.IpcWriteOptions(compression="zstd")) as w:
-        w.write_table(t)
-    rd = da.Reader(buffers=[sink.getvalue().to_pybytes()])
-    with pytest.raises(da.MiError) as e:
+    with ipc.new_stream(sink, table.schema, options=ipc.IpcWriteOptions(**opts)) as w:
+        for b in table.to_batches(max_chunksize=3000):
+            w.write_batch(b)
+    return sink.getvalue().to_pybytes()
+
+
+def test_zstd_bodies_are_decompressed_like_the_reference():
+    """base_stream_reader.cpp:11-50: per-buffer ZSTD (int64 uncompressed length, -1 = stored raw); the decompressed
+    buffers equal the buffers of the same table written uncompressed."""
+    rng = np.random.default_rng(2)
+    t = pa.table({"a": rng.integers(0, 50, 7000), "s": ["row %d" % (i % 97) for i in range(7000)],
+                  "n": pa.array([None if i % 5 == 0 else float(i) for i in range(7000)]),
+                  "tiny": pa.array([1] * 7000, pa.int8())})
+    plain, packed = _stream(t), _stream(t, compression="zstd")
+    assert len(packed) < len(plain)
+    ra, rb = da.Reader(buffers=[plain]), da.Reader(buffers=[packed])
+    assert ra.schema() == rb.schema()
+    while True:
+        x, y = ra.next_batch(), rb.next_batch()
+        assert (x is None) == (y is None)
+        if x is None:
+            break
+        assert x["length"] == y["length"] and y["compression"] == -1
+        for (xo, xl), (yo, yl) in zip(x["buffers"], y["buffers"]):
+            assert xl == yl and (x["body"][xo: xo + xl] == y["body"][yo: yo + yl]).all() and yo % 64 == 0
+
+
+def test_lz4_is_rejected_like_the_reference():
+    """No LZ4 function is registered (base_stream_reader.cpp:37-50)."""
+    t = pa.table({"a": list(range(1000))})
+    rd = da.Reader(buffers=[_stream(t, compression="lz4")])
+    with pytest.raises(da.MiError, match="LZ4_FRAME") as e:
         rd.next_batch()
-    assert e.value.code == _ffi.MI_ENOTSUP and "Compressed" in str(e.value)
+    assert e.value.code == _ffi.MI_ENOTSUP
+
+
+def test_corrupt_zstd_frame_is_an_io_error():
+    t = pa.table({"a": list(range(5000))})
+    buf = bytearray(_stream(t, compression="zstd"))
+    msgs = po.walk_stream(np.frombuffer(bytes(buf), np.uint8))
+    m = msgs[1]
+    buf[m["body_off"] + 12: m["body_off"] + 20] = b"\xff" * 8
+    rd = da.Reader(buffers=[bytes(buf)])
+    with pytest.raises(da.MiError, match="ZSTD_decompress") as e:
+        rd.next_batch()
+    assert e.value.code == _ffi.MI_EIO
 
 
 def test_synthetic_lineitem_stream_is_valid_arrow():
