@@ -270,9 +270,11 @@ def _flat_values(duck_type, width, data_ptr, validity_ptr, n):
     if duck_type in ("FLOAT", "DOUBLE"):
         vals = raw.view(np.float32 if width == 4 else np.float64)
         return [float(vals[i]) if ok[i] else None for i in range(n)]
+    if duck_type == '"NULL"':
+        return [None] * n
     if duck_type == "INTERVAL":
-        v = raw.view(np.int64)
-        return [int(v[2 * i + 1]) if ok[i] else None for i in range(n)]
+        md, us = raw.view(np.int32), raw.view(np.int64)
+        return [(int(md[4 * i]), int(md[4 * i + 1]), int(us[2 * i + 1])) if ok[i] else None for i in range(n)]
     if duck_type.startswith("DECIMAL") and width == 16:
         lo, hi = raw.view(np.uint64)[0::2], raw.view(np.int64)[1::2]
         return [(int(hi[i]) << 64) + int(lo[i]) if ok[i] else None for i in range(n)]

@@ -45,6 +45,10 @@ int OutWidth(int32_t kind, int64_t param) {
     case MI_K_DATE64: return 4;
     case MI_K_MUL_I32: case MI_K_MUL_I64: case MI_K_DIV_I64: return 8;
     case MI_K_STR32: case MI_K_STR64: case MI_K_FIXED_BINARY: case MI_K_DURATION: return 16;
+    case MI_K_INTERVAL_MONTHS: case MI_K_INTERVAL_MDN: return 16;
+    case MI_K_NARROW: return static_cast<int>((param >> 8) & 0xFF);
+    case MI_K_HALF_FLOAT: return 4;
+    case MI_K_NULL: return 1;
     case MI_K_DICT: return 4;
     default: return 0;
   }
@@ -62,8 +66,13 @@ static void ValidateTask(const mi_col_task& t, size_t i) {
   if (reinterpret_cast<uintptr_t>(t.out_data) % 16 != 0) fail("out_data must be 16-byte aligned");
   if (t.out_validity && reinterpret_cast<uintptr_t>(t.out_validity) % 8 != 0) fail("out_validity must be 8-byte aligned");
   if (t.validity && reinterpret_cast<uintptr_t>(t.validity) % 8 != 0) fail("validity bitmap must be 8-byte aligned");
-  if (t.buf1 == nullptr) fail("buf1 is NULL");
+  if (t.buf1 == nullptr && t.kind != MI_K_NULL) fail("buf1 is NULL");
   switch (t.kind) {
+    case MI_K_NARROW: {
+      const int sw = static_cast<int>(t.param & 0xFF), dw = static_cast<int>((t.param >> 8) & 0xFF);
+      if (!((sw == 4 && dw == 2) || (sw == 8 && (dw == 2 || dw == 4)))) fail("NARROW needs src 4->2 or 8->2/4");
+      break;
+    }
     case MI_K_COPY:
       if (t.param != 1 && t.param != 2 && t.param != 4 && t.param != 8 && t.param != 16) fail("COPY width must be 1,2,4,8,16");
       break;
@@ -125,6 +134,10 @@ static int64_t TaskBytesRead(const mi_col_task& t) {
       case MI_K_STR32: b += (n ? (n + 1) * 4 : 0) + t.buf2_len; break;
       case MI_K_STR64: b += (n ? (n + 1) * 8 : 0) + t.buf2_len; break;
       case MI_K_DICT: b += n * (t.param & 0xFF); break;
+      case MI_K_INTERVAL_MONTHS: b += n * 4; break;
+      case MI_K_INTERVAL_MDN: b += n * 16; break;
+      case MI_K_NARROW: b += n * (t.param & 0xFF); break;
+      case MI_K_HALF_FLOAT: b += n * 2; break;
       default: break;
     }
   } else {

@@ -114,11 +114,16 @@ bool ArrowField::Plan(int32_t* kind, int64_t* param, int32_t* out_width, int32_t
   auto set = [&](int32_t k, int64_t p, int32_t w) { *kind = k; *param = p; *out_width = w; return true; };
   switch (type) {
     case MI_AT_INT: return set(MI_K_COPY, bit_width / 8, bit_width / 8);
+    case MI_AT_NULL: *n_buffers = 0; return set(MI_K_NULL, 0, 1);
     case MI_AT_FLOAT:
-      if (precision == 0) return false;  // half float needs a widening cast
+      if (precision == 0) return set(MI_K_HALF_FLOAT, 0, 4);
       return set(MI_K_COPY, precision == 1 ? 4 : 8, precision == 1 ? 4 : 8);
     case MI_AT_BOOL: return set(MI_K_BOOL, 0, 1);
     case MI_AT_DECIMAL:
+      if ((bit_width == 32 && precision <= 9) || (bit_width == 64 && precision <= 18)) {
+        const int32_t sw = bit_width / 8, dw = precision <= 4 ? 2 : precision <= 9 ? 4 : 8;
+        return sw == dw ? set(MI_K_COPY, sw, sw) : set(MI_K_NARROW, sw | (dw << 8), dw);
+      }
       if (bit_width != 128 || precision > 38) return false;
       if (precision <= 4) return set(MI_K_DEC128, 2, 2);
       if (precision <= 9) return set(MI_K_DEC128, 4, 4);
@@ -142,6 +147,10 @@ bool ArrowField::Plan(int32_t* kind, int64_t* param, int32_t* out_width, int32_t
       }
     case MI_AT_DURATION:
       return set(MI_K_DURATION, unit == 0 ? 1000000 : unit == 1 ? 1000 : unit == 2 ? 1 : -1000, 16);
+    case MI_AT_INTERVAL:
+      if (unit == 0) return set(MI_K_INTERVAL_MONTHS, 0, 16);
+      if (unit == 2) return set(MI_K_INTERVAL_MDN, 0, 16);
+      return false;  // day_time: upstream's conversion is not restated
     case MI_AT_UTF8: case MI_AT_BINARY: *n_buffers = 3; return set(MI_K_STR32, 0, 16);
     case MI_AT_LARGE_UTF8: case MI_AT_LARGE_BINARY: *n_buffers = 3; return set(MI_K_STR64, 0, 16);
     case MI_AT_FIXED_BINARY: return set(MI_K_FIXED_BINARY, byte_width, 16);

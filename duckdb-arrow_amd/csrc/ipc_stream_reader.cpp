@@ -332,7 +332,7 @@ void IPCStreamReader::SliceBatch(const RecordBatchMeta& meta, DecodedBatch* out)
       // size checks of ArrowArrayViewValidate (FULL), minus the data-dependent offsets walk
       if (spans[0].length != 0 && spans[0].length < (n + 7) / 8)
         throw InternalException(BufferSizeError(f.name, 0, (n + 7) / 8, spans[0].length));
-      if (nulls != 0 && spans[0].length == 0 && n > 0 && nulls > 0)
+      if (kind != MI_K_NULL && spans[0].length == 0 && n > 0 && nulls > 0)
         throw InternalException("Column " + f.name + " has null_count " + std::to_string(nulls) + " but no validity buffer");
       int64_t need1 = 0;
       switch (kind) {
@@ -344,6 +344,10 @@ void IPCStreamReader::SliceBatch(const RecordBatchMeta& meta, DecodedBatch* out)
         case MI_K_STR32: need1 = n > 0 ? (n + 1) * 4 : 0; break;
         case MI_K_STR64: need1 = n > 0 ? (n + 1) * 8 : 0; break;
         case MI_K_DICT: need1 = n * (param & 0xFF); break;
+        case MI_K_INTERVAL_MONTHS: need1 = n * 4; break;
+        case MI_K_INTERVAL_MDN: need1 = n * 16; break;
+        case MI_K_NARROW: need1 = n * (param & 0xFF); break;
+        case MI_K_HALF_FLOAT: need1 = n * 2; break;
         default: break;
       }
       if (spans[1].length < need1) throw InternalException(BufferSizeError(f.name, 1, need1, spans[1].length));

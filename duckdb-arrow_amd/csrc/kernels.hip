@@ -496,6 +496,82 @@ __device__ __forceinline__ void tile_duration(const mi_col_task& t, int64_t row0
   raise(status, err);
 }
 
+__device__ __forceinline__ void tile_interval_months(const mi_col_task& t, int64_t row0, int n) {
+  gptr<const int32_t> src = GC<int32_t>(t.buf1) + t.row_offset + row0;
+  gptr<u32x4> out = GM<u32x4>(t.out_data) + row0;
+#pragma unroll 4
+  for (int r = threadIdx.x; r < n; r += kBlockThreads) out[r] = u32x4{static_cast<uint32_t>(src[r]), 0u, 0u, 0u};
+}
+
+__device__ __forceinline__ void tile_interval_mdn(const mi_col_task& t, int64_t row0, int n) {
+  gptr<const uint8_t> src = GC<uint8_t>(t.buf1) + (t.row_offset + row0) * 16;
+  gptr<u32x4> out = GM<u32x4>(t.out_data) + row0;
+#pragma unroll 4
+  for (int r = threadIdx.x; r < n; r += kBlockThreads) {
+    const u32x4 v = *(gptr<const u32x4_a4>)(src + 16 * static_cast<int64_t>(r));
+    const int64_t nanos = static_cast<int64_t>(static_cast<uint64_t>(v.z) | (static_cast<uint64_t>(v.w) << 32));
+    const uint64_t micros = static_cast<uint64_t>(nanos / 1000);
+    out[r] = u32x4{v.x, v.y, static_cast<uint32_t>(micros), static_cast<uint32_t>(micros >> 32)};
+  }
+}
+
+// decimal32 / decimal64 -> the physical type of the declared precision, valid rows only (NULL -> 0)
+template <typename SRC, typename DST>
+__device__ __forceinline__ void tile_narrow(const mi_col_task& t, int64_t row0, int n, uint32_t* status) {
+  gptr<const SRC> src = GC<SRC>(t.buf1) + t.row_offset + row0;
+  gptr<DST> out = GM<DST>(t.out_data) + row0;
+  gptr<const uint8_t> bitmap = GC<uint8_t>(t.validity);
+  const bool has_nulls = t.validity != nullptr && t.null_count != 0;
+  uint32_t err = 0;
+#pragma unroll 4
+  for (int r = threadIdx.x; r < n; r += kBlockThreads) {
+    DST o = 0;
+    if (row_valid(bitmap, has_nulls, t.row_offset + row0 + r)) {
+      const SRC v = src[r];
+      o = static_cast<DST>(v);
+      if (static_cast<SRC>(o) != v) err = MI_ST_DECIMAL_RANGE;
+    }
+    out[r] = o;
+  }
+  raise(status, err);
+}
+
+// IEEE binary16 -> binary32, exact (subnormals normalised, inf / nan keep their payload)
+__device__ __forceinline__ void tile_half_float(const mi_col_task& t, int64_t row0, int n) {
+  gptr<const uint16_t> src = GC<uint16_t>(t.buf1) + t.row_offset + row0;
+  gptr<uint32_t> out = GM<uint32_t>(t.out_data) + row0;
+#pragma unroll 4
+  for (int r = threadIdx.x; r < n; r += kBlockThreads) {
+    const uint32_t h = src[r];
+    const uint32_t sign = (h & 0x8000u) << 16, exp = (h >> 10) & 0x1F;
+    uint32_t man = h & 0x3FF, f;
+    if (exp == 0) {
+      if (man == 0) {
+        f = sign;
+      } else {
+        const int lz = __builtin_clz(man) - 21;  // shifts needed to bring the leading 1 to bit 10
+        man = (man << lz) & 0x3FF;
+        f = sign | (static_cast<uint32_t>(113 - lz) << 23) | (man << 13);
+      }
+    } else if (exp == 31) {
+      f = sign | 0x7F800000u | (man << 13);
+    } else {
+      f = sign | ((exp + 112) << 23) | (man << 13);
+    }
+    out[r] = f;
+  }
+}
+
+// arrow null type: every row NULL
+__device__ __forceinline__ void tile_null(const mi_col_task& t, int64_t row0, int n) {
+  gptr<uint8_t> out = GM<uint8_t>(t.out_data) + row0;
+  for (int r = threadIdx.x; r < n; r += kBlockThreads) out[r] = 0;
+  if (t.out_validity != nullptr) {
+    const int nwords = (n + 63) >> 6;
+    for (int w = threadIdx.x; w < nwords; w += kBlockThreads) GM<uint64_t>(t.out_validity)[(row0 >> 6) + w] = 0ull;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------- K5
 // Dictionary indices -> sel_t; NULL -> dict_len (the extra NULL slot of the decoded dictionary).
 __device__ __forceinline__ void tile_dict(const mi_col_task& t, int64_t row0, int n, uint32_t* status) {
@@ -537,8 +613,19 @@ __global__ __launch_bounds__(kBlockThreads) void transcode_misc(const mi_col_tas
                                                                 uint32_t total_tiles, uint32_t* __restrict__ status) {
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     MI_TILE_PROLOGUE();
-    tile_validity(t, row0, n);
+    if (t.kind != MI_K_NULL) tile_validity(t, row0, n);
     switch (t.kind) {
+      case MI_K_NULL: tile_null(t, row0, n); break;
+      case MI_K_INTERVAL_MONTHS: tile_interval_months(t, row0, n); break;
+      case MI_K_INTERVAL_MDN: tile_interval_mdn(t, row0, n); break;
+      case MI_K_HALF_FLOAT: tile_half_float(t, row0, n); break;
+      case MI_K_NARROW: {
+        const int sw = static_cast<int>(t.param & 0xFF), dw = static_cast<int>((t.param >> 8) & 0xFF);
+        if (sw == 4) tile_narrow<int32_t, int16_t>(t, row0, n, status);
+        else if (dw == 2) tile_narrow<int64_t, int16_t>(t, row0, n, status);
+        else tile_narrow<int64_t, int32_t>(t, row0, n, status);
+        break;
+      }
       case MI_K_BOOL: tile_bool(t, row0, n); break;
       case MI_K_DATE64: tile_date64(t, row0, n); break;
       case MI_K_MUL_I32: tile_mul_i32(t, row0, n); break;
@@ -863,7 +950,8 @@ int ClassOfKind(int32_t kind) {
     case MI_K_DEC128: return kClassDec128;
     case MI_K_STR32: case MI_K_STR64: case MI_K_FIXED_BINARY: return kClassString;
     case MI_K_BOOL: case MI_K_DATE64: case MI_K_MUL_I32: case MI_K_MUL_I64: case MI_K_DIV_I64: case MI_K_DURATION:
-    case MI_K_DICT: return kClassMisc;
+    case MI_K_DICT: case MI_K_INTERVAL_MONTHS: case MI_K_INTERVAL_MDN: case MI_K_NARROW: case MI_K_HALF_FLOAT:
+    case MI_K_NULL: return kClassMisc;
     case MI_K_ENC_COPY: case MI_K_ENC_DEC128: case MI_K_ENC_BOOL: return kClassEncFixed;
     case MI_K_ENC_STR32: return kClassEncString;
     default: return -1;

@@ -88,6 +88,11 @@ enum mi_kind {
   MI_K_DICT = 10,         /* K5  dictionary indices -> sel_t; param = idx width | signed<<8; param2 = dict_len */
   MI_K_FIXED_BINARY = 11, /* K4c fixed_size_binary -> string_t; param = byte width */
   MI_K_DURATION = 12,     /* K3c duration -> interval_t; param = factor (>0 multiply, <0 divide by -param) */
+  MI_K_INTERVAL_MONTHS = 13, /* K3c interval[months] int32 -> interval_t{months,0,0} */
+  MI_K_INTERVAL_MDN = 14, /* K3c interval[month_day_nano] -> interval_t{months, days, nanos/1000} */
+  MI_K_NARROW = 15,       /* K3b decimal32/64 -> int16/32 (valid rows); param = src width | dst width << 8 */
+  MI_K_HALF_FLOAT = 16,   /* float16 -> float32 (DuckDB FLOAT) */
+  MI_K_NULL = 17,         /* arrow null type: no buffers, all rows NULL (1-byte placeholder data) */
   /* encode direction (K7), used by mi_encode_* plans */
   MI_K_ENC_COPY = 32,     /* K7b fixed-width copy; param = width */
   MI_K_ENC_DEC128 = 33,   /* K7b int16/32/64 -> decimal128 sign extension; param = in width */

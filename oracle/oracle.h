@@ -145,6 +145,10 @@ void orc_div_i64(const int64_t* src, int64_t o, int64_t n, int64_t divisor, int6
 /* duration -> interval_t{int32 months,int32 days,int64 micros}: factor>0 multiply, factor<0 divide by -factor */
 int orc_duration_to_interval(const int64_t* src, const uint64_t* valid, int64_t o, int64_t n,
                              int64_t factor, uint8_t* out16);
+void orc_interval_months(const int32_t* src, int64_t o, int64_t n, uint8_t* out16);
+void orc_interval_mdn(const uint8_t* src16, int64_t o, int64_t n, uint8_t* out16);
+void orc_narrow(const void* src, int32_t src_width, const uint64_t* valid, int64_t o, int64_t n, int32_t dst_width, void* out);
+void orc_half_to_float(const uint16_t* src, int64_t o, int64_t n, uint32_t* out_bits);
 /* K4a/b: utf8/binary with int32 / int64 offsets -> string_t (16 B).  ptr_base is the address the
  * consumer will see for byte 0 of the data buffer (host or device). */
 int orc_string32(const int32_t* off, const uint8_t* data, const uint64_t* valid, int64_t o, int64_t n,
@@ -191,7 +195,12 @@ enum {
   ORC_K_STR64 = 9,
   ORC_K_DICT = 10,     /* param = idx_width | (signed<<8); param2 = dict_len */
   ORC_K_FIXED_BINARY = 11, /* param = width */
-  ORC_K_DURATION = 12  /* param = factor (neg = divide) */
+  ORC_K_DURATION = 12, /* param = factor (neg = divide) */
+  ORC_K_INTERVAL_MONTHS = 13, /* tiM: int32 months -> interval_t{months,0,0}, all rows (IntervalConversionMonths) */
+  ORC_K_INTERVAL_MDN = 14,    /* tin: {i32 months, i32 days, i64 nanos} -> interval_t{months, days, nanos/1000}, all rows */
+  ORC_K_NARROW = 15,          /* decimal32/64 -> int16/32: param = src width | dst width << 8; valid rows, NULL -> 0 */
+  ORC_K_HALF_FLOAT = 16,      /* float16 -> float32, all rows */
+  ORC_K_NULL = 17             /* arrow null type: no buffers, every row NULL */
 };
 
 typedef struct {

@@ -35,13 +35,19 @@ int orc_plan_column(const orc_field* f, int32_t* kind, int64_t* param, int32_t* 
       *kind = ORC_K_COPY;
       *param = f->bit_width / 8;
       return ORC_OK;
+    case ORC_T_NULL: *kind = ORC_K_NULL; *n_buffers = 0; return ORC_OK;
     case ORC_T_FLOAT:
-      if (f->precision == 0) return ORC_ENOTSUP;
+      if (f->precision == 0) { *kind = ORC_K_HALF_FLOAT; return ORC_OK; }
       *kind = ORC_K_COPY;
       *param = f->precision == 1 ? 4 : 8;
       return ORC_OK;
     case ORC_T_BOOL: *kind = ORC_K_BOOL; return ORC_OK;
     case ORC_T_DECIMAL:
+      if ((f->bit_width == 32 && f->precision <= 9) || (f->bit_width == 64 && f->precision <= 18)) {
+        int32_t sw = f->bit_width / 8, dw = f->precision <= 4 ? 2 : f->precision <= 9 ? 4 : 8;
+        if (sw == dw) { *kind = ORC_K_COPY; *param = sw; } else { *kind = ORC_K_NARROW; *param = sw | (dw << 8); }
+        return ORC_OK;
+      }
       if (f->bit_width != 128 || f->precision > 38) return ORC_ENOTSUP;
       if (f->precision <= 4) { *kind = ORC_K_DEC128; *param = 2; }
       else if (f->precision <= 9) { *kind = ORC_K_DEC128; *param = 4; }
@@ -72,6 +78,10 @@ int orc_plan_column(const orc_field* f, int32_t* kind, int64_t* param, int32_t* 
       *kind = ORC_K_DURATION;
       *param = f->unit == 0 ? 1000000 : f->unit == 1 ? 1000 : f->unit == 2 ? 1 : -1000;
       return ORC_OK;
+    case ORC_T_INTERVAL:
+      if (f->unit == 0) { *kind = ORC_K_INTERVAL_MONTHS; return ORC_OK; }
+      if (f->unit == 2) { *kind = ORC_K_INTERVAL_MDN; return ORC_OK; }
+      return ORC_ENOTSUP; /* day_time: upstream's handling is not restated */
     case ORC_T_UTF8: case ORC_T_BINARY: *kind = ORC_K_STR32; *n_buffers = 3; return ORC_OK;
     case ORC_T_LARGE_UTF8: case ORC_T_LARGE_BINARY: *kind = ORC_K_STR64; *n_buffers = 3; return ORC_OK;
     case ORC_T_FIXED_BINARY: *kind = ORC_K_FIXED_BINARY; *param = f->byte_width; return ORC_OK;
@@ -157,8 +167,8 @@ int orc_scan_stream(const uint8_t* buf, int64_t size, int32_t max_batches, int32
         memset(&t, 0, sizeof(t));
         t.kind = kind[c];
         t.param = param[c];
-        t.validity = cb[c][0];
-        t.buf1 = cb[c][1];
+        t.validity = nbuf[c] ? cb[c][0] : NULL;
+        t.buf1 = nbuf[c] ? cb[c][1] : NULL;
         t.buf2 = nbuf[c] > 2 ? cb[c][2] : NULL;
         t.buf2_len = nbuf[c] > 2 ? cl[c][2] : 0;
         t.null_count = nodes[c].null_count;
@@ -179,6 +189,11 @@ int orc_scan_stream(const uint8_t* buf, int64_t size, int32_t max_batches, int32
           case ORC_K_STR32: rc |= orc_string32((const int32_t*)t.buf1, t.buf2, chunk_valid, o, n, t.ptr_base, chunk_data[c]); break;
           case ORC_K_STR64: rc |= orc_string64((const int64_t*)t.buf1, t.buf2, chunk_valid, o, n, t.ptr_base, chunk_data[c]); break;
           case ORC_K_FIXED_BINARY: orc_fixed_binary(t.buf1, (int32_t)t.param, chunk_valid, o, n, t.ptr_base, chunk_data[c]); break;
+          case ORC_K_INTERVAL_MONTHS: orc_interval_months((const int32_t*)t.buf1, o, n, chunk_data[c]); break;
+          case ORC_K_INTERVAL_MDN: orc_interval_mdn(t.buf1, o, n, chunk_data[c]); break;
+          case ORC_K_NARROW: orc_narrow(t.buf1, (int32_t)(t.param & 0xFF), chunk_valid, o, n, w, chunk_data[c]); break;
+          case ORC_K_HALF_FLOAT: orc_half_to_float((const uint16_t*)t.buf1, o, n, (uint32_t*)chunk_data[c]); break;
+          case ORC_K_NULL: memset(chunk_valid, 0, sizeof(chunk_valid)); memset(chunk_data[c], 0, (size_t)n); break;
           default: rc = ORC_ENOTSUP; break;
         }
         st->bytes_out += n * w + ((n + 63) / 64) * 8;

@@ -125,6 +125,57 @@ int orc_duration_to_interval(const int64_t* src, const uint64_t* valid, int64_t 
   return rc;
 }
 
+void orc_interval_months(const int32_t* src, int64_t o, int64_t n, uint8_t* out16) {
+  for (int64_t i = 0; i < n; i++) {
+    memset(out16 + 16 * i, 0, 16);
+    memcpy(out16 + 16 * i, &src[o + i], 4);
+  }
+}
+
+void orc_interval_mdn(const uint8_t* src16, int64_t o, int64_t n, uint8_t* out16) {
+  for (int64_t i = 0; i < n; i++) {
+    int64_t nanos;
+    memcpy(out16 + 16 * i, src16 + 16 * (o + i), 8); /* months, days */
+    memcpy(&nanos, src16 + 16 * (o + i) + 8, 8);
+    int64_t micros = nanos / 1000;
+    memcpy(out16 + 16 * i + 8, &micros, 8);
+  }
+}
+
+/* decimal32 / decimal64 inputs (DuckDB v1.3): TryCast to the physical type of the declared precision on valid rows */
+void orc_narrow(const void* src, int32_t src_width, const uint64_t* valid, int64_t o, int64_t n, int32_t dst_width, void* out) {
+  for (int64_t i = 0; i < n; i++) {
+    int64_t v = 0;
+    if (word_valid(valid, i)) v = src_width == 4 ? ((const int32_t*)src)[o + i] : ((const int64_t*)src)[o + i];
+    switch (dst_width) {
+      case 2: ((int16_t*)out)[i] = (int16_t)v; break;
+      case 4: ((int32_t*)out)[i] = (int32_t)v; break;
+      default: ((int64_t*)out)[i] = v; break;
+    }
+  }
+}
+
+/* IEEE 754 binary16 -> binary32 (exact): subnormals are normalised, inf/nan keep their payload */
+void orc_half_to_float(const uint16_t* src, int64_t o, int64_t n, uint32_t* out_bits) {
+  for (int64_t i = 0; i < n; i++) {
+    uint32_t h = src[o + i];
+    uint32_t sign = (h & 0x8000u) << 16, exp = (h >> 10) & 0x1F, man = h & 0x3FF, f;
+    if (exp == 0) {
+      if (man == 0) f = sign;
+      else {
+        int e = -1;
+        do { e++; man <<= 1; } while ((man & 0x400) == 0);
+        f = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3FF) << 13);
+      }
+    } else if (exp == 31) {
+      f = sign | 0x7F800000u | (man << 13);
+    } else {
+      f = sign | ((exp + 112) << 23) | (man << 13);
+    }
+    out_bits[i] = f;
+  }
+}
+
 /* ------------------------------------------------------------------------------------------------ K4 */
 static inline void make_string_t(uint8_t* dst, const uint8_t* payload, uint32_t len, uint64_t ptr) {
   memcpy(dst, &len, 4);
@@ -287,6 +338,10 @@ int32_t orc_out_width(int32_t kind, int64_t param) {
     case ORC_K_DATE64: return 4;
     case ORC_K_MUL_I32: case ORC_K_MUL_I64: case ORC_K_DIV_I64: return 8;
     case ORC_K_STR32: case ORC_K_STR64: case ORC_K_FIXED_BINARY: case ORC_K_DURATION: return 16;
+    case ORC_K_INTERVAL_MONTHS: case ORC_K_INTERVAL_MDN: return 16;
+    case ORC_K_NARROW: return (int32_t)((param >> 8) & 0xFF);
+    case ORC_K_HALF_FLOAT: return 4;
+    case ORC_K_NULL: return 1;
     case ORC_K_DICT: return 4;
     default: return 0;
   }
@@ -301,6 +356,7 @@ int orc_decode_column(const orc_col_task* t, int32_t copy_direct) {
     int64_t n = t->nrows - o < ORC_VECTOR_SIZE ? t->nrows - o : ORC_VECTOR_SIZE;
     uint64_t* valid = t->out_validity + o / 64;
     orc_validity(t->validity, t->null_count, o, n, valid);
+    if (t->kind == ORC_K_NULL) memset(valid, 0, (size_t)((n + 63) / 64) * 8);
     uint8_t* out = t->out_data + o * (int64_t)w;
     int r = ORC_OK;
     switch (t->kind) {
@@ -317,6 +373,11 @@ int orc_decode_column(const orc_col_task* t, int32_t copy_direct) {
       case ORC_K_STR32: r = orc_string32((const int32_t*)t->buf1, t->buf2, valid, o, n, t->ptr_base, out); break;
       case ORC_K_STR64: r = orc_string64((const int64_t*)t->buf1, t->buf2, valid, o, n, t->ptr_base, out); break;
       case ORC_K_FIXED_BINARY: orc_fixed_binary(t->buf1, (int32_t)t->param, valid, o, n, t->ptr_base, out); break;
+      case ORC_K_INTERVAL_MONTHS: orc_interval_months((const int32_t*)t->buf1, o, n, out); break;
+      case ORC_K_INTERVAL_MDN: orc_interval_mdn(t->buf1, o, n, out); break;
+      case ORC_K_NARROW: orc_narrow(t->buf1, (int32_t)(t->param & 0xFF), valid, o, n, w, out); break;
+      case ORC_K_HALF_FLOAT: orc_half_to_float((const uint16_t*)t->buf1, o, n, (uint32_t*)out); break;
+      case ORC_K_NULL: memset(out, 0, (size_t)n); break;
       case ORC_K_DICT:
         r = orc_dict_sel(t->buf1, (int32_t)(t->param & 0xFF), (int32_t)((t->param >> 8) & 1), valid, o, n,
                          (uint32_t)t->param2, (uint32_t*)out);

@@ -16,7 +16,7 @@ VECTOR_SIZE = 2048
 
 # kinds (oracle.h)
 K_COPY, K_BOOL, K_DEC128, K_DATE64, K_MUL_I32, K_MUL_I64, K_DIV_I64, K_STR32, K_STR64, K_DICT, K_FIXED_BINARY, \
-    K_DURATION = range(1, 13)
+    K_DURATION, K_INTERVAL_MONTHS, K_INTERVAL_MDN, K_NARROW, K_HALF_FLOAT, K_NULL = range(1, 18)
 MSG_SCHEMA, MSG_DICTIONARY_BATCH, MSG_RECORD_BATCH = 1, 2, 3
 
 
@@ -189,6 +189,8 @@ def decode_column(kind, param, nrows, validity, buf1, buf2=None, null_count=-1, 
 
 
 def _slice_column(body, bl, nbuf):
+    if nbuf == 0:
+        return None, np.zeros(16, np.uint8), None
     v = body[bl[0][0]: bl[0][0] + bl[0][1]] if bl[0][1] else None
     b1 = body[bl[1][0]: bl[1][0] + bl[1][1]]
     b2 = body[bl[2][0]: bl[2][0] + bl[2][1]] if nbuf > 2 else None
@@ -241,7 +243,7 @@ def decode_stream(buf, ptr_base_of=None, columns=None):
                 continue
             nrows, null_count = rb["nodes"][ci]
             v, b1, b2 = _slice_column(body, bl, nbuf)
-            boff = bl[2][0] if nbuf > 2 else bl[1][0]
+            boff = bl[2][0] if nbuf > 2 else (bl[1][0] if nbuf else 0)
             base = ptr_base_of(bi, m["body_off"], boff) if ptr_base_of else m["body_off"] + boff
             dictionary = dicts.get(f["dict_id"]) if f["has_dict"] else None
             d, val, rc = decode_column(kind, param, nrows, v, b1, b2, null_count, base,

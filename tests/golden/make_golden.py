@@ -38,7 +38,7 @@ def canon_value(v):
     if v is None or isinstance(v, (bool, int, str)):
         return v
     if isinstance(v, float):
-        return repr(v)
+        return "nan" if v != v else repr(v)
     if isinstance(v, bytes):
         return "b:" + v.hex()
     if isinstance(v, decimal.Decimal):
@@ -77,6 +77,8 @@ def canon_column(col: pa.ChunkedArray):
     if pa.types.is_duration(t):
         f = {"s": 1000000, "ms": 1000, "us": 1, "ns": None}[t.unit]
         return [None if x is None else (x * f if f else tdiv(x, 1000)) for x in col.cast(pa.int64()).to_pylist()]
+    if pa.types.is_interval(t):
+        return [None if x is None else [x.months, x.days, tdiv(x.nanoseconds, 1000)] for x in col.to_pylist()]
     if pa.types.is_decimal(t):
         scale = t.scale
         return [None if x is None else int(x.scaleb(scale)) for x in col.to_pylist()]
@@ -231,6 +233,32 @@ def main():
     write_stream(p, batches[0].schema, batches)
     exp["edge_types.arrows"] = table_expectation(read_any(p))
     exp["edge_types.arrows"]["batch_sizes"] = sizes
+
+    # 3b'. types DuckDB >= 1.3 also reads: decimal32/64 inputs, half floats, month_day_nano intervals, durations, null
+    def types2_batch(n):
+        import datetime
+        cols = {
+            "d32_7": pa.array([decimal.Decimal(int(x)).scaleb(-2) for x in rng.integers(-9999999, 9999999, n)], pa.decimal32(7, 2)),
+            "d32_4": pa.array([decimal.Decimal(int(x)).scaleb(-1) for x in rng.integers(-9999, 9999, n)], pa.decimal32(4, 1)),
+            "d64_12": pa.array([decimal.Decimal(int(x)).scaleb(-2) for x in rng.integers(-10**12 + 1, 10**12 - 1, n)], pa.decimal64(12, 2)),
+            "d64_9": pa.array([decimal.Decimal(int(x)).scaleb(-3) for x in rng.integers(-10**9 + 1, 10**9 - 1, n)], pa.decimal64(9, 3)),
+            "d64_4": pa.array([decimal.Decimal(int(x)).scaleb(-1) for x in rng.integers(-9999, 9999, n)], pa.decimal64(4, 1)),
+            "f16": pa.array(rng.integers(0, 65536, n).astype(np.uint16).view(np.float16)),
+            "mdn": pa.array([pa.MonthDayNano([int(a), int(b), int(c)]) for a, b, c in
+                             zip(rng.integers(-100, 100, n), rng.integers(-1000, 1000, n), rng.integers(-10**15, 10**15, n))],
+                            pa.month_day_nano_interval()),
+            "dur_s": pa.array(rng.integers(-10**9, 10**9, n), pa.duration("s")),
+            "dur_ms": pa.array(rng.integers(-10**12, 10**12, n), pa.duration("ms")),
+            "dur_us": pa.array(rng.integers(-10**15, 10**15, n), pa.duration("us")),
+            "dur_ns": pa.array(rng.integers(-10**18, 10**18, n), pa.duration("ns")),
+        }
+        arrays = [nullify(a) for a in cols.values()] + [pa.nulls(n)]
+        return pa.record_batch(arrays, names=list(cols.keys()) + ["nothing"])
+
+    b2 = [types2_batch(n) for n in (1, 65, 2049, 3000)]
+    p = os.path.join(HERE, "edge_types2.arrows")
+    write_stream(p, b2[0].schema, b2)
+    exp["edge_types2.arrows"] = table_expectation(read_any(p))
 
     # 3c. empty batches, all-null and all-valid columns, zero-length validity
     sch = pa.schema([("a", pa.int32()), ("s", pa.string()), ("n", pa.int64())])

@@ -32,9 +32,11 @@ def canon_flat(field, kind, param, width, data, validity, n, heap, heap_base=0):
         return [("b:" + v.hex()) if (as_bytes and v is not None) else v for v in vals]
     if kind == po.K_BOOL:
         return [bool(data[i]) if ok[i] else None for i in range(n)]
+    if kind == po.K_NULL:
+        return [None] * n
     if t == T_FLOAT:
         vals = data.view(np.float32 if width == 4 else np.float64)
-        return [repr(float(vals[i])) if ok[i] else None for i in range(n)]
+        return [("nan" if vals[i] != vals[i] else repr(float(vals[i]))) if ok[i] else None for i in range(n)]
     if t == T_INT:
         dt = np.dtype("%s%d" % ("i" if field["is_signed"] else "u", width))
         return _fixed(data, ok, dt)
@@ -44,6 +46,9 @@ def canon_flat(field, kind, param, width, data, validity, n, heap, heap_base=0):
         return [(int(hi[i]) << 64) + int(lo[i]) if ok[i] else None for i in range(n)]
     if kind == po.K_DURATION:
         return [int(data.view(np.int64)[2 * i + 1]) if ok[i] else None for i in range(n)]
+    if kind in (po.K_INTERVAL_MONTHS, po.K_INTERVAL_MDN):
+        md, us = data.view(np.int32), data.view(np.int64)
+        return [[int(md[4 * i]), int(md[4 * i + 1]), int(us[2 * i + 1])] if ok[i] else None for i in range(n)]
     dt = {2: np.int16, 4: np.int32, 8: np.int64}[width]
     return _fixed(data, ok, dt)
 

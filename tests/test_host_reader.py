@@ -40,7 +40,7 @@ def test_reader_matches_oracle_and_pyarrow_metadata(golden_dir, rel):
             flat = [s for s in b["buffers"] if True]
             k = 0
             for ci, f in enumerate(fields):
-                nb = 3 if f["kind"] in (_ffi.K_STR32, _ffi.K_STR64) else 2
+                nb = 3 if f["kind"] in (_ffi.K_STR32, _ffi.K_STR64) else (0 if f["kind"] == _ffi.K_NULL else 2)
                 assert [tuple(x) for x in flat[3 * ci: 3 * ci + nb]] == [tuple(x) for x in rb["buffers"][k: k + nb]]
                 assert b["null_count"][ci] == rb["nodes"][ci][1]
                 k += nb
