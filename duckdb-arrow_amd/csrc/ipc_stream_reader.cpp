@@ -628,9 +628,53 @@ void IPCFileStreamReader::Seek(int64_t prefix_offset) {
   finished = false;
 }
 
+bool IPCFileStreamReader::IndexFromFooter() {
+  // Arrow IPC *file*: "ARROW1\0\0" stream footer int32 footer_len "ARROW1".  The footer lists every dictionary and
+  // record-batch block {offset, metaDataLength, bodyLength}: random access for sharding without walking the headers
+  // (the reference notes this as future work: ipc_file_stream_reader.cpp:113-115, arrow_file_scan.cpp:36-40).
+  if (file_size < 8 + 10) return false;
+  uint8_t magic[8];
+  if (::pread(fd, magic, 8, 0) != 8 || std::memcmp(magic, "ARROW1\0\0", 8) != 0) return false;
+  uint8_t tail10[10];
+  if (::pread(fd, tail10, 10, static_cast<off_t>(file_size - 10)) != 10 || std::memcmp(tail10 + 4, "ARROW1", 6) != 0) return false;
+  int32_t flen;
+  std::memcpy(&flen, tail10, 4);
+  if (flen <= 0 || static_cast<int64_t>(flen) + 18 > file_size) return false;
+  std::vector<uint8_t> tail(static_cast<size_t>(flen) + 10);
+  if (::pread(fd, tail.data(), tail.size(), static_cast<off_t>(file_size - static_cast<int64_t>(tail.size()))) != static_cast<ssize_t>(tail.size()))
+    return false;
+  std::vector<FooterBlock> dict_blocks, batch_blocks;
+  if (!DecodeFooter(tail.data(), static_cast<int64_t>(tail.size()), file_size, &dict_blocks, &batch_blocks)) return false;
+  std::vector<uint8_t> meta;
+  auto add = [&](const FooterBlock& b, MessageType type) {
+    // block.metaDataLength covers the 8-byte prefix + the padded flatbuffer
+    if (b.offset < 8 || b.meta_len < 8 || b.offset + b.meta_len + b.body_len > file_size) throw IOException("Footer block out of bounds");
+    BatchIndexEntry e{b.offset, b.meta_len - 8, static_cast<int32_t>(type), b.offset + b.meta_len, b.body_len, 0};
+    meta.resize(static_cast<size_t>(b.meta_len - 8));
+    if (::pread(fd, meta.data(), meta.size(), static_cast<off_t>(b.offset + 8)) != static_cast<ssize_t>(meta.size()))
+      throw IOException("Could not read record batch metadata at offset " + std::to_string(b.offset));
+    e.n_rows = DecodeRecordBatch(meta.data(), static_cast<int64_t>(meta.size())).length;
+    index.push_back(e);
+  };
+  // stream order: dictionaries precede the batches that use them
+  std::vector<std::pair<FooterBlock, MessageType>> all;
+  for (auto& b : dict_blocks) all.emplace_back(b, MessageType::DICTIONARY_BATCH);
+  for (auto& b : batch_blocks) all.emplace_back(b, MessageType::RECORD_BATCH);
+  std::sort(all.begin(), all.end(), [](const auto& x, const auto& y) { return x.first.offset < y.first.offset; });
+  for (auto& b : all)
+    if (b.first.offset >= offset) add(b.first, b.second);
+  return true;
+}
+
 const std::vector<BatchIndexEntry>& IPCFileStreamReader::BuildIndex() {
   if (index_built) return index;
   GetBaseSchema();
+  if (IndexFromFooter()) {
+    index_built = true;
+    index_from_footer = true;
+    return index;
+  }
+  index.clear();
   int64_t saved = offset;
   bool saved_finished = finished;
   // Walk headers only; bodies are skipped (the stream format has no footer index: SURVEY "Hard parts")

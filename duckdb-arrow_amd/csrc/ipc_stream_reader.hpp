@@ -147,14 +147,18 @@ class IPCFileStreamReader : public IPCStreamReader {
   //! Positions the reader on a message found by BuildIndex (record-batch sharding)
   void Seek(int64_t prefix_offset);
   int64_t FileSize() const { return file_size; }
+  //! true when BuildIndex() came from the IPC file footer instead of a header walk
+  bool IndexFromFooterUsed() const { return index_from_footer; }
 
  protected:
   const uint8_t* ReadData(uint8_t* ptr, idx_t size);
   bool DecodeHeader(idx_t message_header_size) override;
   void DecodeBody() override;
   void EnsureInputStreamAligned();
+  bool IndexFromFooter();
 
  private:
+  bool index_from_footer = false;
   int fd = -1;
   std::string path;
   int64_t file_size = 0;

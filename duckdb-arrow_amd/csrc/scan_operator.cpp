@@ -78,13 +78,14 @@ ArrowScan::~ArrowScan() {
     if (s.compute_done) (void)hipEventDestroy(s.compute_done);
     if (s.d2h_done) (void)hipEventDestroy(s.d2h_done);
   }
-  for (auto& kv : dicts) {
-    if (kv.second.d_data) (void)hipFree(kv.second.d_data);
-    if (kv.second.d_validity) (void)hipFree(kv.second.d_validity);
-    if (kv.second.d_heap) (void)hipFree(kv.second.d_heap);
-    if (kv.second.h_data) (void)hipHostFree(kv.second.h_data);
-    if (kv.second.h_validity) (void)hipHostFree(kv.second.h_validity);
-  }
+  dicts.clear();
+}
+
+ArrowScan::DictState::~DictState() {
+  if (d_data) (void)hipFree(d_data);
+  if (d_validity) (void)hipFree(d_validity);
+  if (h_data) (void)hipHostFree(h_data);
+  if (h_validity) (void)hipHostFree(h_validity);
 }
 
 void ArrowScan::OpenSource(size_t i) {
@@ -246,68 +247,94 @@ ArrowScan::Slot* ArrowScan::FreeSlot() {
 }
 
 void ArrowScan::DecodeDictionary(Source& src, const DecodedBatch& b) {
-  if (b.is_delta) throw NotImplementedException("Delta dictionaries are not supported by the MI355X scan path");
   ctx->Bind();
   const ArrowField& f = src.reader->GetBaseSchema().fields[static_cast<size_t>(b.column_field[0])];
   int32_t kind, w, nb;
   int64_t param;
   if (!f.Plan(&kind, &param, &w, &nb, /*value_only*/ true))
     throw NotImplementedException("Dictionary value type " + f.Format() + " is not decoded by the MI355X scan path");
-  DictState& d = dicts[b.dict_id];
-  if (d.d_data) {  // dictionary replacement: drop the old one
-    (void)hipFree(d.d_data); (void)hipFree(d.d_validity);
-    if (d.d_heap) (void)hipFree(d.d_heap);
-    if (d.h_data) (void)hipHostFree(d.h_data);
-    if (d.h_validity) (void)hipHostFree(d.h_validity);
-    d = DictState();
+  // isDelta: the new values are appended to the existing dictionary (indices keep their meaning); otherwise the
+  // dictionary is replaced.  Either way a NEW version is built; batches already in flight keep theirs.
+  std::shared_ptr<DictState> old = dicts.count(b.dict_id) ? dicts[b.dict_id] : nullptr;
+  const bool delta = b.is_delta && old;
+  if (delta && old->kind != kind) throw IOException("Delta dictionary changes the value type");
+  auto d = std::make_shared<DictState>();
+  const int64_t n_new = b.column_length[0];
+  const int64_t n_old = delta ? old->dict_len : 0;
+  const int64_t n = n_old + n_new;
+  d->dict_len = n;
+  d->kind = kind;
+  d->out_width = w;
+  if (delta) {
+    d->d_heaps = old->d_heaps;
+    d->host_bodies = old->host_bodies;
   }
-  const int64_t n = b.column_length[0];
-  d.dict_len = n;
-  d.kind = kind;
-  d.out_width = w;
-  d.host_body = b.owner;
+  if (b.owner) d->host_bodies.push_back(b.owner);
   const size_t data_bytes = RoundUp(static_cast<size_t>(n + 1) * static_cast<size_t>(w));
   const size_t valid_bytes = RoundUp(static_cast<size_t>((n + 1 + 63) / 64) * 8);
-  MI_HIP_CHECK(hipMalloc(&d.d_data, data_bytes));
-  MI_HIP_CHECK(hipMalloc(&d.d_validity, valid_bytes));
-  MI_HIP_CHECK(hipMemset(d.d_data, 0, data_bytes));
-  MI_HIP_CHECK(hipMemset(d.d_validity, 0xFF, valid_bytes));
+  MI_HIP_CHECK(hipMalloc(&d->d_data, data_bytes));
+  MI_HIP_CHECK(hipMalloc(&d->d_validity, valid_bytes));
+  MI_HIP_CHECK(hipMemset(d->d_data, 0, data_bytes));
+  uint8_t* heap = nullptr;
   if (b.body_size > 0) {
-    MI_HIP_CHECK(hipMalloc(&d.d_heap, RoundUp(static_cast<size_t>(b.body_size) + 16)));
-    MI_HIP_CHECK(hipMemcpy(d.d_heap, b.body, static_cast<size_t>(b.body_size), hipMemcpyHostToDevice));
+    void* p = nullptr;
+    MI_HIP_CHECK(hipMalloc(&p, RoundUp(static_cast<size_t>(b.body_size) + 16)));
+    d->d_heaps.push_back(std::shared_ptr<void>(p, [](void* q) { (void)hipFree(q); }));
+    heap = static_cast<uint8_t*>(p);
+    MI_HIP_CHECK(hipMemcpy(heap, b.body, static_cast<size_t>(b.body_size), hipMemcpyHostToDevice));
   }
-  if (n > 0) {
+  if (n_old > 0)
+    MI_HIP_CHECK(hipMemcpy(d->d_data, old->d_data, static_cast<size_t>(n_old) * static_cast<size_t>(w), hipMemcpyDeviceToDevice));
+  std::vector<uint64_t> words(valid_bytes / 8, ~0ull);
+  auto set_bit = [&](int64_t i, bool v) {
+    if (v) words[static_cast<size_t>(i >> 6)] |= 1ull << (i & 63);
+    else words[static_cast<size_t>(i >> 6)] &= ~(1ull << (i & 63));
+  };
+  if (n_old > 0) {
+    std::vector<uint64_t> ow(static_cast<size_t>((n_old + 63) / 64));
+    MI_HIP_CHECK(hipMemcpy(ow.data(), old->d_validity, ow.size() * 8, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n_old; i++) set_bit(i, (ow[static_cast<size_t>(i >> 6)] >> (i & 63)) & 1);
+  }
+  if (n_new > 0) {
+    // decode the new values into a tile-aligned scratch vector, then append
+    void* scratch_data = nullptr;
+    void* scratch_valid = nullptr;
+    MI_HIP_CHECK(hipMalloc(&scratch_data, RoundUp(static_cast<size_t>(n_new) * static_cast<size_t>(w) + 16)));
+    MI_HIP_CHECK(hipMalloc(&scratch_valid, RoundUp(static_cast<size_t>((n_new + 63) / 64) * 8 + 8)));
+    std::shared_ptr<void> g1(scratch_data, [](void* q) { (void)hipFree(q); }), g2(scratch_valid, [](void* q) { (void)hipFree(q); });
     mi_col_task t;
     std::memset(&t, 0, sizeof(t));
     const mi_buffer_span* sp = &b.buffers[0];
-    uint8_t* base = static_cast<uint8_t*>(d.d_heap);
-    t.validity = sp[0].length ? base + sp[0].offset : nullptr;
-    t.buf1 = base + sp[1].offset;
-    t.buf2 = nb > 2 ? base + sp[2].offset : nullptr;
+    t.validity = sp[0].length ? heap + sp[0].offset : nullptr;
+    t.buf1 = heap + sp[1].offset;
+    t.buf2 = nb > 2 ? heap + sp[2].offset : nullptr;
     t.buf2_len = nb > 2 ? sp[2].length : 0;
-    t.out_data = d.d_data;
-    t.out_validity = d.d_validity;
+    t.out_data = scratch_data;
+    t.out_validity = scratch_valid;
     const int64_t data_off = nb > 2 ? sp[2].offset : sp[1].offset;
-    t.ptr_base = opts.device_resident ? reinterpret_cast<uint64_t>(base + data_off) : reinterpret_cast<uint64_t>(b.body + data_off);
-    t.nrows = n;
+    t.ptr_base = opts.device_resident ? reinterpret_cast<uint64_t>(heap + data_off) : reinterpret_cast<uint64_t>(b.body + data_off);
+    t.nrows = n_new;
     t.null_count = b.null_count[0];
     t.kind = kind;
     t.param = param;
     Plan plan(ctx, &t, 1);
     plan.Launch(ctx->stream);
     ThrowForStatus(plan.Status());
+    MI_HIP_CHECK(hipMemcpy(static_cast<uint8_t*>(d->d_data) + static_cast<size_t>(n_old) * static_cast<size_t>(w), scratch_data,
+                           static_cast<size_t>(n_new) * static_cast<size_t>(w), hipMemcpyDeviceToDevice));
+    std::vector<uint64_t> nw(static_cast<size_t>((n_new + 63) / 64));
+    MI_HIP_CHECK(hipMemcpy(nw.data(), scratch_valid, nw.size() * 8, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n_new; i++) set_bit(n_old + i, (nw[static_cast<size_t>(i >> 6)] >> (i & 63)) & 1);
   }
-  // the extra NULL entry at index dict_len (ColumnArrowToDuckDBDictionary): clear its validity bit
-  std::vector<uint64_t> words(valid_bytes / 8);
-  MI_HIP_CHECK(hipMemcpy(words.data(), d.d_validity, valid_bytes, hipMemcpyDeviceToHost));
-  words[static_cast<size_t>(n >> 6)] &= ~(1ull << (n & 63));
-  MI_HIP_CHECK(hipMemcpy(d.d_validity, words.data(), valid_bytes, hipMemcpyHostToDevice));
+  set_bit(n, false);  // the extra NULL entry at index dict_len (ColumnArrowToDuckDBDictionary)
+  MI_HIP_CHECK(hipMemcpy(d->d_validity, words.data(), valid_bytes, hipMemcpyHostToDevice));
   if (!opts.device_resident) {
-    MI_HIP_CHECK(hipHostMalloc(&d.h_data, data_bytes, hipHostMallocDefault));
-    MI_HIP_CHECK(hipHostMalloc(&d.h_validity, valid_bytes, hipHostMallocDefault));
-    MI_HIP_CHECK(hipMemcpy(d.h_data, d.d_data, data_bytes, hipMemcpyDeviceToHost));
-    std::memcpy(d.h_validity, words.data(), valid_bytes);
+    MI_HIP_CHECK(hipHostMalloc(&d->h_data, data_bytes, hipHostMallocDefault));
+    MI_HIP_CHECK(hipHostMalloc(&d->h_validity, valid_bytes, hipHostMallocDefault));
+    MI_HIP_CHECK(hipMemcpy(d->h_data, d->d_data, data_bytes, hipMemcpyDeviceToHost));
+    std::memcpy(d->h_validity, words.data(), valid_bytes);
   }
+  dicts[b.dict_id] = d;
 }
 
 void ArrowScan::EnqueueBatch(Slot& s) {
@@ -320,6 +347,7 @@ void ArrowScan::EnqueueBatch(Slot& s) {
   size_t off = 0;
   s.col_data_off.assign(out_columns.size(), 0);
   s.col_valid_off.assign(out_columns.size(), 0);
+  s.col_dict.assign(out_columns.size(), nullptr);
   std::vector<int32_t> kinds(out_columns.size(), 0), widths(out_columns.size(), 0), nbufs(out_columns.size(), 0);
   std::vector<int64_t> params(out_columns.size(), 0);
   for (size_t c = 0; c < out_columns.size(); c++) {
@@ -366,7 +394,8 @@ void ArrowScan::EnqueueBatch(Slot& s) {
     if (kinds[c] == MI_K_DICT) {
       auto it = dicts.find(out_columns[c].field.dict_id);
       if (it == dicts.end()) throw IOException("RecordBatch uses dictionary id " + std::to_string(out_columns[c].field.dict_id) + " before its DictionaryBatch");
-      t.param2 = it->second.dict_len;
+      s.col_dict[c] = it->second;
+      t.param2 = it->second->dict_len;
     }
     tasks.push_back(t);
   }
@@ -538,8 +567,8 @@ void ArrowScan::Next(mi_data_chunk* out) {
     v.validity = reinterpret_cast<mi_validity_t*>(base + s.col_valid_off[c]) + cur_row / 64;
     v.kind = kind;
     v.out_width = w;
-    if (kind == MI_K_DICT) {
-      const DictState& d = dicts[out_columns[c].field.dict_id];
+    if (kind == MI_K_DICT && s.col_dict[c]) {
+      const DictState& d = *s.col_dict[c];
       v.dictionary = opts.device_resident ? d.d_data : d.h_data;
       v.dictionary_validity = static_cast<const mi_validity_t*>(opts.device_resident ? d.d_validity : d.h_validity);
       v.dict_len = d.dict_len;

@@ -59,15 +59,18 @@ class ArrowScan {
     std::map<std::string, std::string> hive;   // key -> value parsed from the path
     bool opened = false;
   };
+  //! One immutable version of a decoded dictionary (dict_len + 1 entries, the last one NULL).  Record batches keep the
+  //! version they were enqueued with, so a later replacement / delta never changes what an in-flight batch sees.
   struct DictState {
-    void* d_data = nullptr;        // decoded dictionary values (dict_len + 1 entries) on the device
+    void* d_data = nullptr;        // decoded values on the device
     void* d_validity = nullptr;
     void* h_data = nullptr;        // pinned host copy (host consumers)
     void* h_validity = nullptr;
-    void* d_heap = nullptr;        // device copy of the dictionary's IPC body (string payload lives here)
-    std::shared_ptr<void> host_body;  // keeps the host body alive: long dictionary strings point into it
+    std::vector<std::shared_ptr<void>> d_heaps;      // device copies of the dictionary bodies (long string payload)
+    std::vector<std::shared_ptr<void>> host_bodies;  // host bodies: long dictionary strings point into them
     int64_t dict_len = 0;
     int32_t kind = 0, out_width = 0;
+    ~DictState();
   };
   struct Slot {
     // one record batch in flight
@@ -86,6 +89,7 @@ class ArrowScan {
     std::vector<size_t> col_data_off, col_valid_off;   // per output column, offsets into d_out / h_out
     size_t sel_off = 0, sel_count_off = 0;             // filter outputs
     std::shared_ptr<void> external_body;               // buffer sources: nothing to own, body is caller memory
+    std::vector<std::shared_ptr<DictState>> col_dict;  // per output column: the dictionary version this batch uses
   };
 
   void OpenSource(size_t i);
@@ -121,7 +125,7 @@ class ArrowScan {
   std::vector<std::vector<mi_string_t>> const_vectors;
   std::vector<mi_validity_t> all_valid;
   // dictionaries by id
-  std::map<int64_t, DictState> dicts;
+  std::map<int64_t, std::shared_ptr<DictState>> dicts;
   // filter
   bool has_filter = false;
   std::string filter_column;

@@ -234,6 +234,34 @@ def test_dictionary_encoded_columns(con, golden_dir, expected):
         assert column_digest(values) == expected["edge_dict.arrows"]["columns"][name], name
 
 
+def test_delta_and_replacement_dictionaries(con, tmp_path):
+    """DictionaryBatch.isDelta appends to the dictionary, a plain DictionaryBatch replaces it; batches already in flight
+    keep the version they were enqueued with (beyond the reference)."""
+    sch = pa.schema([("k", pa.dictionary(pa.int8(), pa.string())), ("v", pa.int32())])
+
+    def batch(values, dictionary, n0):
+        idx = pa.array([None if v is None else dictionary.index(v) for v in values], pa.int8())
+        return pa.record_batch([pa.DictionaryArray.from_arrays(idx, pa.array(dictionary)), pa.array(range(n0, n0 + len(values)), pa.int32())],
+                               schema=sch)
+
+    rows = [(["a", "b", None, "a"], ["a", "b"]),
+            (["c", "a", None, "a much longer dictionary value"], ["a", "b", "c", "a much longer dictionary value"]),   # delta
+            (["x", None, "y", "x"], ["x", "y"]),                                                                       # replacement
+            (["y", "z"], ["x", "y", "z"])]                                                                              # delta again
+    p = str(tmp_path / "delta.arrows")
+    with ipc.new_stream(p, sch, options=ipc.IpcWriteOptions(emit_dictionary_deltas=True)) as w:
+        n0 = 0
+        for values, dictionary in rows:
+            w.write_batch(batch(values, dictionary, n0))
+            n0 += len(values)
+    kinds = [(e["type"]) for e in da.Reader(path=p).index()]
+    assert kinds.count(2) == 4 and kinds.count(3) == 4
+    got = con.read_arrow(p, accept_dictionaries=True).fetchall()
+    want = [(v, i) for i, v in enumerate(v for values, _ in rows for v in values)]
+    assert got == want
+    assert got == [(r["k"], r["v"]) for r in ipc.open_stream(p).read_all().to_pylist()]
+
+
 def test_device_resident_chunks(con, golden_dir):
     """device_resident = 1: vectors stay in HBM for a GPU consumer (no D2H); pointers are device addresses."""
     import torch

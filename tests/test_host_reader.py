@@ -172,6 +172,23 @@ def test_batch_index_for_sharding(golden_dir):
     assert idx2 == idx
 
 
+def test_file_footer_index_equals_header_walk(golden_dir, tmp_path):
+    """IPC *file* format: the footer's Block list gives the batch index without walking the stream
+    (noted as future work in the reference: ipc_file_stream_reader.cpp:113-115, arrow_file_scan.cpp:36-40)."""
+    for rel in ("edge_file_format.arrow", "ref_data/fruit.arrow"):
+        p = os.path.join(golden_dir, rel)
+        from_footer = da.Reader(path=p).index()
+        walked = da.Reader(buffers=[load(golden_dir, rel)]).index()  # the buffer reader always walks headers
+        assert from_footer == walked and len(from_footer) >= 1
+    # a file with a dictionary: dictionary blocks come first, in stream order
+    t = pa.table({"d": pa.array(["x", "y", "x", None] * 50).dictionary_encode(), "v": list(range(200))})
+    p = str(tmp_path / "dict.arrow")
+    with ipc.new_file(p, t.schema) as w:
+        w.write_table(t, max_chunksize=64)
+    idx = da.Reader(path=p).index()
+    assert [e["type"] for e in idx] == [2, 3, 3, 3, 3] and sum(e["n_rows"] for e in idx if e["type"] == 3) == 200
+
+
 def test_size_validation_rejects_short_buffers(golden_dir):
     """NANOARROW_VALIDATION_LEVEL_FULL size checks: a RecordBatch whose body is shorter than its buffers claim."""
     buf = load(golden_dir, "ref_data/test.arrows").copy()
