@@ -124,7 +124,15 @@ class Reader:
                     is_delta=bool(b.is_delta), compression=b.compression,
                     column_field=[b.column_field[i] for i in range(nc)],
                     null_count=[b.null_count[i] for i in range(nc)],
-                    buffers=[(b.buffers[i].offset, b.buffers[i].length) for i in range(3 * nc)])
+                    buffers=[(b.buffers[i].offset, b.buffers[i].length) for i in range(3 * nc)],
+                    column_node=[b.column_node[i] for i in range(nc)],
+                    nodes=[dict(name=b.nodes[i].name.decode(), arrow_type=b.nodes[i].arrow_type, kind=b.nodes[i].kind,
+                                out_width=b.nodes[i].out_width, parent=b.nodes[i].parent, depth=b.nodes[i].depth,
+                                n_children=b.nodes[i].n_children, param=b.nodes[i].param, length=b.nodes[i].length,
+                                null_count=b.nodes[i].null_count,
+                                spans=[(b.node_spans[j].offset, b.node_spans[j].length)
+                                       for j in range(b.nodes[i].first_span, b.nodes[i].first_span + b.nodes[i].n_spans)])
+                           for i in range(b.n_nodes)])
 
     def index(self):
         ent = C.POINTER(_ffi.BatchIndexEntry)()
@@ -156,12 +164,12 @@ class Context:
 
 
 def make_task(kind, nrows, buf1, out_data, *, validity=0, buf2=0, out_validity=0, out_aux=0, ptr_base=0, row_offset=0,
-              buf2_len=0, param=0, param2=0, null_count=-1):
-    """mi_col_task from raw device addresses."""
+              buf2_len=0, param=0, param2=0, null_count=-1, depth=0, parent_div=0):
+    """mi_col_task from raw device addresses (decode: out_aux = parent validity words, parent_div = rows per parent row)."""
     return _ffi.ColTask(validity=validity or None, buf1=buf1 or None, buf2=buf2 or None, out_data=out_data or None,
                         out_validity=out_validity or None, out_aux=out_aux or None, ptr_base=ptr_base, nrows=nrows,
                         row_offset=row_offset, buf2_len=buf2_len, param=param, param2=param2, null_count=null_count,
-                        kind=kind, flags=0)
+                        kind=kind, flags=parent_div, depth=depth)
 
 
 class Plan:

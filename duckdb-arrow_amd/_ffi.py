@@ -14,7 +14,8 @@ VECTOR_SIZE = 2048
 
 # enum mi_kind
 K_COPY, K_BOOL, K_DEC128, K_DATE64, K_MUL_I32, K_MUL_I64, K_DIV_I64, K_STR32, K_STR64, K_DICT, K_FIXED_BINARY, \
-    K_DURATION, K_INTERVAL_MONTHS, K_INTERVAL_MDN, K_NARROW, K_HALF_FLOAT, K_NULL = range(1, 18)
+    K_DURATION, K_INTERVAL_MONTHS, K_INTERVAL_MDN, K_NARROW, K_HALF_FLOAT, K_NULL, K_STRVIEW, K_LIST32, K_LIST64, \
+    K_STRUCT = range(1, 22)
 K_ENC_COPY, K_ENC_DEC128, K_ENC_BOOL, K_ENC_STR32 = 32, 33, 34, 35
 
 ST_BAD_OFFSETS, ST_STRING_TOO_LARGE, ST_MUL_OVERFLOW, ST_INDEX_RANGE, ST_DECIMAL_RANGE, ST_OFFSET_OVERFLOW = \
@@ -39,12 +40,19 @@ class BufferSpan(C.Structure):
     _fields_ = [("offset", C.c_int64), ("length", C.c_int64)]
 
 
+class BatchNode(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("arrow_type", C.c_int32), ("kind", C.c_int32), ("out_width", C.c_int32),
+                ("parent", C.c_int32), ("depth", C.c_int32), ("n_children", C.c_int32), ("first_span", C.c_int32),
+                ("n_spans", C.c_int32), ("param", C.c_int64), ("length", C.c_int64), ("null_count", C.c_int64)]
+
+
 class Batch(C.Structure):
     _fields_ = [("length", C.c_int64), ("body", C.c_void_p), ("body_size", C.c_int64),
                 ("body_file_offset", C.c_int64), ("n_columns", C.c_int32), ("is_dictionary", C.c_int32),
                 ("dict_id", C.c_int64), ("is_delta", C.c_int32), ("compression", C.c_int32),
                 ("column_field", C.POINTER(C.c_int32)), ("null_count", C.POINTER(C.c_int64)),
-                ("buffers", C.POINTER(BufferSpan))]
+                ("buffers", C.POINTER(BufferSpan)), ("n_nodes", C.c_int32), ("_pad", C.c_int32),
+                ("nodes", C.POINTER(BatchNode)), ("node_spans", C.POINTER(BufferSpan)), ("column_node", C.POINTER(C.c_int32))]
 
 
 class BatchIndexEntry(C.Structure):
@@ -56,7 +64,8 @@ class ColTask(C.Structure):
     _fields_ = [("validity", C.c_void_p), ("buf1", C.c_void_p), ("buf2", C.c_void_p), ("out_data", C.c_void_p),
                 ("out_validity", C.c_void_p), ("out_aux", C.c_void_p), ("ptr_base", C.c_uint64),
                 ("nrows", C.c_int64), ("row_offset", C.c_int64), ("buf2_len", C.c_int64), ("param", C.c_int64),
-                ("param2", C.c_int64), ("null_count", C.c_int64), ("kind", C.c_int32), ("flags", C.c_int32)]
+                ("param2", C.c_int64), ("null_count", C.c_int64), ("kind", C.c_int32), ("flags", C.c_int32),
+                ("depth", C.c_int32), ("_reserved", C.c_int32)]
 
 
 class ScanOptions(C.Structure):
@@ -66,8 +75,13 @@ class ScanOptions(C.Structure):
 
 
 class Vector(C.Structure):
-    _fields_ = [("data", C.c_void_p), ("validity", C.c_void_p), ("kind", C.c_int32), ("out_width", C.c_int32),
-                ("dictionary", C.c_void_p), ("dictionary_validity", C.c_void_p), ("dict_len", C.c_int64)]
+    pass
+
+
+Vector._fields_ = [("data", C.c_void_p), ("validity", C.c_void_p), ("kind", C.c_int32), ("out_width", C.c_int32),
+                   ("dictionary", C.c_void_p), ("dictionary_validity", C.c_void_p), ("dict_len", C.c_int64),
+                   ("children", C.POINTER(Vector)), ("n_children", C.c_int32), ("validity_shift", C.c_int32),
+                   ("count", C.c_int64)]
 
 
 class DataChunk(C.Structure):

@@ -42,6 +42,8 @@ int Wrap(F&& f) {
 struct mi_reader {
   std::unique_ptr<IPCStreamReader> reader;
   DecodedBatch batch;
+  std::vector<mi_batch_node> nodes;
+  std::vector<mi_buffer_span> node_spans;
   std::vector<mi_batch_index_entry> index;
 };
 struct mi_ctx {
@@ -140,6 +142,34 @@ int mi_reader_next_batch(mi_reader* r, int32_t accept_dictionaries, mi_batch* ou
     out->column_field = b.column_field.data();
     out->null_count = b.null_count.data();
     out->buffers = b.buffers.data();
+    r->nodes.clear();
+    r->node_spans.clear();
+    for (auto& nd : b.nodes) {
+      mi_batch_node c;
+      std::memset(&c, 0, sizeof(c));
+      std::snprintf(c.name, sizeof(c.name), "%s", nd.field->name.c_str());
+      c.arrow_type = nd.field->type;
+      int32_t kind = 0, w = 0, nb = 0;
+      int64_t param = 0;
+      if (nd.field->Plan(&kind, &param, &w, &nb, nd.value_only)) {
+        c.kind = kind;
+        c.out_width = w;
+        c.param = param;
+      }
+      c.parent = nd.parent;
+      c.depth = nd.depth;
+      c.n_children = static_cast<int32_t>(nd.children.size());
+      c.first_span = static_cast<int32_t>(r->node_spans.size());
+      c.n_spans = static_cast<int32_t>(nd.spans.size());
+      c.length = nd.length;
+      c.null_count = nd.null_count;
+      r->node_spans.insert(r->node_spans.end(), nd.spans.begin(), nd.spans.end());
+      r->nodes.push_back(c);
+    }
+    out->n_nodes = static_cast<int32_t>(r->nodes.size());
+    out->nodes = r->nodes.data();
+    out->node_spans = r->node_spans.data();
+    out->column_node = b.column_node.data();
   });
   if (rc != MI_OK) return rc;
   return got ? MI_OK : MI_ENODATA;
@@ -220,7 +250,7 @@ int mi_plan_class_stats(const mi_plan* plan, int32_t cls, int64_t* bytes_read, i
     if (bytes_read) *bytes_read = plan->plan->class_bytes_read[cls];
     if (bytes_written) *bytes_written = plan->plan->class_bytes_written[cls];
     if (rows) *rows = plan->plan->class_rows[cls];
-    if (tiles) *tiles = plan->plan->classes[cls].total_tiles;
+    if (tiles) *tiles = plan->plan->class_tiles[cls];
     if (kernel_name) *kernel_name = names[cls];
   });
 }

@@ -49,6 +49,8 @@ int OutWidth(int32_t kind, int64_t param) {
     case MI_K_NARROW: return static_cast<int>((param >> 8) & 0xFF);
     case MI_K_HALF_FLOAT: return 4;
     case MI_K_NULL: return 1;
+    case MI_K_STRVIEW: case MI_K_LIST32: case MI_K_LIST64: return 16;
+    case MI_K_STRUCT: return 0;
     case MI_K_DICT: return 4;
     default: return 0;
   }
@@ -61,13 +63,28 @@ static void ValidateTask(const mi_col_task& t, size_t i) {
   if (device::ClassOfKind(t.kind) < 0) fail("unknown kind " + std::to_string(t.kind));
   if (t.nrows < 0) fail("negative row count");
   if (t.row_offset < 0) fail("negative row offset");
+  if (t.depth < 0 || t.depth > 64) fail("bad nesting depth");
   if (t.nrows == 0) return;
+  if (t.kind == MI_K_STRUCT) {
+    if (t.out_validity == nullptr) fail("STRUCT tasks produce validity only: out_validity is NULL");
+    if (reinterpret_cast<uintptr_t>(t.out_validity) % 8 != 0) fail("out_validity must be 8-byte aligned");
+    return;
+  }
   if (t.out_data == nullptr) fail("out_data is NULL");
   if (reinterpret_cast<uintptr_t>(t.out_data) % 16 != 0) fail("out_data must be 16-byte aligned");
   if (t.out_validity && reinterpret_cast<uintptr_t>(t.out_validity) % 8 != 0) fail("out_validity must be 8-byte aligned");
   if (t.validity && reinterpret_cast<uintptr_t>(t.validity) % 8 != 0) fail("validity bitmap must be 8-byte aligned");
   if (t.buf1 == nullptr && t.kind != MI_K_NULL) fail("buf1 is NULL");
   switch (t.kind) {
+    case MI_K_LIST32: case MI_K_LIST64:
+      if (reinterpret_cast<uintptr_t>(t.buf1) % (t.kind == MI_K_LIST32 ? 4 : 8) != 0) fail("offsets buffer misaligned");
+      if (t.param < 0) fail("LIST needs param = child length");
+      if (t.buf2 && t.buf2_len <= 0) fail("window table is empty");
+      break;
+    case MI_K_STRVIEW:
+      if (reinterpret_cast<uintptr_t>(t.buf1) % 4 != 0) fail("views buffer misaligned");
+      if (t.buf2_len > 0 && t.buf2 == nullptr) fail("STRVIEW needs the variadic buffer table in buf2");
+      break;
     case MI_K_NARROW: {
       const int sw = static_cast<int>(t.param & 0xFF), dw = static_cast<int>((t.param >> 8) & 0xFF);
       if (!((sw == 4 && dw == 2) || (sw == 8 && (dw == 2 || dw == 4)))) fail("NARROW needs src 4->2 or 8->2/4");
@@ -138,8 +155,12 @@ static int64_t TaskBytesRead(const mi_col_task& t) {
       case MI_K_INTERVAL_MDN: b += n * 16; break;
       case MI_K_NARROW: b += n * (t.param & 0xFF); break;
       case MI_K_HALF_FLOAT: b += n * 2; break;
+      case MI_K_LIST32: b += n ? (n + 1) * 4 : 0; break;
+      case MI_K_LIST64: b += n ? (n + 1) * 8 : 0; break;
+      case MI_K_STRVIEW: b += n * 16; break;
       default: break;
     }
+    if (t.out_aux) b += ((n + 63) / 64) * 8;
   } else {
     if (t.validity) b += ((n + 63) / 64) * 8;
     switch (t.kind) {
@@ -195,14 +216,18 @@ void Plan::Set(const mi_col_task* in_tasks, int32_t n_tasks, hipStream_t upload_
   tasks.clear();
   order.clear();
   tile_begin.clear();
-  tile_task.clear();
-  class_tile_task_at.assign(device::kNumClasses, 0);
   total_tiles = 0;
   bytes_read = bytes_written = rows = 0;
   for (int c = 0; c < device::kNumClasses; c++) class_bytes_read[c] = class_bytes_written[c] = class_rows[c] = 0;
   is_encode = false;
-  // group by kernel class, stable inside a class
-  std::vector<std::vector<mi_col_task>> by_class(device::kNumClasses);
+  // group by (nesting depth, kernel class), stable inside a group: a child task runs in a later launch than its parent,
+  // so it sees the parent's finished validity words
+  slices.clear();
+  tile_task.clear();
+  for (int c = 0; c < device::kNumClasses; c++) class_tiles[c] = 0;
+  int max_depth = 0;
+  std::vector<mi_col_task> staged;
+  std::vector<int> staged_cls;
   int64_t null_counter = 0;
   for (int32_t i = 0; i < n_tasks; i++) {
     ValidateTask(in_tasks[i], static_cast<size_t>(i));
@@ -210,6 +235,7 @@ void Plan::Set(const mi_col_task* in_tasks, int32_t n_tasks, hipStream_t upload_
     const int cls = device::ClassOfKind(t.kind);
     if (t.kind >= MI_K_ENC_COPY) {
       is_encode = true;
+      t.depth = 0;
       t.param2 = null_counter++;  // slot of this task's NULL counter
     }
     bytes_read += TaskBytesRead(t);
@@ -218,31 +244,43 @@ void Plan::Set(const mi_col_task* in_tasks, int32_t n_tasks, hipStream_t upload_
     class_bytes_read[cls] += TaskBytesRead(t);
     class_bytes_written[cls] += TaskBytesWritten(t);
     class_rows[cls] += t.nrows;
-    order.push_back({cls, static_cast<int32_t>(by_class[static_cast<size_t>(cls)].size())});
-    by_class[static_cast<size_t>(cls)].push_back(t);
+    max_depth = std::max(max_depth, t.depth);
+    staged.push_back(t);
+    staged_cls.push_back(cls);
   }
   n_null_counts = null_counter;
-  for (int c = 0; c < device::kNumClasses; c++) {
-    ClassSlice& s = classes[c];
-    s.first_task = static_cast<int32_t>(tasks.size());
-    s.n_tasks = static_cast<int32_t>(by_class[static_cast<size_t>(c)].size());
-    s.tile_begin_at = static_cast<int32_t>(tile_begin.size());
-    uint64_t tiles = 0;
-    class_tile_task_at[static_cast<size_t>(c)] = tile_task.size();
-    uint32_t local_task = 0;
-    for (auto& t : by_class[static_cast<size_t>(c)]) {
-      tile_begin.push_back(static_cast<uint32_t>(tiles));
+  order.assign(static_cast<size_t>(n_tasks), {0, 0});
+  for (int depth = 0; depth <= max_depth; depth++) {
+    for (int c = 0; c < device::kNumClasses; c++) {
+      ClassSlice sl;
+      sl.cls = c;
+      sl.depth = depth;
+      sl.first_task = static_cast<int32_t>(tasks.size());
+      sl.tile_begin_at = static_cast<int32_t>(tile_begin.size());
+      sl.tile_task_at = tile_task.size();
       const int64_t tile_rows = device::TileRowsOfClass(c);
-      const uint64_t nt = static_cast<uint64_t>((t.nrows + tile_rows - 1) / tile_rows);
-      tiles += nt;
-      if (tiles > 0xFFFFFFF0ull) throw InvalidInputException("plan has too many tiles");
-      if (c < device::kClassEncFixed) tile_task.insert(tile_task.end(), static_cast<size_t>(nt), local_task);
-      local_task++;
-      tasks.push_back(t);
+      uint64_t tiles = 0;
+      uint32_t local_task = 0;
+      for (size_t i = 0; i < staged.size(); i++) {
+        if (staged_cls[i] != c || staged[i].depth != depth) continue;
+        const mi_col_task& t = staged[i];
+        tile_begin.push_back(static_cast<uint32_t>(tiles));
+        const uint64_t nt = static_cast<uint64_t>((t.nrows + tile_rows - 1) / tile_rows);
+        tiles += nt;
+        if (tiles > 0xFFFFFFF0ull) throw InvalidInputException("plan has too many tiles");
+        if (c < device::kClassEncFixed) tile_task.insert(tile_task.end(), static_cast<size_t>(nt), local_task);
+        order[i] = {static_cast<int>(slices.size()), static_cast<int32_t>(local_task)};
+        local_task++;
+        tasks.push_back(t);
+      }
+      if (local_task == 0) continue;
+      tile_begin.push_back(static_cast<uint32_t>(tiles));
+      sl.n_tasks = static_cast<int32_t>(local_task);
+      sl.total_tiles = static_cast<uint32_t>(tiles);
+      total_tiles += sl.total_tiles;
+      class_tiles[c] += sl.total_tiles;
+      slices.push_back(sl);
     }
-    tile_begin.push_back(static_cast<uint32_t>(tiles));
-    s.total_tiles = static_cast<uint32_t>(tiles);
-    total_tiles += s.total_tiles;
   }
   // device tables
   const size_t old_cap_tasks = cap_tasks, old_cap_tb = cap_tile_begin;
@@ -254,8 +292,7 @@ void Plan::Set(const mi_col_task* in_tasks, int32_t n_tasks, hipStream_t upload_
     MI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_status), 64));
     MI_HIP_CHECK(hipMemset(d_status, 0, 64));
   }
-  if (classes[device::kClassEncString].total_tiles)
-    EnsureDevice(&d_tile_sums, &cap_tile_sums, classes[device::kClassEncString].total_tiles);
+  if (class_tiles[device::kClassEncString]) EnsureDevice(&d_tile_sums, &cap_tile_sums, class_tiles[device::kClassEncString]);
   if (n_null_counts) {
     const size_t before = cap_null_counts;
     EnsureDevice(&d_null_counts, &cap_null_counts, static_cast<size_t>(n_null_counts));
@@ -305,13 +342,12 @@ Plan::~Plan() {
   if (h_tile_task) (void)hipHostFree(h_tile_task);
 }
 
-void Plan::LaunchClass(int c, hipStream_t s) {
+void Plan::LaunchSlice(const ClassSlice& cs, hipStream_t s) {
   const int grid = ctx->GridBlocks();
-  const ClassSlice& cs = classes[c];
   if (cs.total_tiles == 0) return;
   const mi_col_task* t = d_tasks + cs.first_task;
   const uint32_t* tb = d_tile_begin + cs.tile_begin_at;
-  switch (c) {
+  switch (cs.cls) {
     case device::kClassEncFixed:
       MI_HIP_CHECK(device::LaunchEncodeFixed(t, tb, cs.n_tasks, cs.total_tiles, d_null_counts, grid, s));
       break;
@@ -321,8 +357,8 @@ void Plan::LaunchClass(int c, hipStream_t s) {
       MI_HIP_CHECK(device::LaunchEncodeString(t, tb, cs.n_tasks, cs.total_tiles, d_tile_sums, d_null_counts, grid, s));
       break;
     default:
-      MI_HIP_CHECK(device::LaunchTranscode(c, t, tb, d_tile_task + class_tile_task_at[static_cast<size_t>(c)], cs.n_tasks,
-                                           cs.total_tiles, d_status, ctx->num_cus, s));
+      MI_HIP_CHECK(device::LaunchTranscode(cs.cls, t, tb, d_tile_task + cs.tile_task_at, cs.n_tasks, cs.total_tiles, d_status,
+                                           ctx->num_cus, s));
       break;
   }
 }
@@ -331,24 +367,26 @@ void Plan::Launch(hipStream_t s) {
   ctx->Bind();
   if (!s) s = ctx->stream;
   last_stream = s;
-  for (int c = 0; c < device::kNumClasses; c++) LaunchClass(c, s);
+  for (const auto& sl : slices) LaunchSlice(sl, s);
 }
 
 void Plan::LaunchTimed(hipStream_t s, float* ms_per_class) {
   ctx->Bind();
   if (!s) s = ctx->stream;
   last_stream = s;
-  hipEvent_t ev[device::kNumClasses + 1];
+  std::vector<hipEvent_t> ev(slices.size() + 1);
   for (auto& e : ev) MI_HIP_CHECK(hipEventCreate(&e));
   MI_HIP_CHECK(hipEventRecord(ev[0], s));
-  for (int c = 0; c < device::kNumClasses; c++) {
-    LaunchClass(c, s);
-    MI_HIP_CHECK(hipEventRecord(ev[c + 1], s));
+  for (size_t i = 0; i < slices.size(); i++) {
+    LaunchSlice(slices[i], s);
+    MI_HIP_CHECK(hipEventRecord(ev[i + 1], s));
   }
   MI_HIP_CHECK(hipStreamSynchronize(s));
-  for (int c = 0; c < device::kNumClasses; c++) {
-    ms_per_class[c] = 0;
-    if (classes[c].total_tiles) MI_HIP_CHECK(hipEventElapsedTime(&ms_per_class[c], ev[c], ev[c + 1]));
+  for (int c = 0; c < device::kNumClasses; c++) ms_per_class[c] = 0;
+  for (size_t i = 0; i < slices.size(); i++) {
+    float ms = 0;
+    MI_HIP_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+    ms_per_class[slices[i].cls] += ms;
   }
   for (auto& e : ev) (void)hipEventDestroy(e);
 }
@@ -375,7 +413,7 @@ std::vector<int64_t> Plan::NullCounts(bool reset) {
   // back to the caller's task order (non-encode tasks report 0)
   std::vector<int64_t> out(order.size(), 0);
   for (size_t i = 0; i < order.size(); i++) {
-    const mi_col_task& t = tasks[static_cast<size_t>(classes[order[i].first].first_task + order[i].second)];
+    const mi_col_task& t = tasks[static_cast<size_t>(slices[static_cast<size_t>(order[i].first)].first_task + order[i].second)];
     if (t.kind >= MI_K_ENC_COPY) out[i] = per_slot[static_cast<size_t>(t.param2)];
   }
   return out;

@@ -37,6 +37,9 @@ struct Context {
 int OutWidth(int32_t kind, int64_t param);
 
 struct ClassSlice {
+  int32_t cls = 0;            // device::KernelClass
+  int32_t depth = 0;          // nesting depth of the tasks in this slice
+  size_t tile_task_at = 0;    // index into Plan::tile_task / d_tile_task
   int32_t first_task = 0;     // index into Plan::tasks / d_tasks
   int32_t n_tasks = 0;
   int32_t tile_begin_at = 0;  // index into Plan::tile_begin / d_tile_begin (n_tasks + 1 entries)
@@ -50,14 +53,14 @@ struct Plan {
   std::vector<mi_col_task> tasks;                 // grouped by class
   std::vector<std::pair<int, int32_t>> order;     // caller order -> (class, index inside the class)
   std::vector<uint32_t> tile_begin;
-  ClassSlice classes[device::kNumClasses];
+  std::vector<ClassSlice> slices;                 // launch order: depth by depth, class by class
+  uint32_t class_tiles[device::kNumClasses] = {0};
   mi_col_task* d_tasks = nullptr;
   uint32_t* d_tile_begin = nullptr;
   uint32_t* d_tile_task = nullptr;   // per class slice: task index (within the slice) of every tile
   uint32_t* h_tile_task = nullptr;
   size_t cap_tile_task = 0;
   std::vector<uint32_t> tile_task;
-  std::vector<size_t> class_tile_task_at;
   uint32_t* d_status = nullptr;
   int64_t* d_tile_sums = nullptr;    // encode plans with string columns
   int64_t* d_null_counts = nullptr;  // encode plans: one counter per task
@@ -81,7 +84,7 @@ struct Plan {
   Plan(const Plan&) = delete;
   Plan& operator=(const Plan&) = delete;
   void Launch(hipStream_t stream);
-  void LaunchClass(int cls, hipStream_t stream);
+  void LaunchSlice(const ClassSlice& cs, hipStream_t stream);
   //! Launch with hipEvents around each class; returns milliseconds per class after synchronising the stream
   void LaunchTimed(hipStream_t stream, float* ms_per_class);
   int64_t class_bytes_read[device::kNumClasses] = {0}, class_bytes_written[device::kNumClasses] = {0},

@@ -154,8 +154,26 @@ bool ArrowField::Plan(int32_t* kind, int64_t* param, int32_t* out_width, int32_t
     case MI_AT_UTF8: case MI_AT_BINARY: *n_buffers = 3; return set(MI_K_STR32, 0, 16);
     case MI_AT_LARGE_UTF8: case MI_AT_LARGE_BINARY: *n_buffers = 3; return set(MI_K_STR64, 0, 16);
     case MI_AT_FIXED_BINARY: return set(MI_K_FIXED_BINARY, byte_width, 16);
+    case MI_AT_UTF8_VIEW: case MI_AT_BINARY_VIEW: return set(MI_K_STRVIEW, 0, 16);  // + variadic data buffers
+    case MI_AT_LIST: case MI_AT_MAP: return set(MI_K_LIST32, 0, 16);
+    case MI_AT_LARGE_LIST: return set(MI_K_LIST64, 0, 16);
+    case MI_AT_STRUCT: *n_buffers = 1; return set(MI_K_STRUCT, 0, 0);
+    case MI_AT_FIXED_LIST: *n_buffers = 1; return set(MI_K_STRUCT, byte_width, 0);  // DuckDB ARRAY: validity + one child
     default: return false;
   }
+}
+
+bool ArrowField::Supported(std::string* why) const {
+  int32_t kind, w, nb;
+  int64_t param;
+  if (!Plan(&kind, &param, &w, &nb)) {
+    if (why) *why = "Arrow type " + Format() + " of field '" + name + "'";
+    return false;
+  }
+  if (has_dictionary) return true;
+  for (auto& c : children)
+    if (!c.Supported(why)) return false;
+  return true;
 }
 
 int64_t ArrowField::CountFields() const {
@@ -272,6 +290,7 @@ static ArrowField DecodeField(const fb::Table& f, int depth) {
     case MI_AT_INTERVAL: o.unit = t.scalar<int16_t>(0, 0); break;
     case MI_AT_FIXED_BINARY: o.byte_width = t.scalar<int32_t>(0, 0); break;
     case MI_AT_FIXED_LIST: o.byte_width = t.scalar<int32_t>(0, 0); break;
+    case MI_AT_UNION: o.unit = t.scalar<int16_t>(0, 0); break;  // UnionMode: 0 sparse, 1 dense
     default: break;
   }
   fb::Table d = f.table(4);

@@ -70,6 +70,7 @@ struct ArrowField {
   std::string DuckType() const;  // DuckDB logical type name
   // Transcode plan for the value type (ignoring dictionary encoding when value_only)
   bool Plan(int32_t* kind, int64_t* param, int32_t* out_width, int32_t* n_buffers, bool value_only = false) const;
+  bool Supported(std::string* why) const;  // this field and all its descendants can be decoded by the path
   int64_t CountFields() const;   // IPCStreamReader::CountFields (base_stream_reader.cpp:271-277)
   int64_t CountBuffers() const;  // buffers this field and its children own in a RecordBatch body
 };

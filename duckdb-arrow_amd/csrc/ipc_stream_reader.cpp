@@ -313,52 +313,100 @@ void IPCStreamReader::SliceBatch(const RecordBatchMeta& meta, DecodedBatch* out)
     if (s.offset % 8 != 0) throw InternalException("Buffer offset " + std::to_string(s.offset) + " is not 8-byte aligned");
   };
 
-  auto emit = [&](const ArrowField& f, int32_t top_index, size_t node_i, size_t buf_i) {
-    int32_t kind, w, nb;
-    int64_t param;
-    bool ok = f.Plan(&kind, &param, &w, &nb, /*value_only*/ meta.is_dictionary);
-    if (node_i >= meta.nodes.size()) throw InternalException("RecordBatch has too few field nodes");
-    int64_t n = meta.nodes[node_i].first;
-    int64_t nulls = meta.nodes[node_i].second;
-    if (n < 0) throw InternalException("Field node length is negative");
-    if (!ok) nb = static_cast<int32_t>(std::min<int64_t>(f.CountBuffers(), 3));
-    mi_buffer_span spans[3] = {{0, 0}, {0, 0}, {0, 0}};
-    for (int32_t k = 0; k < nb && k < 3; k++) {
-      if (buf_i + static_cast<size_t>(k) >= meta.buffers.size()) throw InternalException("RecordBatch has too few buffers");
-      spans[k] = meta.buffers[buf_i + static_cast<size_t>(k)];
-      check_span(spans[k]);
-    }
-    if (ok) {
-      // size checks of ArrowArrayViewValidate (FULL), minus the data-dependent offsets walk
-      if (spans[0].length != 0 && spans[0].length < (n + 7) / 8)
-        throw InternalException(BufferSizeError(f.name, 0, (n + 7) / 8, spans[0].length));
-      if (kind != MI_K_NULL && spans[0].length == 0 && n > 0 && nulls > 0)
-        throw InternalException("Column " + f.name + " has null_count " + std::to_string(nulls) + " but no validity buffer");
-      int64_t need1 = 0;
-      switch (kind) {
-        case MI_K_COPY: case MI_K_FIXED_BINARY: need1 = n * param; break;
-        case MI_K_BOOL: need1 = (n + 7) / 8; break;
-        case MI_K_DEC128: need1 = n * 16; break;
-        case MI_K_DATE64: case MI_K_MUL_I64: case MI_K_DIV_I64: case MI_K_DURATION: need1 = n * 8; break;
-        case MI_K_MUL_I32: need1 = n * 4; break;
-        case MI_K_STR32: need1 = n > 0 ? (n + 1) * 4 : 0; break;
-        case MI_K_STR64: need1 = n > 0 ? (n + 1) * 8 : 0; break;
-        case MI_K_DICT: need1 = n * (param & 0xFF); break;
-        case MI_K_INTERVAL_MONTHS: need1 = n * 4; break;
-        case MI_K_INTERVAL_MDN: need1 = n * 16; break;
-        case MI_K_NARROW: need1 = n * (param & 0xFF); break;
-        case MI_K_HALF_FLOAT: need1 = n * 2; break;
-        default: break;
-      }
-      if (spans[1].length < need1) throw InternalException(BufferSizeError(f.name, 1, need1, spans[1].length));
-    }
-    out->column_field.push_back(top_index);
-    out->null_count.push_back(nulls);
-    out->column_length.push_back(n);
-    out->buffers.push_back(spans[0]);
-    out->buffers.push_back(spans[1]);
-    out->buffers.push_back(spans[2]);
+  // Depth-first walk over ALL fields keeps the node / buffer / variadic cursors of RecordBatch.{nodes,buffers,
+  // variadicBufferCounts} in step; nodes are materialised only for the projected columns and their descendants.
+  struct Cursor {
+    size_t node = 0, buf = 0, variadic = 0;
   };
+  std::function<int32_t(const ArrowField&, Cursor&, bool, int32_t, int32_t, bool)> walk =
+      [&](const ArrowField& f, Cursor& cur, bool keep, int32_t parent, int32_t depth, bool value_only) -> int32_t {
+    if (cur.node >= meta.nodes.size()) throw InternalException("RecordBatch has too few field nodes");
+    const int64_t n = meta.nodes[cur.node].first;
+    const int64_t nulls = meta.nodes[cur.node].second;
+    cur.node++;
+    if (n < 0) throw InternalException("Field node length is negative");
+    const bool dict = f.has_dictionary && !value_only;
+    size_t own;
+    if (dict) {
+      own = 2;
+    } else {
+      switch (f.type) {
+        case MI_AT_NULL: own = 0; break;
+        case MI_AT_STRUCT: case MI_AT_FIXED_LIST: own = 1; break;
+        case MI_AT_UTF8: case MI_AT_BINARY: case MI_AT_LARGE_UTF8: case MI_AT_LARGE_BINARY: own = 3; break;
+        case MI_AT_UTF8_VIEW: case MI_AT_BINARY_VIEW: {
+          if (cur.variadic >= meta.variadic_counts.size()) throw InternalException("RecordBatch has too few variadicBufferCounts");
+          const int64_t vc = meta.variadic_counts[cur.variadic++];
+          if (vc < 0 || vc > (1 << 20)) throw InternalException("Invalid variadic buffer count");
+          own = 2 + static_cast<size_t>(vc);
+          break;
+        }
+        case MI_AT_UNION: own = f.unit == 1 ? 2 : 1; break;  // dense: types + offsets, sparse: types
+        default: own = 2; break;
+      }
+    }
+    if (cur.buf + own > meta.buffers.size()) throw InternalException("RecordBatch has too few buffers");
+    int32_t idx = -1;
+    if (keep) {
+      idx = static_cast<int32_t>(out->nodes.size());
+      out->nodes.emplace_back();
+      DecodedNode nd;
+      nd.field = &f;
+      nd.parent = parent;
+      nd.depth = depth;
+      nd.length = n;
+      nd.null_count = nulls;
+      nd.value_only = value_only;
+      for (size_t k = 0; k < own; k++) {
+        nd.spans.push_back(meta.buffers[cur.buf + k]);
+        check_span(nd.spans.back());
+      }
+      // size checks of ArrowArrayViewValidate (FULL), minus the data-dependent offsets walk (done on the device)
+      int32_t kind, w, nb;
+      int64_t param;
+      if (f.Plan(&kind, &param, &w, &nb, value_only)) {
+        const mi_buffer_span none{0, 0};
+        const mi_buffer_span& s0 = own > 0 ? nd.spans[0] : none;
+        const mi_buffer_span& s1 = own > 1 ? nd.spans[1] : none;
+        if (s0.length != 0 && s0.length < (n + 7) / 8) throw InternalException(BufferSizeError(f.name, 0, (n + 7) / 8, s0.length));
+        if (kind != MI_K_NULL && s0.length == 0 && n > 0 && nulls > 0)
+          throw InternalException("Column " + f.name + " has null_count " + std::to_string(nulls) + " but no validity buffer");
+        int64_t need1 = 0;
+        switch (kind) {
+          case MI_K_COPY: case MI_K_FIXED_BINARY: need1 = n * param; break;
+          case MI_K_BOOL: need1 = (n + 7) / 8; break;
+          case MI_K_DEC128: case MI_K_INTERVAL_MDN: case MI_K_STRVIEW: need1 = n * 16; break;
+          case MI_K_DATE64: case MI_K_MUL_I64: case MI_K_DIV_I64: case MI_K_DURATION: need1 = n * 8; break;
+          case MI_K_MUL_I32: case MI_K_INTERVAL_MONTHS: need1 = n * 4; break;
+          case MI_K_STR32: case MI_K_LIST32: need1 = n > 0 ? (n + 1) * 4 : 0; break;
+          case MI_K_STR64: case MI_K_LIST64: need1 = n > 0 ? (n + 1) * 8 : 0; break;
+          case MI_K_DICT: case MI_K_NARROW: need1 = n * (param & 0xFF); break;
+          case MI_K_HALF_FLOAT: need1 = n * 2; break;
+          default: break;
+        }
+        if (s1.length < need1) throw InternalException(BufferSizeError(f.name, 1, need1, s1.length));
+      }
+      out->nodes[static_cast<size_t>(idx)] = std::move(nd);
+    }
+    cur.buf += own;
+    if (!dict) {
+      for (auto& c : f.children) {
+        const int32_t ci = walk(c, cur, keep, idx, depth + 1, false);
+        if (keep) out->nodes[static_cast<size_t>(idx)].children.push_back(ci);
+      }
+    }
+    return idx;
+  };
+  auto add_column = [&](int32_t top_index, int32_t node_idx) {
+    const DecodedNode& nd = out->nodes[static_cast<size_t>(node_idx)];
+    out->column_field.push_back(top_index);
+    out->column_node.push_back(node_idx);
+    out->null_count.push_back(nd.null_count);
+    out->column_length.push_back(nd.length);
+    for (size_t k = 0; k < 3; k++) out->buffers.push_back(k < nd.spans.size() ? nd.spans[k] : mi_buffer_span{0, 0});
+  };
+  out->nodes.clear();
+  out->column_node.clear();
 
   if (meta.is_dictionary) {
     // one node: the dictionary values of the field(s) that carry this id
@@ -372,32 +420,25 @@ void IPCStreamReader::SliceBatch(const RecordBatchMeta& meta, DecodedBatch* out)
       }
     }
     if (!owner_field) throw IOException("DictionaryBatch refers to unknown dictionary id " + std::to_string(meta.dict_id));
-    emit(*owner_field, top, 0, 0);
+    Cursor cur;
+    add_column(top, walk(*owner_field, cur, true, -1, 0, /*value_only*/ true));
     return;
   }
 
-  // node / buffer cursor per top-level field (depth-first layout of RecordBatch.nodes / .buffers)
-  std::vector<size_t> node_start(base_schema.fields.size()), buf_start(base_schema.fields.size());
-  size_t node_i = 0, buf_i = 0;
-  for (size_t i = 0; i < base_schema.fields.size(); i++) {
-    node_start[i] = node_i;
-    buf_start[i] = buf_i;
-    node_i += static_cast<size_t>(base_schema.fields[i].CountFields());
-    buf_i += static_cast<size_t>(base_schema.fields[i].CountBuffers());
-  }
-  if (node_i != meta.nodes.size()) {
-    throw InternalException("Expected " + std::to_string(node_i) + " field nodes in message but found " +
+  std::vector<int32_t> node_of_field(base_schema.fields.size(), -1);
+  std::vector<char> wanted(base_schema.fields.size(), HasProjection() ? 0 : 1);
+  for (int32_t c : projected_columns) wanted[static_cast<size_t>(c)] = 1;
+  Cursor cur;
+  for (size_t i = 0; i < base_schema.fields.size(); i++)
+    node_of_field[i] = walk(base_schema.fields[i], cur, wanted[i] != 0, -1, 0, false);
+  if (cur.node != meta.nodes.size()) {
+    throw InternalException("Expected " + std::to_string(cur.node) + " field nodes in message but found " +
                             std::to_string(meta.nodes.size()));
   }
-  if (buf_i > meta.buffers.size()) {
-    throw InternalException("Expected " + std::to_string(buf_i) + " buffers in message but found " +
-                            std::to_string(meta.buffers.size()));
-  }
   if (HasProjection()) {
-    for (int32_t c : projected_columns)
-      emit(base_schema.fields[static_cast<size_t>(c)], c, node_start[static_cast<size_t>(c)], buf_start[static_cast<size_t>(c)]);
+    for (int32_t c : projected_columns) add_column(c, node_of_field[static_cast<size_t>(c)]);
   } else {
-    for (size_t i = 0; i < base_schema.fields.size(); i++) emit(base_schema.fields[i], static_cast<int32_t>(i), node_start[i], buf_start[i]);
+    for (size_t i = 0; i < base_schema.fields.size(); i++) add_column(static_cast<int32_t>(i), node_of_field[i]);
   }
 }
 

@@ -33,6 +33,18 @@ struct ArrowIPCBuffer {
   uint64_t size;
 };
 
+//! One field node of a record batch (depth-first), with every buffer it owns.
+struct DecodedNode {
+  const ArrowField* field = nullptr;
+  int32_t parent = -1;
+  int32_t depth = 0;
+  int64_t length = 0;
+  int64_t null_count = 0;
+  bool value_only = false;               // dictionary batch: decode with the value type, not as indices
+  std::vector<mi_buffer_span> spans;     // validity, buffer 1, buffer 2, ... (views: + variadic data buffers)
+  std::vector<int32_t> children;         // indices into DecodedBatch::nodes
+};
+
 //! What GetNextBatch produces: the buffers of every (projected) top-level column of one message.
 struct DecodedBatch {
   int64_t length = 0;
@@ -47,6 +59,8 @@ struct DecodedBatch {
   std::vector<int64_t> null_count;       // per output column
   std::vector<int64_t> column_length;    // per output column (== length for top-level fields)
   std::vector<mi_buffer_span> buffers;   // 3 per output column: validity, buf1, buf2
+  std::vector<DecodedNode> nodes;        // the projected columns with their descendants, depth-first
+  std::vector<int32_t> column_node;      // per output column: its node
   //! Keeps the body alive (file reader: shared ownership like shared_ptr<AllocatedData>, base_stream_reader.cpp:286-294)
   std::shared_ptr<void> owner;
 };

@@ -52,12 +52,6 @@ __device__ __forceinline__ void raise(uint32_t* status, uint32_t bits) {
   if (bits) atomicOr(status, bits);
 }
 
-// Row validity straight from the Arrow bitmap (bit = 1 valid). null_count == 0 => bitmap ignored (GetValidityMask).
-__device__ __forceinline__ bool row_valid(gptr<const uint8_t> bitmap, bool has_nulls, int64_t bit) {
-  if (!has_nulls) return true;
-  return (bitmap[bit >> 3] >> (bit & 7)) & 1;
-}
-
 // Finds the task that owns a tile: largest i with tile_begin[i] <= tile.  The tile index is wave-uniform, so the
 // search runs on the scalar unit (s_load) and the task descriptor lands in SGPRs.
 __device__ __forceinline__ int find_task(const uint32_t* __restrict__ tile_begin, int n_tasks, uint32_t tile) {
@@ -84,8 +78,16 @@ __device__ __forceinline__ int find_task(const uint32_t* __restrict__ tile_begin
 // Validity bitmap -> DuckDB validity_t words for one tile.  Word w of the tile holds rows [64w, 64w+64); the source
 // bit position is row_offset + row0 + 64w, realigned with a 64-bit funnel shift when it is not word aligned (the CPU
 // path's "copy n+1 bytes and shift right by o%8").  One lane per output word.
-__device__ __forceinline__ void tile_validity(const mi_col_task& t, int64_t row0, int n) {
-  if (t.out_validity == nullptr) return;
+// With a parent (out_aux = validity words of the struct / fixed_size_list vector that owns this column) the parent's
+// NULLs propagate into the child (ArrowToDuckDBStruct / ArrowToDuckDBArray).  `s_valid` (LDS, 32 words) receives the
+// combined words so the data lanes canonicalise NULL rows with the same mask; returns whether any row can be NULL.
+__device__ __forceinline__ bool tile_needs_mask(const mi_col_task& t) {
+  return (t.validity != nullptr && t.null_count != 0) || t.out_aux != nullptr;
+}
+
+__device__ __forceinline__ void tile_validity(const mi_col_task& t, int64_t row0, int n, uint64_t* s_valid = nullptr) {
+  const bool need_mask = s_valid != nullptr && tile_needs_mask(t);
+  if (t.out_validity == nullptr && !need_mask) return;
   const int nwords = (n + 63) >> 6;
   for (int lane = threadIdx.x; lane < nwords; lane += kBlockThreads) {
     uint64_t w = ~0ull;
@@ -99,10 +101,33 @@ __device__ __forceinline__ void tile_validity(const mi_col_task& t, int64_t row0
       const uint64_t hi = (sh != 0 && q + 1 <= last_q) ? W[q + 1] : 0ull;
       w = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
     }
+    if (t.out_aux != nullptr) {
+      gptr<const uint64_t> P = GC<uint64_t>(t.out_aux);
+      const int64_t r = row0 + 64 * lane;
+      if (t.flags <= 1) {
+        w &= P[r >> 6];  // same row numbering, same word
+      } else {
+        const int64_t div = t.flags;
+        uint64_t pw = 0;
+        for (int i = 0; i < 64; i++) {
+          const int64_t pr = (r + i) / div;
+          pw |= ((P[pr >> 6] >> (pr & 63)) & 1ull) << i;
+        }
+        w &= pw;
+      }
+    }
     const int rem = n - 64 * lane;
     if (rem < 64) w |= ~0ull << rem;  // canonical pad bits
-    GM<uint64_t>(t.out_validity)[(row0 >> 6) + lane] = w;
+    if (t.out_validity != nullptr) GM<uint64_t>(t.out_validity)[(row0 >> 6) + lane] = w;
+    if (need_mask) s_valid[lane] = w;
   }
+  if (need_mask) __syncthreads();
+}
+
+// Row validity for the data lanes: the combined tile mask in LDS (null_count == 0 and no parent => every row valid,
+// the bitmap is not even read: GetValidityMask).
+__device__ __forceinline__ bool row_valid(const uint64_t* s_valid, bool need_mask, int r) {
+  return !need_mask || ((s_valid[r >> 6] >> (r & 63)) & 1);
 }
 
 // ---------------------------------------------------------------------------------------------------- K3a
@@ -198,11 +223,10 @@ __global__ __launch_bounds__(kBlockThreads) void transcode_copy(const mi_col_tas
 // decimal128 {u64 lower, i64 upper} -> int16/32/64 for valid rows (Hugeint::TryCast: value fits by precision);
 // NULL rows canonical 0.  Each lane reads the whole 16-byte value (the upper half is what proves the range).
 template <typename OUT, int VARIANT>
-__device__ __forceinline__ void tile_dec128(const mi_col_task& t, int64_t row0, int n, uint32_t* status) {
+__device__ __forceinline__ void tile_dec128(const mi_col_task& t, int64_t row0, int n, uint32_t* status, const uint64_t* s_valid) {
   gptr<const uint8_t> src = GC<uint8_t>(t.buf1) + (t.row_offset + row0) * 16;
   gptr<OUT> out = GM<OUT>(t.out_data) + row0;
-  gptr<const uint8_t> bitmap = GC<uint8_t>(t.validity);
-  const bool has_nulls = t.validity != nullptr && t.null_count != 0;
+  const bool has_nulls = tile_needs_mask(t);
   const bool a16 = VARIANT >= 1 || (reinterpret_cast<uintptr_t>(src) & 15) == 0;
   uint32_t err = 0;
 #pragma unroll 4
@@ -219,7 +243,7 @@ __device__ __forceinline__ void tile_dec128(const mi_col_task& t, int64_t row0, 
       upper = static_cast<int64_t>(p[1]);
     }
     OUT o = 0;
-    if (row_valid(bitmap, has_nulls, t.row_offset + row0 + r)) {
+    if (row_valid(s_valid, has_nulls, r)) {
       o = static_cast<OUT>(lower);
       const int64_t sext = static_cast<int64_t>(o);
       if (static_cast<uint64_t>(sext) != lower || upper != (sext >> 63)) err = MI_ST_DECIMAL_RANGE;
@@ -237,10 +261,12 @@ __global__ __launch_bounds__(kBlockThreads) void transcode_dec128(const mi_col_t
                                                                   uint32_t total_tiles, uint32_t* __restrict__ status) {
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     MI_TILE_PROLOGUE_ROWS(kDecTileRows);
-    tile_validity(t, row0, n);
-    if (t.param == 8) tile_dec128<int64_t, VARIANT>(t, row0, n, status);
-    else if (t.param == 4) tile_dec128<int32_t, VARIANT>(t, row0, n, status);
-    else tile_dec128<int16_t, VARIANT>(t, row0, n, status);
+    __shared__ uint64_t s_valid[kDecTileRows / 64];
+    if (tile_needs_mask(t)) __syncthreads();  // the previous tile's lanes are done with the mask
+    tile_validity(t, row0, n, s_valid);
+    if (t.param == 8) tile_dec128<int64_t, VARIANT>(t, row0, n, status, s_valid);
+    else if (t.param == 4) tile_dec128<int32_t, VARIANT>(t, row0, n, status, s_valid);
+    else tile_dec128<int16_t, VARIANT>(t, row0, n, status, s_valid);
   }
 }
 
@@ -280,12 +306,11 @@ __device__ __forceinline__ u32x4 make_string_t(gptr<const uint8_t> data, int64_t
 // utf8 / binary with int32 or int64 offsets.  Lane r reads off[r], off[r+1] (coalesced; the second read hits L1),
 // validates them like NANOARROW_VALIDATION_LEVEL_FULL, and stores one 16-byte string_t (1 KiB per wave store).
 template <typename OFF>
-__device__ __forceinline__ void tile_string(const mi_col_task& t, int64_t row0, int n, uint32_t* status) {
+__device__ __forceinline__ void tile_string(const mi_col_task& t, int64_t row0, int n, uint32_t* status, const uint64_t* s_valid) {
   gptr<const OFF> off = GC<OFF>(t.buf1) + t.row_offset + row0;
   gptr<const uint8_t> data = GC<uint8_t>(t.buf2);
   gptr<u32x4> out = GM<u32x4>(t.out_data) + row0;
-  gptr<const uint8_t> bitmap = GC<uint8_t>(t.validity);
-  const bool has_nulls = t.validity != nullptr && t.null_count != 0;
+  const bool has_nulls = tile_needs_mask(t);
   const int64_t data_len = t.buf2_len;
   uint32_t err = 0;
 #pragma unroll 2
@@ -298,7 +323,7 @@ __device__ __forceinline__ void tile_string(const mi_col_task& t, int64_t row0, 
       err |= MI_ST_BAD_OFFSETS;
     } else if (sizeof(OFF) == 8 && b > 0xFFFFFFFFll) {
       err |= MI_ST_STRING_TOO_LARGE;  // "DuckDB does not support Strings over 4GB"
-    } else if (row_valid(bitmap, has_nulls, t.row_offset + row0 + r)) {
+    } else if (row_valid(s_valid, has_nulls, r)) {
       s = make_string_t(data, a, static_cast<uint32_t>(b - a), t.ptr_base);
     }
     out[r] = s;
@@ -310,13 +335,12 @@ __device__ __forceinline__ void tile_string(const mi_col_task& t, int64_t row0, 
 // (8 independent offset loads, then up to 8 x 4 payload dwords), so one wave has 8 rows in flight instead of 2.
 // off[r+1] comes from the neighbouring lane (one DPP/permute) except at the wave edge and at the last row.
 template <typename OFF, int NT>
-__device__ __forceinline__ void tile_string_deep(const mi_col_task& t, int64_t row0, int n, uint32_t* status) {
+__device__ __forceinline__ void tile_string_deep(const mi_col_task& t, int64_t row0, int n, uint32_t* status, const uint64_t* s_valid) {
   constexpr int R = kTileRows / kBlockThreads;
   gptr<const OFF> off = GC<OFF>(t.buf1) + t.row_offset + row0;
   gptr<const uint8_t> data = GC<uint8_t>(t.buf2);
   gptr<u32x4> out = GM<u32x4>(t.out_data) + row0;
-  gptr<const uint8_t> bitmap = GC<uint8_t>(t.validity);
-  const bool has_nulls = t.validity != nullptr && t.null_count != 0;
+  const bool has_nulls = tile_needs_mask(t);
   const int64_t data_len = t.buf2_len;
   const int lane = threadIdx.x & 63;
   OFF a[R], b[R];
@@ -345,7 +369,7 @@ __device__ __forceinline__ void tile_string_deep(const mi_col_task& t, int64_t r
         err |= MI_ST_BAD_OFFSETS;
       } else if (sizeof(OFF) == 8 && bb > 0xFFFFFFFFll) {
         err |= MI_ST_STRING_TOO_LARGE;
-      } else if (row_valid(bitmap, has_nulls, t.row_offset + row0 + r)) {
+      } else if (row_valid(s_valid, has_nulls, r)) {
         s[k] = make_string_t(data, aa, static_cast<uint32_t>(bb - aa), t.ptr_base);
       }
     }
@@ -362,16 +386,15 @@ __device__ __forceinline__ void tile_string_deep(const mi_col_task& t, int64_t r
 }
 
 // fixed_size_binary(width) -> string_t
-__device__ __forceinline__ void tile_fixed_binary(const mi_col_task& t, int64_t row0, int n) {
+__device__ __forceinline__ void tile_fixed_binary(const mi_col_task& t, int64_t row0, int n, const uint64_t* s_valid) {
   gptr<const uint8_t> data = GC<uint8_t>(t.buf1);
   gptr<u32x4> out = GM<u32x4>(t.out_data) + row0;
-  gptr<const uint8_t> bitmap = GC<uint8_t>(t.validity);
-  const bool has_nulls = t.validity != nullptr && t.null_count != 0;
+  const bool has_nulls = tile_needs_mask(t);
   const int64_t width = t.param;
 #pragma unroll 2
   for (int r = threadIdx.x; r < n; r += kBlockThreads) {
     u32x4 s = {0u, 0u, 0u, 0u};
-    if (row_valid(bitmap, has_nulls, t.row_offset + row0 + r))
+    if (row_valid(s_valid, has_nulls, r))
       s = make_string_t(data, (t.row_offset + row0 + r) * width, static_cast<uint32_t>(width), t.ptr_base);
     out[r] = s;
   }
@@ -384,15 +407,17 @@ __global__ __launch_bounds__(kBlockThreads) void transcode_string(const mi_col_t
                                                                   uint32_t total_tiles, uint32_t* __restrict__ status) {
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     MI_TILE_PROLOGUE();
-    tile_validity(t, row0, n);
+    __shared__ uint64_t s_valid[kTileRows / 64];
+    if (tile_needs_mask(t)) __syncthreads();
+    tile_validity(t, row0, n, s_valid);
     if (VARIANT >= 1) {
-      if (t.kind == MI_K_STR32) tile_string_deep<int32_t, VARIANT - 1>(t, row0, n, status);
-      else if (t.kind == MI_K_STR64) tile_string_deep<int64_t, VARIANT - 1>(t, row0, n, status);
-      else tile_fixed_binary(t, row0, n);
+      if (t.kind == MI_K_STR32) tile_string_deep<int32_t, VARIANT - 1>(t, row0, n, status, s_valid);
+      else if (t.kind == MI_K_STR64) tile_string_deep<int64_t, VARIANT - 1>(t, row0, n, status, s_valid);
+      else tile_fixed_binary(t, row0, n, s_valid);
     } else {
-      if (t.kind == MI_K_STR32) tile_string<int32_t>(t, row0, n, status);
-      else if (t.kind == MI_K_STR64) tile_string<int64_t>(t, row0, n, status);
-      else tile_fixed_binary(t, row0, n);
+      if (t.kind == MI_K_STR32) tile_string<int32_t>(t, row0, n, status, s_valid);
+      else if (t.kind == MI_K_STR64) tile_string<int64_t>(t, row0, n, status, s_valid);
+      else tile_fixed_binary(t, row0, n, s_valid);
     }
   }
 }
@@ -429,28 +454,26 @@ __device__ __forceinline__ void tile_date64(const mi_col_task& t, int64_t row0, 
   for (int r = threadIdx.x; r < n; r += kBlockThreads) out[r] = static_cast<int32_t>(src[r] / 86400000ll);
 }
 
-__device__ __forceinline__ void tile_mul_i32(const mi_col_task& t, int64_t row0, int n) {
+__device__ __forceinline__ void tile_mul_i32(const mi_col_task& t, int64_t row0, int n, const uint64_t* s_valid) {
   gptr<const int32_t> src = GC<int32_t>(t.buf1) + t.row_offset + row0;
   gptr<int64_t> out = GM<int64_t>(t.out_data) + row0;
-  gptr<const uint8_t> bitmap = GC<uint8_t>(t.validity);
-  const bool has_nulls = t.validity != nullptr && t.null_count != 0;
+  const bool has_nulls = tile_needs_mask(t);
 #pragma unroll 4
   for (int r = threadIdx.x; r < n; r += kBlockThreads) {
-    const bool ok = row_valid(bitmap, has_nulls, t.row_offset + row0 + r);
+    const bool ok = row_valid(s_valid, has_nulls, r);
     out[r] = ok ? static_cast<int64_t>(src[r]) * t.param : 0;  // int32 * 1e6 cannot overflow int64
   }
 }
 
-__device__ __forceinline__ void tile_mul_i64(const mi_col_task& t, int64_t row0, int n, uint32_t* status) {
+__device__ __forceinline__ void tile_mul_i64(const mi_col_task& t, int64_t row0, int n, uint32_t* status, const uint64_t* s_valid) {
   gptr<const int64_t> src = GC<int64_t>(t.buf1) + t.row_offset + row0;
   gptr<int64_t> out = GM<int64_t>(t.out_data) + row0;
-  gptr<const uint8_t> bitmap = GC<uint8_t>(t.validity);
-  const bool has_nulls = t.validity != nullptr && t.null_count != 0;
+  const bool has_nulls = tile_needs_mask(t);
   uint32_t err = 0;
 #pragma unroll 4
   for (int r = threadIdx.x; r < n; r += kBlockThreads) {
     int64_t v = 0;
-    if (row_valid(bitmap, has_nulls, t.row_offset + row0 + r)) {
+    if (row_valid(s_valid, has_nulls, r)) {
       if (__builtin_mul_overflow(src[r], t.param, &v)) {  // TryMultiplyOperator => ConversionException
         v = 0;
         err = MI_ST_MUL_OVERFLOW;
@@ -469,18 +492,17 @@ __device__ __forceinline__ void tile_div_i64(const mi_col_task& t, int64_t row0,
   for (int r = threadIdx.x; r < n; r += kBlockThreads) out[r] = src[r] / d;  // all rows, like upstream
 }
 
-__device__ __forceinline__ void tile_duration(const mi_col_task& t, int64_t row0, int n, uint32_t* status) {
+__device__ __forceinline__ void tile_duration(const mi_col_task& t, int64_t row0, int n, uint32_t* status, const uint64_t* s_valid) {
   gptr<const int64_t> src = GC<int64_t>(t.buf1) + t.row_offset + row0;
   gptr<u32x4> out = GM<u32x4>(t.out_data) + row0;
-  gptr<const uint8_t> bitmap = GC<uint8_t>(t.validity);
-  const bool has_nulls = t.validity != nullptr && t.null_count != 0;
+  const bool has_nulls = tile_needs_mask(t);
   uint32_t err = 0;
 #pragma unroll 4
   for (int r = threadIdx.x; r < n; r += kBlockThreads) {
     int64_t micros = 0;
     if (t.param < 0) {
       micros = src[r] / (-t.param);
-    } else if (row_valid(bitmap, has_nulls, t.row_offset + row0 + r)) {
+    } else if (row_valid(s_valid, has_nulls, r)) {
       if (__builtin_mul_overflow(src[r], t.param, &micros)) {
         micros = 0;
         err = MI_ST_MUL_OVERFLOW;
@@ -517,16 +539,15 @@ __device__ __forceinline__ void tile_interval_mdn(const mi_col_task& t, int64_t 
 
 // decimal32 / decimal64 -> the physical type of the declared precision, valid rows only (NULL -> 0)
 template <typename SRC, typename DST>
-__device__ __forceinline__ void tile_narrow(const mi_col_task& t, int64_t row0, int n, uint32_t* status) {
+__device__ __forceinline__ void tile_narrow(const mi_col_task& t, int64_t row0, int n, uint32_t* status, const uint64_t* s_valid) {
   gptr<const SRC> src = GC<SRC>(t.buf1) + t.row_offset + row0;
   gptr<DST> out = GM<DST>(t.out_data) + row0;
-  gptr<const uint8_t> bitmap = GC<uint8_t>(t.validity);
-  const bool has_nulls = t.validity != nullptr && t.null_count != 0;
+  const bool has_nulls = tile_needs_mask(t);
   uint32_t err = 0;
 #pragma unroll 4
   for (int r = threadIdx.x; r < n; r += kBlockThreads) {
     DST o = 0;
-    if (row_valid(bitmap, has_nulls, t.row_offset + row0 + r)) {
+    if (row_valid(s_valid, has_nulls, r)) {
       const SRC v = src[r];
       o = static_cast<DST>(v);
       if (static_cast<SRC>(o) != v) err = MI_ST_DECIMAL_RANGE;
@@ -572,21 +593,91 @@ __device__ __forceinline__ void tile_null(const mi_col_task& t, int64_t row0, in
   }
 }
 
+// ---------------------------------------------------------------------------------------------------- nested
+// list / large_list / map offsets -> list_entry_t{u64 offset, u64 length} (ConvertArrowListOffsets): the offset is
+// relative to the first element of the row's top-level 2048-row window, because the child vector a chunk carries starts
+// there.  For a top-level list the window is this tile; for a list nested inside lists buf2 holds the window starts in
+// this list's own row space (computed on the host from the outer offsets).  Offsets are validated like FULL.
+template <typename OFF>
+__device__ __forceinline__ void tile_list(const mi_col_task& t, int64_t row0, int n, uint32_t* status) {
+  gptr<const OFF> off = GC<OFF>(t.buf1) + t.row_offset;
+  gptr<u32x4> out = GM<u32x4>(t.out_data) + row0;
+  gptr<const int64_t> wins = GC<int64_t>(t.buf2);
+  const int nwin = static_cast<int>(t.buf2_len);
+  const int64_t child_len = t.param;
+  uint32_t err = 0;
+#pragma unroll 2
+  for (int r = threadIdx.x; r < n; r += kBlockThreads) {
+    const int64_t row = row0 + r;
+    int64_t win_row = row0;  // top-level list: the tile is the window
+    if (t.buf2 != nullptr) {
+      int lo = 0, hi = nwin;  // largest k with wins[k] <= row
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (wins[mid] <= row) lo = mid; else hi = mid;
+      }
+      win_row = wins[lo];
+    }
+    const int64_t a = static_cast<int64_t>(off[row]), b = static_cast<int64_t>(off[row + 1]);
+    const int64_t base = static_cast<int64_t>(off[win_row]);
+    if (a < 0 || b < a || b > child_len || a < base) err = MI_ST_BAD_OFFSETS;
+    const uint64_t o = static_cast<uint64_t>(a - base), l = static_cast<uint64_t>(b - a);
+    out[r] = u32x4{static_cast<uint32_t>(o), static_cast<uint32_t>(o >> 32), static_cast<uint32_t>(l), static_cast<uint32_t>(l >> 32)};
+  }
+  raise(status, err);
+}
+
+// utf8_view / binary_view -> string_t.  Inline views (len <= 12) are already string_t shaped (the pad bytes are
+// re-zeroed like the string_t constructor does); long views {len, prefix, buffer_index, offset} get the pointer
+// bases[buffer_index] + offset from the per-task table of variadic data buffers.
+__device__ __forceinline__ void tile_strview(const mi_col_task& t, int64_t row0, int n, uint32_t* status, const uint64_t* s_valid) {
+  gptr<const u32x4_a4> src = (gptr<const u32x4_a4>)(GC<uint8_t>(t.buf1) + (t.row_offset + row0) * 16);
+  gptr<u32x4> out = GM<u32x4>(t.out_data) + row0;
+  gptr<const uint64_t> table = GC<uint64_t>(t.buf2);  // {address, length} pairs
+  const int64_t nbuf = t.buf2_len;
+  const bool has_nulls = tile_needs_mask(t);
+  uint32_t err = 0;
+#pragma unroll 2
+  for (int r = threadIdx.x; r < n; r += kBlockThreads) {
+    u32x4 s = {0u, 0u, 0u, 0u};
+    if (row_valid(s_valid, has_nulls, r)) {
+      const u32x4 v = src[r];
+      const uint32_t len = v.x;
+      if (len <= 12) {
+        const uint32_t k0 = len >= 4 ? 4 : len, k1 = len >= 8 ? 4 : (len > 4 ? len - 4 : 0), k2 = len > 8 ? len - 8 : 0;
+        s.x = len;
+        s.y = k0 == 4 ? v.y : (v.y & ((1u << (8 * k0)) - 1u));
+        s.z = k1 == 4 ? v.z : (v.z & ((1u << (8 * k1)) - 1u));
+        s.w = k2 == 4 ? v.w : (v.w & ((1u << (8 * k2)) - 1u));
+      } else {
+        const int64_t bi = static_cast<int32_t>(v.z), bo = static_cast<int32_t>(v.w);
+        if (bi < 0 || bi >= nbuf || bo < 0 || static_cast<uint64_t>(bo) + len > table[2 * bi + 1]) {
+          err = MI_ST_BAD_OFFSETS;
+        } else {
+          const uint64_t p = table[2 * bi] + static_cast<uint64_t>(bo);
+          s = u32x4{len, v.y, static_cast<uint32_t>(p), static_cast<uint32_t>(p >> 32)};
+        }
+      }
+    }
+    out[r] = s;
+  }
+  raise(status, err);
+}
+
 // ---------------------------------------------------------------------------------------------------- K5
 // Dictionary indices -> sel_t; NULL -> dict_len (the extra NULL slot of the decoded dictionary).
-__device__ __forceinline__ void tile_dict(const mi_col_task& t, int64_t row0, int n, uint32_t* status) {
+__device__ __forceinline__ void tile_dict(const mi_col_task& t, int64_t row0, int n, uint32_t* status, const uint64_t* s_valid) {
   const int iw = static_cast<int>(t.param & 0xFF);
   const bool is_signed = ((t.param >> 8) & 1) != 0;
   gptr<const uint8_t> idx = GC<uint8_t>(t.buf1) + (t.row_offset + row0) * iw;
   gptr<uint32_t> out = GM<uint32_t>(t.out_data) + row0;
-  gptr<const uint8_t> bitmap = GC<uint8_t>(t.validity);
-  const bool has_nulls = t.validity != nullptr && t.null_count != 0;
+  const bool has_nulls = tile_needs_mask(t);
   const uint32_t dict_len = static_cast<uint32_t>(t.param2);
   uint32_t err = 0;
 #pragma unroll 4
   for (int r = threadIdx.x; r < n; r += kBlockThreads) {
     uint32_t sel = dict_len;
-    if (row_valid(bitmap, has_nulls, t.row_offset + row0 + r)) {
+    if (row_valid(s_valid, has_nulls, r)) {
       uint64_t v;
       switch (iw) {
         case 1: v = is_signed ? static_cast<uint64_t>(static_cast<int64_t>(((gptr<const int8_t>)idx)[r])) : idx[r]; break;
@@ -613,26 +704,32 @@ __global__ __launch_bounds__(kBlockThreads) void transcode_misc(const mi_col_tas
                                                                 uint32_t total_tiles, uint32_t* __restrict__ status) {
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     MI_TILE_PROLOGUE();
-    if (t.kind != MI_K_NULL) tile_validity(t, row0, n);
+    __shared__ uint64_t s_valid[kTileRows / 64];
+    if (tile_needs_mask(t)) __syncthreads();
+    if (t.kind != MI_K_NULL) tile_validity(t, row0, n, s_valid);
     switch (t.kind) {
       case MI_K_NULL: tile_null(t, row0, n); break;
+      case MI_K_STRUCT: break;  // validity only
+      case MI_K_LIST32: tile_list<int32_t>(t, row0, n, status); break;
+      case MI_K_LIST64: tile_list<int64_t>(t, row0, n, status); break;
+      case MI_K_STRVIEW: tile_strview(t, row0, n, status, s_valid); break;
       case MI_K_INTERVAL_MONTHS: tile_interval_months(t, row0, n); break;
       case MI_K_INTERVAL_MDN: tile_interval_mdn(t, row0, n); break;
       case MI_K_HALF_FLOAT: tile_half_float(t, row0, n); break;
       case MI_K_NARROW: {
         const int sw = static_cast<int>(t.param & 0xFF), dw = static_cast<int>((t.param >> 8) & 0xFF);
-        if (sw == 4) tile_narrow<int32_t, int16_t>(t, row0, n, status);
-        else if (dw == 2) tile_narrow<int64_t, int16_t>(t, row0, n, status);
-        else tile_narrow<int64_t, int32_t>(t, row0, n, status);
+        if (sw == 4) tile_narrow<int32_t, int16_t>(t, row0, n, status, s_valid);
+        else if (dw == 2) tile_narrow<int64_t, int16_t>(t, row0, n, status, s_valid);
+        else tile_narrow<int64_t, int32_t>(t, row0, n, status, s_valid);
         break;
       }
       case MI_K_BOOL: tile_bool(t, row0, n); break;
       case MI_K_DATE64: tile_date64(t, row0, n); break;
-      case MI_K_MUL_I32: tile_mul_i32(t, row0, n); break;
-      case MI_K_MUL_I64: tile_mul_i64(t, row0, n, status); break;
+      case MI_K_MUL_I32: tile_mul_i32(t, row0, n, s_valid); break;
+      case MI_K_MUL_I64: tile_mul_i64(t, row0, n, status, s_valid); break;
       case MI_K_DIV_I64: tile_div_i64(t, row0, n); break;
-      case MI_K_DURATION: tile_duration(t, row0, n, status); break;
-      case MI_K_DICT: tile_dict(t, row0, n, status); break;
+      case MI_K_DURATION: tile_duration(t, row0, n, status, s_valid); break;
+      case MI_K_DICT: tile_dict(t, row0, n, status, s_valid); break;
       default: break;
     }
   }
@@ -951,7 +1048,7 @@ int ClassOfKind(int32_t kind) {
     case MI_K_STR32: case MI_K_STR64: case MI_K_FIXED_BINARY: return kClassString;
     case MI_K_BOOL: case MI_K_DATE64: case MI_K_MUL_I32: case MI_K_MUL_I64: case MI_K_DIV_I64: case MI_K_DURATION:
     case MI_K_DICT: case MI_K_INTERVAL_MONTHS: case MI_K_INTERVAL_MDN: case MI_K_NARROW: case MI_K_HALF_FLOAT:
-    case MI_K_NULL: return kClassMisc;
+    case MI_K_NULL: case MI_K_STRVIEW: case MI_K_LIST32: case MI_K_LIST64: case MI_K_STRUCT: return kClassMisc;
     case MI_K_ENC_COPY: case MI_K_ENC_DEC128: case MI_K_ENC_BOOL: return kClassEncFixed;
     case MI_K_ENC_STR32: return kClassEncString;
     default: return -1;

@@ -1,20 +1,24 @@
 """HBM-resident decode of a whole Arrow IPC stream through the kernel-level C ABI (mi_plan_*).
 
 torch is plumbing only (device memory + the stream handle): the stream's bytes are uploaded once, the host
-reader (mi_reader_*) slices every record batch into buffers, ONE plan holds a task per (record batch, column)
+reader (mi_reader_*) slices every record batch into buffers, ONE plan holds a task per (record batch, field node)
 and a launch is a handful of kernels regardless of the number of batches.  This is what bench.py times and what
 the GPU parity tests compare against the CPU checker.
 """
-import ctypes as C
-
 import numpy as np
 
 from . import _ffi
 from . import Reader, Plan, make_task
 
+VECTOR_SIZE = 2048
+
 
 def _round_up(v, a=256):
     return (v + a - 1) // a * a
+
+
+def _windows(n):
+    return (list(range(0, n, VECTOR_SIZE)) + [n]) if n else [0, 0]
 
 
 class HbmStream:
@@ -30,11 +34,7 @@ class HbmStream:
         self.fields = rd.schema()
         if columns is not None:
             rd.set_projection(list(columns))
-            by_name = {f["name"]: f for f in self.fields}
-            self.out_fields = [by_name[c] for c in columns]
-        else:
-            self.out_fields = self.fields
-        # host parse: every message -> per-column buffer spans (absolute positions inside the stream)
+        # host parse: every message -> field nodes with their buffer spans (positions relative to the message body)
         self.batches, self.dict_batches = [], {}
         while True:
             b = rd.next_batch(accept_dictionaries=accept_dictionaries)
@@ -42,61 +42,113 @@ class HbmStream:
                 break
             (self.dict_batches.__setitem__(b["dict_id"], b) if b["is_dictionary"] else self.batches.append(b))
         rd.close()
-        # HBM: the stream itself (8-byte slack so the last buffer's padding is addressable) + the output arena
+        # HBM: the stream itself (slack so the last buffer's padding is addressable) + the output arena + small tables
         self.d_in = torch.empty(_round_up(host.size + 64), dtype=torch.uint8, device=device)
         self.d_in[: host.size].copy_(torch.from_numpy(host), non_blocking=False)
-        base = self.d_in.data_ptr()
-        layout, off = [], 0
-        tasks = []
-        by_top = {i: f for i, f in enumerate(self.fields)}
-
-        def add_task(b, ci, field, kind, param, width, nrows, out_rows, param2=0):
-            nonlocal off
-            data_off = off
-            off += _round_up(out_rows * width + 16)
-            valid_off = off
-            off += _round_up(((out_rows + 63) // 64) * 8 + 8)
-            sp = b["buffers"][3 * ci: 3 * ci + 3]
-            body = b["body_file_offset"]
-            nbuf = 3 if kind in (_ffi.K_STR32, _ffi.K_STR64) else 2
-            data_span = sp[2] if nbuf == 3 else sp[1]
-            entry = dict(name=field["name"], kind=kind, param=param, width=width, nrows=nrows, data_off=data_off,
-                         valid_off=valid_off, null_count=b["null_count"][ci], ptr_base=body + data_span[0],
-                         buffers=sp, body_off=body)
-            if nrows > 0:
-                tasks.append((entry, dict(kind=kind, nrows=nrows, buf1=base + body + sp[1][0],
-                                          validity=(base + body + sp[0][0]) if sp[0][1] else 0,
-                                          buf2=(base + body + sp[2][0]) if nbuf == 3 else 0,
-                                          buf2_len=sp[2][1] if nbuf == 3 else 0, ptr_base=body + data_span[0],
-                                          param=param, param2=param2, null_count=b["null_count"][ci])))
-            return entry
-
+        self._off = 0
+        self._aux = []        # (offset, int64/uint64 ndarray): list window tables, string-view buffer tables
+        self._aux_bytes = 0
+        self._tasks = []      # (entry, kwargs with symbolic aux / out references)
         self.dict_layout = {}
         for did, b in self.dict_batches.items():
-            f = by_top[b["column_field"][0]]
-            vkind, vparam, vwidth = _value_plan(f)
-            n = _dict_rows(b, vkind, vparam)
-            self.dict_layout[did] = add_task(b, 0, f, vkind, vparam, vwidth, n, n + 1)
+            self.dict_layout[did] = self._add_node(b, b["column_node"][0], _windows(b["length"]), True, extra_rows=1)
+        self.layout = []
         for b in self.batches:
-            cols = []
-            for ci, top in enumerate(b["column_field"]):
-                f = by_top[top]
-                param2 = self.dict_layout[f["dict_id"]]["nrows"] if f["kind"] == _ffi.K_DICT else 0
-                cols.append(add_task(b, ci, f, f["kind"], f["param"], f["out_width"], b["length"], b["length"], param2))
-            layout.append(dict(nrows=b["length"], columns=cols, body_off=b["body_file_offset"], body_len=b["body_size"]))
-        self.layout = layout
-        self.out_bytes = off
-        self.d_out = torch.zeros(max(off, 256), dtype=torch.uint8, device=device)
-        obase = self.d_out.data_ptr()
+            cols = [self._add_node(b, ni, _windows(b["length"]), True) for ni in b["column_node"]]
+            self.layout.append(dict(nrows=b["length"], columns=cols, body_off=b["body_file_offset"], body_len=b["body_size"]))
+        self.out_bytes = self._off
+        self.d_out = torch.zeros(max(self._off, 256), dtype=torch.uint8, device=device)
+        aux = np.zeros(max(self._aux_bytes // 8, 1), np.uint64)
+        for off, arr in self._aux:
+            aux[off // 8: off // 8 + arr.size] = arr.view(np.uint64)
+        self.d_aux = torch.from_numpy(aux.view(np.uint8).copy()).to(device)
+        ibase, obase, abase = self.d_in.data_ptr(), self.d_out.data_ptr(), self.d_aux.data_ptr()
         ctasks = []
-        for entry, t in tasks:
-            ctasks.append(make_task(t["kind"], t["nrows"], t["buf1"], obase + entry["data_off"], validity=t["validity"],
-                                    buf2=t["buf2"], out_validity=(obase + entry["valid_off"]) if with_validity_out else 0,
-                                    ptr_base=t["ptr_base"], buf2_len=t["buf2_len"], param=t["param"], param2=t["param2"],
-                                    null_count=t["null_count"]))
+        for e, t in self._tasks:
+            ctasks.append(make_task(
+                t["kind"], t["nrows"], ibase + t["buf1"] if t["buf1"] is not None else 0, obase + e["data_off"],
+                validity=(ibase + t["validity"]) if t["validity"] is not None else 0,
+                buf2=(ibase + t["buf2"]) if t.get("buf2") is not None else ((abase + t["aux"]) if t.get("aux") is not None else 0),
+                out_validity=(obase + e["valid_off"]) if (with_validity_out or t["kind"] == _ffi.K_STRUCT) else 0,
+                out_aux=(obase + t["parent_valid_off"]) if t.get("parent_valid_off") is not None else 0,
+                ptr_base=t.get("ptr_base", 0), buf2_len=t.get("buf2_len", 0), param=t.get("param", 0), param2=t.get("param2", 0),
+                null_count=t["null_count"], depth=t["depth"], parent_div=t.get("parent_div", 0)))
         self.plan = Plan(ctx, ctasks)
         self.n_rows = sum(b["length"] for b in self.batches)
 
+    # ------------------------------------------------------------------------------------------------ layout
+    def _alloc(self, rows, width):
+        data_off = self._off
+        self._off += _round_up(rows * width + 16)
+        valid_off = self._off
+        self._off += _round_up(((rows + 63) // 64) * 8 + 8)
+        return data_off, valid_off
+
+    def _aux_table(self, arr):
+        off = self._aux_bytes
+        self._aux.append((off, np.ascontiguousarray(arr)))
+        self._aux_bytes += _round_up(arr.size * 8, 64)
+        return off
+
+    def _add_node(self, b, ni, win, win_is_tiles, parent_valid_off=None, parent_div=0, extra_rows=0):
+        nodes = b["nodes"]
+        nd = nodes[ni]
+        kind, width, n, body = nd["kind"], nd["out_width"], nd["length"], b["body_file_offset"]
+        if kind == 0:
+            raise NotImplementedError("field %r (arrow type %d) is not decoded by the path" % (nd["name"], nd["arrow_type"]))
+        sp = nd["spans"]
+        data_off, valid_off = self._alloc(n + extra_rows, max(width, 1))
+        children = [i for i in range(ni + 1, len(nodes)) if nodes[i]["parent"] == ni]
+        pos = lambda s: body + s[0]
+        entry = dict(name=nd["name"], kind=kind, param=nd["param"], width=width, nrows=n, data_off=data_off, valid_off=valid_off,
+                     null_count=nd["null_count"], buffers=sp, body_off=body, win=list(win), children=[], arrow_type=nd["arrow_type"],
+                     ptr_base=0)
+        t = dict(kind=kind, nrows=n, param=nd["param"], null_count=nd["null_count"], depth=nd["depth"],
+                 validity=pos(sp[0]) if (len(sp) > 0 and sp[0][1]) else None, buf1=pos(sp[1]) if len(sp) > 1 else None)
+        if parent_valid_off is not None:
+            t["parent_valid_off"], t["parent_div"] = parent_valid_off, parent_div
+        if kind in (_ffi.K_STR32, _ffi.K_STR64):
+            t.update(buf2=pos(sp[2]), buf2_len=sp[2][1], ptr_base=pos(sp[2]))
+            entry["ptr_base"] = pos(sp[2])
+        elif kind == _ffi.K_FIXED_BINARY:
+            t.update(ptr_base=pos(sp[1]))
+            entry["ptr_base"] = pos(sp[1])
+        elif kind == _ffi.K_STRVIEW:
+            table = np.zeros(max(2 * (len(sp) - 2), 2), np.uint64)
+            for j, s in enumerate(sp[2:]):
+                table[2 * j], table[2 * j + 1] = pos(s), s[1]   # addresses = positions inside the stream (heap = stream)
+            t.update(aux=self._aux_table(table), buf2_len=len(sp) - 2)
+        elif kind == _ffi.K_DICT:
+            t["param2"] = self.dict_layout[self._dict_id_of(nd["name"])]["nrows"]
+            entry["dict_id"] = self._dict_id_of(nd["name"])
+        elif kind in (_ffi.K_LIST32, _ffi.K_LIST64):
+            offw = 4 if kind == _ffi.K_LIST32 else 8
+            offs = self.host[pos(sp[1]): pos(sp[1]) + (n + 1) * offw].view(np.int32 if offw == 4 else np.int64) if n else np.zeros(1, np.int64)
+            t["param"] = nodes[children[0]]["length"]
+            if not win_is_tiles:
+                t.update(aux=self._aux_table(np.array(win, np.int64)), buf2_len=len(win))
+            child_win = [int(offs[r]) for r in win] if n else [0] * len(win)
+        if n > 0 or kind == _ffi.K_STRUCT:
+            if n > 0:
+                self._tasks.append((entry, t))
+        if kind in (_ffi.K_LIST32, _ffi.K_LIST64):
+            entry["children"].append(self._add_node(b, children[0], child_win, False))
+        elif kind == _ffi.K_STRUCT:
+            is_fixed_list = nd["arrow_type"] == 16
+            size = int(nd["param"]) if is_fixed_list else 1
+            cwin = [r * size for r in win] if is_fixed_list else list(win)
+            for c in children:
+                entry["children"].append(self._add_node(b, c, cwin, win_is_tiles and not is_fixed_list, parent_valid_off=valid_off,
+                                                        parent_div=size if is_fixed_list else 1))
+        return entry
+
+    def _dict_id_of(self, name):
+        for f in self.fields:
+            if f["name"] == name and f["has_dictionary"]:
+                return f["dict_id"]
+        raise KeyError(name)
+
+    # ------------------------------------------------------------------------------------------------ run
     def launch(self, stream=None):
         s = self.torch.cuda.current_stream().cuda_stream if stream is None else stream
         self.plan.launch(s)
@@ -108,55 +160,21 @@ class HbmStream:
         return self.plan.stats()
 
     def fetch(self):
-        """D2H of the output arena -> per record batch, per column: data bytes + validity words (numpy)."""
+        """D2H of the output arena -> per record batch, per column a node: data bytes + validity words (numpy) + children."""
         self.torch.cuda.synchronize()
         out = self.d_out[: max(self.out_bytes, 1)].cpu().numpy()
-        dicts = {}
-        for did, e in self.dict_layout.items():
+
+        def node(e, dict_extra=0):
             n = e["nrows"]
-            d = out[e["data_off"]: e["data_off"] + (n + 1) * e["width"]].copy()
-            v = out[e["valid_off"]: e["valid_off"] + ((n + 1 + 63) // 64) * 8].copy().view(np.uint64)
-            dicts[did] = dict(kind=e["kind"], param=e["param"], width=e["width"], data=d[: n * e["width"]],
-                              validity=v[: max((n + 63) // 64, 0)], nrows=n, ptr_base=e["ptr_base"])
-        batches = []
-        by_name = {f["name"]: f for f in self.fields}
-        for b in self.layout:
-            cols = []
-            for e in b["columns"]:
-                n = e["nrows"]
-                d = out[e["data_off"]: e["data_off"] + n * e["width"]].copy()
-                v = out[e["valid_off"]: e["valid_off"] + ((n + 63) // 64) * 8].copy().view(np.uint64)
-                f = by_name[e["name"]]
-                cols.append(dict(name=e["name"], kind=e["kind"], param=e["param"], width=e["width"], data=d, validity=v,
-                                 rc=0, buffers=e["buffers"], ptr_base=e["ptr_base"], null_count=e["null_count"],
-                                 dictionary=dicts.get(f["dict_id"]) if e["kind"] == _ffi.K_DICT else None))
-            batches.append(dict(nrows=b["nrows"], columns=cols, body_off=b["body_off"], body_len=b["body_len"]))
-        return batches
+            d = out[e["data_off"]: e["data_off"] + n * e["width"]].copy()
+            v = out[e["valid_off"]: e["valid_off"] + ((n + 63) // 64) * 8].copy().view(np.uint64)
+            r = dict(name=e["name"], kind=e["kind"], param=e["param"], width=e["width"], data=d, validity=v, rc=0, nrows=n,
+                     buffers=e["buffers"], ptr_base=e["ptr_base"], null_count=e["null_count"], win=e["win"],
+                     children=[node(c) for c in e["children"]])
+            if e["kind"] == _ffi.K_DICT:
+                r["dictionary"] = dicts[e["dict_id"]]
+            return r
 
-
-def _value_plan(f):
-    """(kind, param, width) of a dictionary's VALUE type (the field's own plan is MI_K_DICT)."""
-    t = f["arrow_type"]
-    if t in (5, 4):
-        return _ffi.K_STR32, 0, 16
-    if t in (20, 19):
-        return _ffi.K_STR64, 0, 16
-    if t == 2:
-        return _ffi.K_COPY, f["bit_width"] // 8, f["bit_width"] // 8
-    if t == 3:
-        w = 4 if f["precision"] == 1 else 8
-        return _ffi.K_COPY, w, w
-    if t == 6:
-        return _ffi.K_BOOL, 0, 1
-    if t == 8 and f["unit"] == 0:
-        return _ffi.K_COPY, 4, 4
-    if t == 7 and f["bit_width"] == 128:
-        p = f["precision"]
-        return (_ffi.K_DEC128, 2, 2) if p <= 4 else (_ffi.K_DEC128, 4, 4) if p <= 9 else (_ffi.K_DEC128, 8, 8) if p <= 18 \
-            else (_ffi.K_COPY, 16, 16)
-    raise NotImplementedError("dictionary value type %s" % f["format"])
-
-
-def _dict_rows(b, kind, param):
-    """A DictionaryBatch's row count from its buffers (the reader reports lengths through the spans)."""
-    return b["length"]
+        dicts = {did: node(e) for did, e in self.dict_layout.items()}
+        return [dict(nrows=b["nrows"], columns=[node(e) for e in b["columns"]], body_off=b["body_off"], body_len=b["body_len"])
+                for b in self.layout]

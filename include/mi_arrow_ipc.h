@@ -93,6 +93,13 @@ enum mi_kind {
   MI_K_NARROW = 15,       /* K3b decimal32/64 -> int16/32 (valid rows); param = src width | dst width << 8 */
   MI_K_HALF_FLOAT = 16,   /* float16 -> float32 (DuckDB FLOAT) */
   MI_K_NULL = 17,         /* arrow null type: no buffers, all rows NULL (1-byte placeholder data) */
+  MI_K_STRVIEW = 18,      /* K4c utf8_view / binary_view -> string_t; buf2 = table of {u64 address, i64 length} per variadic
+                             data buffer (addresses as the consumer sees them), buf2_len = number of buffers */
+  MI_K_LIST32 = 19,       /* list / map, int32 offsets -> list_entry_t{u64 offset, u64 length}; offsets are relative to the
+                             start of the row's top-level 2048-row window (ConvertArrowListOffsets); param = child length;
+                             buf2 = i64 window starts in this list's row space (NULL: windows are the 2048-row tiles) */
+  MI_K_LIST64 = 20,       /* large_list */
+  MI_K_STRUCT = 21,       /* struct / fixed_size_list: validity only (children are their own tasks) */
   /* encode direction (K7), used by mi_encode_* plans */
   MI_K_ENC_COPY = 32,     /* K7b fixed-width copy; param = width */
   MI_K_ENC_DEC128 = 33,   /* K7b int16/32/64 -> decimal128 sign extension; param = in width */
@@ -145,6 +152,23 @@ int mi_reader_set_projection(mi_reader* r, const char* const* names, int32_t n);
 
 typedef struct mi_buffer_span { int64_t offset; int64_t length; } mi_buffer_span; /* Buffer{offset,length} in the body */
 
+/* One field node of a record batch (depth-first order): nested columns (list / struct / map / fixed_size_list) and
+ * string views own more than the three buffers of a flat column. */
+typedef struct mi_batch_node {
+  char name[64];
+  int32_t arrow_type;      /* enum mi_arrow_type */
+  int32_t kind;            /* enum mi_kind (0 = not decodable) */
+  int32_t out_width;
+  int32_t parent;          /* node index, -1 for a top-level column */
+  int32_t depth;
+  int32_t n_children;
+  int32_t first_span;      /* index into mi_batch.node_spans */
+  int32_t n_spans;         /* validity, buffer 1, buffer 2, ... (+ variadic data buffers of views) */
+  int64_t param;           /* kind parameter (fixed_size_list: list size) */
+  int64_t length;
+  int64_t null_count;
+} mi_batch_node;
+
 /* One decoded RecordBatch message: what IPCStreamReader::GetNextBatch (base_stream_reader.cpp:86-144) hands to
  * DuckDB as an ArrowArray, flattened.  Pointers stay valid until the next mi_reader_next_batch / close. */
 typedef struct mi_batch {
@@ -160,6 +184,11 @@ typedef struct mi_batch {
   const int32_t* column_field;  /* [n_columns] index into the base schema's top-level fields */
   const int64_t* null_count;    /* [n_columns] */
   const mi_buffer_span* buffers;/* [n_columns * 3]: validity, buf1, buf2 (length 0 when absent) */
+  int32_t n_nodes;              /* every node of the projected columns, children right after their parent's subtree order */
+  int32_t _pad;
+  const mi_batch_node* nodes;
+  const mi_buffer_span* node_spans;
+  const int32_t* column_node;   /* [n_columns] node index of every column */
 } mi_batch;
 
 /* Returns MI_OK and fills *out, or MI_ENODATA at end of stream (EOS marker, truncated stream, or buffers
@@ -198,7 +227,8 @@ typedef struct mi_col_task {
   const void* buf2;       /* string data / (encode) string heap */
   void* out_data;         /* DuckDB vector data, nrows * out_width bytes (encode: Arrow buffer 1) */
   void* out_validity;     /* mi_validity_t[ceil(nrows/64)] or NULL to skip (encode: Arrow bitmap) */
-  void* out_aux;          /* encode: Arrow buffer 2 (string data); decode: unused */
+  void* out_aux;          /* encode: Arrow buffer 2 (string data); decode: validity words of the PARENT vector when NULLs
+                             propagate from it (struct / fixed_size_list parents), else NULL */
   uint64_t ptr_base;      /* address the consumer will see for byte 0 of buf2 (string_t long-string pointers) */
   int64_t nrows;
   int64_t row_offset;     /* Arrow array offset: first row inside the buffers (0 for IPC-decoded arrays) */
@@ -207,7 +237,9 @@ typedef struct mi_col_task {
   int64_t param2;
   int64_t null_count;     /* 0: bitmap ignored, all rows valid (GetValidityMask) */
   int32_t kind;           /* enum mi_kind */
-  int32_t flags;
+  int32_t flags;          /* decode with out_aux: parent row = row / flags (0 or 1: same row; n: fixed_size_list of n) */
+  int32_t depth;          /* nesting depth: tasks run depth by depth so a child sees its parent's finished validity */
+  int32_t _reserved;
 } mi_col_task;
 
 /* Error bits a plan accumulates on the device (polled by mi_plan_status). */
@@ -292,6 +324,14 @@ typedef struct mi_vector {
   const void* dictionary;   /* MI_K_DICT: decoded dictionary values (dict_len + 1 entries, last = NULL) */
   const mi_validity_t* dictionary_validity;
   int64_t dict_len;
+  /* nested vectors (list / map / struct / fixed_size_list): children of this chunk's vector.  A list's child covers the
+   * child rows [child_offset, child_offset + child_count) of the record batch; its data pointer is already advanced, its
+   * validity pointer addresses the word that holds its first row and `validity_shift` = first row mod 64 (child windows
+   * are not word aligned; 0 for top-level vectors and struct children of them). */
+  const struct mi_vector* children;
+  int32_t n_children;
+  int32_t validity_shift;
+  int64_t count;            /* rows in this vector (== chunk size for top-level vectors) */
 } mi_vector;
 
 typedef struct mi_data_chunk {

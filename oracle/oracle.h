@@ -111,6 +111,7 @@ int orc_decode_schema(const uint8_t* meta, int32_t meta_len, orc_field* out, int
 int orc_decode_record_batch(const uint8_t* meta, int32_t meta_len, int64_t* length, orc_node* nodes,
                             int32_t max_nodes, int32_t* n_nodes, orc_buf* bufs, int32_t max_bufs,
                             int32_t* n_bufs, int32_t* compression, int64_t* dict_id, int32_t* is_delta);
+int orc_decode_variadic_counts(const uint8_t* meta, int32_t meta_len, int64_t* out, int32_t max, int32_t* n_out);
 /* Arrow IPC file footer (File.fbs): record-batch blocks {offset, metaDataLength, bodyLength}. */
 int orc_decode_footer(const uint8_t* file, int64_t size, int64_t* blocks3, int32_t max_blocks,
                       int32_t* n_blocks, int32_t* n_dict_blocks);
@@ -149,6 +150,13 @@ void orc_interval_months(const int32_t* src, int64_t o, int64_t n, uint8_t* out1
 void orc_interval_mdn(const uint8_t* src16, int64_t o, int64_t n, uint8_t* out16);
 void orc_narrow(const void* src, int32_t src_width, const uint64_t* valid, int64_t o, int64_t n, int32_t dst_width, void* out);
 void orc_half_to_float(const uint16_t* src, int64_t o, int64_t n, uint32_t* out_bits);
+/* nested (ArrowToDuckDBList -> ConvertArrowListOffsets): rows [o, o+n) of a list column, offsets relative to off[win_row]
+ * = the first element of the child vector the chunk carries.  off_width 4 or 8. */
+int orc_list_entries(const void* off, int32_t off_width, int64_t o, int64_t n, int64_t win_row, int64_t child_len, uint8_t* out16);
+/* K4c: string views {i32 len; len<=12 ? 12 inline : prefix[4], i32 buffer_index, i32 offset} -> string_t.
+ * table = {u64 address, i64 length} per variadic data buffer. */
+int orc_string_view(const uint8_t* views16, const uint64_t* valid, int64_t o, int64_t n, const uint64_t* table, int64_t n_buffers,
+                    uint8_t* out16);
 /* K4a/b: utf8/binary with int32 / int64 offsets -> string_t (16 B).  ptr_base is the address the
  * consumer will see for byte 0 of the data buffer (host or device). */
 int orc_string32(const int32_t* off, const uint8_t* data, const uint64_t* valid, int64_t o, int64_t n,
@@ -200,7 +208,11 @@ enum {
   ORC_K_INTERVAL_MDN = 14,    /* tin: {i32 months, i32 days, i64 nanos} -> interval_t{months, days, nanos/1000}, all rows */
   ORC_K_NARROW = 15,          /* decimal32/64 -> int16/32: param = src width | dst width << 8; valid rows, NULL -> 0 */
   ORC_K_HALF_FLOAT = 16,      /* float16 -> float32, all rows */
-  ORC_K_NULL = 17             /* arrow null type: no buffers, every row NULL */
+  ORC_K_NULL = 17,            /* arrow null type: no buffers, every row NULL */
+  ORC_K_STRVIEW = 18,         /* utf8_view / binary_view -> string_t; buf2 = {u64 address, i64 length} per variadic buffer */
+  ORC_K_LIST32 = 19,          /* list / map offsets -> list_entry_t{u64 offset, u64 length}, window relative */
+  ORC_K_LIST64 = 20,
+  ORC_K_STRUCT = 21           /* struct / fixed_size_list: validity only */
 };
 
 typedef struct {
@@ -224,6 +236,9 @@ int32_t orc_out_width(int32_t kind, int64_t param);
 /* Runs the window loop over one column of one batch.  copy_direct != 0 materialises K3a columns into
  * out_data (what the GPU path produces); 0 = the reference's zero-copy alias (nothing to do). */
 int orc_decode_column(const orc_col_task* t, int32_t copy_direct);
+/* The same conversions over the whole column in one go with a caller-supplied validity (nested columns: the child's own
+ * bitmap ANDed with what propagates from struct / fixed_size_list parents).  Does not touch out_validity. */
+int orc_convert_column(const orc_col_task* t, const uint64_t* valid);
 
 /* ---- whole-stream driver (oracle_scan.c): the timed CPU baseline ---------------------------------- */
 typedef struct {

@@ -300,6 +300,23 @@ int orc_decode_record_batch(const uint8_t* meta, int32_t meta_len, int64_t* leng
   return ORC_OK;
 }
 
+/* RecordBatch.variadicBufferCounts [4]: one entry per utf8_view / binary_view node, depth-first */
+int orc_decode_variadic_counts(const uint8_t* meta, int32_t meta_len, int64_t* out, int32_t max, int32_t* n_out) {
+  fb_buf b = {meta, meta_len};
+  int64_t root = fb_root(&b);
+  *n_out = 0;
+  if (root < 0) return ORC_EINVAL;
+  int64_t rb = fb_table_field(&b, root, 2);
+  if (fb_u8(&b, root, 1, 0) == ORC_MSG_DICTIONARY_BATCH) rb = fb_table_field(&b, rb, 1);
+  if (rb < 0) return ORC_EINVAL;
+  uint32_t n;
+  int64_t v = fb_vector(&b, rb, 4, &n);
+  if (n && (v < 0 || v + 8 * (int64_t)n > b.size || (int32_t)n > max)) return ORC_EINVAL;
+  for (uint32_t i = 0; i < n; i++) out[i] = rd_i64(b.base + v + 8 * (int64_t)i);
+  *n_out = (int32_t)n;
+  return ORC_OK;
+}
+
 /* File layout: "ARROW1\0\0" stream... footer  int32 footer_len "ARROW1".
  * Footer { version [0]; schema [1]; dictionaries:[Block] [2]; recordBatches:[Block] [3] }
  * Block struct { offset:long; metaDataLength:int; pad 4; bodyLength:long } = 24 bytes */

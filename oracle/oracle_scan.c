@@ -85,6 +85,11 @@ int orc_plan_column(const orc_field* f, int32_t* kind, int64_t* param, int32_t* 
     case ORC_T_UTF8: case ORC_T_BINARY: *kind = ORC_K_STR32; *n_buffers = 3; return ORC_OK;
     case ORC_T_LARGE_UTF8: case ORC_T_LARGE_BINARY: *kind = ORC_K_STR64; *n_buffers = 3; return ORC_OK;
     case ORC_T_FIXED_BINARY: *kind = ORC_K_FIXED_BINARY; *param = f->byte_width; return ORC_OK;
+    case ORC_T_UTF8_VIEW: case ORC_T_BINARY_VIEW: *kind = ORC_K_STRVIEW; return ORC_OK; /* + variadic buffers */
+    case ORC_T_LIST: case ORC_T_MAP: *kind = ORC_K_LIST32; return ORC_OK;
+    case ORC_T_LARGE_LIST: *kind = ORC_K_LIST64; return ORC_OK;
+    case ORC_T_STRUCT: *kind = ORC_K_STRUCT; *n_buffers = 1; return ORC_OK;
+    case ORC_T_FIXED_LIST: *kind = ORC_K_STRUCT; *param = f->byte_width; *n_buffers = 1; return ORC_OK;
     default: return ORC_ENOTSUP;
   }
 }

@@ -227,6 +227,49 @@ void orc_fixed_binary(const uint8_t* data, int32_t width, const uint64_t* valid,
   }
 }
 
+int orc_list_entries(const void* off, int32_t off_width, int64_t o, int64_t n, int64_t win_row, int64_t child_len, uint8_t* out16) {
+  int rc = ORC_OK;
+  for (int64_t i = 0; i < n; i++) {
+    int64_t a, b, base;
+    if (off_width == 4) {
+      a = ((const int32_t*)off)[o + i]; b = ((const int32_t*)off)[o + i + 1]; base = ((const int32_t*)off)[win_row];
+    } else {
+      a = ((const int64_t*)off)[o + i]; b = ((const int64_t*)off)[o + i + 1]; base = ((const int64_t*)off)[win_row];
+    }
+    if (a < 0 || b < a || b > child_len || a < base) rc = ORC_EINVAL;
+    uint64_t le[2] = {(uint64_t)(a - base), (uint64_t)(b - a)};
+    memcpy(out16 + 16 * i, le, 16);
+  }
+  return rc;
+}
+
+int orc_string_view(const uint8_t* views16, const uint64_t* valid, int64_t o, int64_t n, const uint64_t* table, int64_t n_buffers,
+                    uint8_t* out16) {
+  int rc = ORC_OK;
+  for (int64_t i = 0; i < n; i++) {
+    uint8_t* dst = out16 + 16 * i;
+    memset(dst, 0, 16);
+    if (!word_valid(valid, i)) continue;
+    const uint8_t* v = views16 + 16 * (o + i);
+    uint32_t len;
+    memcpy(&len, v, 4);
+    if (len <= 12) {
+      memcpy(dst, &len, 4);
+      memcpy(dst + 4, v + 4, len);
+    } else {
+      int32_t bi, bo;
+      memcpy(&bi, v + 8, 4);
+      memcpy(&bo, v + 12, 4);
+      if (bi < 0 || bi >= n_buffers || bo < 0 || (uint64_t)bo + len > table[2 * bi + 1]) { rc = ORC_EINVAL; continue; }
+      uint64_t p = table[2 * bi] + (uint64_t)bo;
+      memcpy(dst, &len, 4);
+      memcpy(dst + 4, v + 4, 4);
+      memcpy(dst + 8, &p, 8);
+    }
+  }
+  return rc;
+}
+
 /* ------------------------------------------------------------------------------------------------ K5 */
 /* SetSelectionVector: sel[i] = valid ? idx[i] : dict_len (the extra NULL entry appended to the decoded
  * dictionary); "DuckDB only supports indices that fit on an uint32" for wider out-of-range values. */
@@ -342,6 +385,8 @@ int32_t orc_out_width(int32_t kind, int64_t param) {
     case ORC_K_NARROW: return (int32_t)((param >> 8) & 0xFF);
     case ORC_K_HALF_FLOAT: return 4;
     case ORC_K_NULL: return 1;
+    case ORC_K_STRVIEW: case ORC_K_LIST32: case ORC_K_LIST64: return 16;
+    case ORC_K_STRUCT: return 0;
     case ORC_K_DICT: return 4;
     default: return 0;
   }
@@ -387,4 +432,34 @@ int orc_decode_column(const orc_col_task* t, int32_t copy_direct) {
     if (r != ORC_OK) rc = r;
   }
   return rc;
+}
+
+int orc_convert_column(const orc_col_task* t, const uint64_t* valid) {
+  const int64_t n = t->nrows;
+  const int32_t w = orc_out_width(t->kind, t->param);
+  uint8_t* out = t->out_data;
+  switch (t->kind) {
+    case ORC_K_COPY: memcpy(out, t->buf1, (size_t)(n * w)); return ORC_OK;
+    case ORC_K_BOOL: orc_bool(t->buf1, 0, n, out); return ORC_OK;
+    case ORC_K_DEC128: orc_decimal128_narrow(t->buf1, valid, 0, n, w, out); return ORC_OK;
+    case ORC_K_DATE64: orc_date64_to_date32((const int64_t*)t->buf1, 0, n, (int32_t*)out); return ORC_OK;
+    case ORC_K_MUL_I32: return orc_mul_i32_to_i64((const int32_t*)t->buf1, valid, 0, n, t->param, (int64_t*)out);
+    case ORC_K_MUL_I64: return orc_mul_i64((const int64_t*)t->buf1, valid, 0, n, t->param, (int64_t*)out);
+    case ORC_K_DIV_I64: orc_div_i64((const int64_t*)t->buf1, 0, n, t->param, (int64_t*)out); return ORC_OK;
+    case ORC_K_DURATION: return orc_duration_to_interval((const int64_t*)t->buf1, valid, 0, n, t->param, out);
+    case ORC_K_INTERVAL_MONTHS: orc_interval_months((const int32_t*)t->buf1, 0, n, out); return ORC_OK;
+    case ORC_K_INTERVAL_MDN: orc_interval_mdn(t->buf1, 0, n, out); return ORC_OK;
+    case ORC_K_NARROW: orc_narrow(t->buf1, (int32_t)(t->param & 0xFF), valid, 0, n, w, out); return ORC_OK;
+    case ORC_K_HALF_FLOAT: orc_half_to_float((const uint16_t*)t->buf1, 0, n, (uint32_t*)out); return ORC_OK;
+    case ORC_K_NULL: memset(out, 0, (size_t)n); return ORC_OK;
+    case ORC_K_STR32: return orc_string32((const int32_t*)t->buf1, t->buf2, valid, 0, n, t->ptr_base, out);
+    case ORC_K_STR64: return orc_string64((const int64_t*)t->buf1, t->buf2, valid, 0, n, t->ptr_base, out);
+    case ORC_K_FIXED_BINARY: orc_fixed_binary(t->buf1, (int32_t)t->param, valid, 0, n, t->ptr_base, out); return ORC_OK;
+    case ORC_K_STRVIEW: return orc_string_view(t->buf1, valid, 0, n, (const uint64_t*)t->buf2, t->buf2_len, out);
+    case ORC_K_DICT:
+      return orc_dict_sel(t->buf1, (int32_t)(t->param & 0xFF), (int32_t)((t->param >> 8) & 1), valid, 0, n, (uint32_t)t->param2,
+                          (uint32_t*)out);
+    case ORC_K_STRUCT: return ORC_OK;
+    default: return ORC_ENOTSUP;
+  }
 }

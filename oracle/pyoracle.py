@@ -16,7 +16,9 @@ VECTOR_SIZE = 2048
 
 # kinds (oracle.h)
 K_COPY, K_BOOL, K_DEC128, K_DATE64, K_MUL_I32, K_MUL_I64, K_DIV_I64, K_STR32, K_STR64, K_DICT, K_FIXED_BINARY, \
-    K_DURATION, K_INTERVAL_MONTHS, K_INTERVAL_MDN, K_NARROW, K_HALF_FLOAT, K_NULL = range(1, 18)
+    K_DURATION, K_INTERVAL_MONTHS, K_INTERVAL_MDN, K_NARROW, K_HALF_FLOAT, K_NULL, K_STRVIEW, K_LIST32, K_LIST64, \
+    K_STRUCT = range(1, 22)
+T_STRUCT, T_FIXED_LIST, T_LIST, T_LARGE_LIST, T_MAP, T_UTF8_VIEW, T_BINARY_VIEW, T_NULL, T_UNION = 13, 16, 12, 21, 17, 24, 23, 1, 14
 MSG_SCHEMA, MSG_DICTIONARY_BATCH, MSG_RECORD_BATCH = 1, 2, 3
 
 
@@ -89,6 +91,8 @@ def lib():
         _lib.orc_enc_bool.restype = None
         _lib.orc_enc_bool.argtypes = [P, P, I64, I64, P]
         _lib.orc_enc_varchar32.argtypes = [P, P, I64, I64, U64, P, P, P]
+        _lib.orc_list_entries.argtypes = [P, I32, I64, I64, I64, I64, P]
+        _lib.orc_convert_column.argtypes = [P, P]
     return _lib
 
 
@@ -143,9 +147,12 @@ def decode_record_batch(meta):
                                        2048, C.byref(nb), C.byref(comp), C.byref(dict_id), C.byref(delta))
     if rc:
         raise ValueError("orc_decode_record_batch rc=%d" % rc)
+    var = (C.c_int64 * 512)()
+    nv = C.c_int32(0)
+    lib().orc_decode_variadic_counts(_ptr(a), C.c_int32(a.size), var, 512, C.byref(nv))
     return dict(length=length.value, nodes=[(x.length, x.null_count) for x in nodes[: nn.value]],
                 buffers=[(x.offset, x.length) for x in bufs[: nb.value]], compression=comp.value,
-                dict_id=dict_id.value, is_delta=delta.value)
+                dict_id=dict_id.value, is_delta=delta.value, variadic=list(var[: nv.value]))
 
 
 def decode_footer(file_bytes):
@@ -197,63 +204,180 @@ def _slice_column(body, bl, nbuf):
     return v, b1, b2
 
 
-def decode_stream(buf, ptr_base_of=None, columns=None):
-    """Decode every RecordBatch of a flat-schema IPC stream with the oracle.
+def _and_parent(words, n, parent_words, div):
+    """NULLs of a struct (div 1) / fixed_size_list (div = list size) parent propagate into the child."""
+    bits = np.unpackbits(words.view(np.uint8), bitorder="little")
+    pbits = np.unpackbits(parent_words.view(np.uint8), bitorder="little")
+    idx = np.arange(n) // max(div, 1)
+    bits[:n] &= pbits[idx]
+    return np.packbits(bits, bitorder="little").view(np.uint64).copy()
 
-    Returns (fields, batches); batches[i] = dict(nrows, columns=[dict(kind,param,width,data,validity,rc,...)]).
-    String pointers are `ptr_base + offset`, ptr_base = ptr_base_of(batch_index, body_off, buf_off) when given,
-    else the absolute position of the data buffer inside `buf` (so `buf` itself is the heap).
-    DictionaryBatch messages (which the reference rejects, base_stream_reader.cpp:86-96) are decoded with the value
-    type's plan and attached to the columns that use them as `dictionary`."""
+
+def _decode_node(a, fields, cur, rb, m, ptr_base_fn, win, parent_valid=None, parent_div=1, value_only=False, keep=True):
+    """Depth-first decode of field `cur['field']` (index into the flattened schema) and its descendants.
+    win = row numbers (in this node's row space) where the top-level 2048-row chunk windows start, plus the end."""
+    f = fields[cur["field"]]
+    cur["field"] += 1
+    nrows, null_count = rb["nodes"][cur["node"]]
+    cur["node"] += 1
+    dict_encoded = f["has_dict"] and not value_only
+    t = f["type"]
+    if dict_encoded:
+        own = 2
+    elif t == T_NULL:
+        own = 0
+    elif t in (T_STRUCT, T_FIXED_LIST):
+        own = 1
+    elif t in (5, 4, 20, 19):
+        own = 3
+    elif t in (T_UTF8_VIEW, T_BINARY_VIEW):
+        own = 2 + rb["variadic"][cur["variadic"]]
+        cur["variadic"] += 1
+    else:
+        own = 2
+    spans = rb["buffers"][cur["buf"]: cur["buf"] + own]
+    cur["buf"] += own
+    body = a[m["body_off"]: m["body_off"] + m["body_len"]]
+    sl = lambda sp: body[sp[0]: sp[0] + sp[1]]
+    if value_only:
+        vf = Field.from_buffer_copy(f["_c"])
+        vf.has_dict = 0
+        kind, param, _ = plan_column(dict(f, _c=vf))
+    else:
+        kind, param, _ = plan_column(f)
+    w = out_width(kind, param)
+    node = dict(name=f["name"], kind=kind, param=param, width=w, nrows=nrows, null_count=null_count, rc=0, win=list(win),
+                buffers=spans, children=[], field=f)
+    # validity: own bitmap (null_count == 0 => all valid), then what propagates from the parent
+    words = np.zeros(max((nrows + 63) // 64, 1), np.uint64)
+    bm = _u8(sl(spans[0])) if own > 0 and spans[0][1] else None
+    if kind == K_NULL:
+        words[:] = 0
+    else:
+        lib().orc_validity(_ptr(bm), null_count, 0, nrows, _ptr(words))
+    if parent_valid is not None and nrows:
+        words = _and_parent(words, nrows, parent_valid, parent_div)
+        if nrows & 63:
+            words[(nrows - 1) >> 6] |= np.uint64(0xFFFFFFFFFFFFFFFF) << np.uint64(nrows & 63)
+    words = words[: (nrows + 63) // 64]
+    node["validity"] = words
+    out = np.zeros(max(nrows * w, 1), np.uint8)
+    vptr = _ptr(words) if len(words) else None
+    if kind in (K_LIST32, K_LIST64):
+        offw = 4 if kind == K_LIST32 else 8
+        offs = _u8(sl(spans[1])).view(np.int32 if offw == 4 else np.int64)
+        child_len = rb["nodes"][cur["node"]][0] if f["n_children"] else 0
+        for k in range(len(win) - 1):
+            r0, r1 = win[k], win[k + 1]
+            if r1 > r0:
+                rc = lib().orc_list_entries(_ptr(offs), offw, r0, r1 - r0, r0, child_len, out[16 * r0:].ctypes.data)
+                node["rc"] |= rc
+        child_win = [int(offs[r]) if nrows else 0 for r in win] if nrows else [0] * len(win)
+        node["data"] = out[: nrows * 16]
+        node["children"].append(_decode_node(a, fields, cur, rb, m, ptr_base_fn, child_win))
+        return node
+    if kind == K_STRUCT:
+        node["data"] = out[:0]
+        size = param if t == T_FIXED_LIST else 1
+        child_win = [r * size for r in win] if t == T_FIXED_LIST else list(win)
+        for _ in range(f["n_children"]):
+            node["children"].append(_decode_node(a, fields, cur, rb, m, ptr_base_fn, child_win, parent_valid=words,
+                                                 parent_div=size))
+        return node
+    task = ColTask(kind=kind, param=param, nrows=nrows, null_count=null_count, out_data=_ptr(out))
+    keep_alive = []
+    if kind == K_STRVIEW:
+        table = np.zeros(max(2 * (own - 2), 2), np.uint64)
+        for j, sp in enumerate(spans[2:]):
+            table[2 * j] = ptr_base_fn(m["body_off"], sp[0])
+            table[2 * j + 1] = sp[1]
+        b1 = _u8(sl(spans[1])) if spans[1][1] else np.zeros(16, np.uint8)
+        task.buf1, task.buf2, task.buf2_len = _ptr(b1), _ptr(table), own - 2
+        keep_alive += [b1, table]
+        node["ptr_base"] = 0
+    elif own >= 2:
+        b1 = _u8(sl(spans[1])) if spans[1][1] else np.zeros(16, np.uint8)
+        task.buf1 = _ptr(b1)
+        keep_alive.append(b1)
+        if own == 3:
+            b2 = _u8(sl(spans[2])) if spans[2][1] else np.zeros(16, np.uint8)
+            task.buf2, task.buf2_len = _ptr(b2), spans[2][1]
+            keep_alive.append(b2)
+        data_span = spans[2] if own == 3 else spans[1]
+        task.ptr_base = ptr_base_fn(m["body_off"], data_span[0])
+        node["ptr_base"] = task.ptr_base
+    if kind == K_DICT:
+        task.param2 = cur["dicts"][f["dict_id"]]["nrows"]
+        node["dictionary"] = cur["dicts"][f["dict_id"]]
+    if nrows:
+        node["rc"] |= lib().orc_convert_column(C.byref(task), vptr)
+    node["data"] = out[: nrows * w]
+    return node
+
+
+def _windows(n):
+    w = list(range(0, n, VECTOR_SIZE)) + [n]
+    return w if n else [0, 0]
+
+
+def _flatten_fields(fields):
+    """index of every top-level field inside the flattened (depth-first) field list"""
+    tops, i = [], 0
+
+    def skip(j):
+        nc = fields[j]["n_children"]
+        j += 1
+        for _ in range(nc):
+            j = skip(j)
+        return j
+
+    while i < len(fields):
+        tops.append(i)
+        i = skip(i)
+    return tops
+
+
+def decode_stream(buf, ptr_base_of=None, columns=None):
+    """Decode every RecordBatch of an IPC stream with the oracle (flat and nested columns, string views, dictionaries).
+
+    Returns (top-level fields, batches); batches[i] = dict(nrows, columns=[node...]) where a node is
+    dict(name, kind, param, width, data, validity, rc, children=[...], win=[...]).  String pointers are
+    `ptr_base + offset`: ptr_base_of(batch_index, body_off, buf_off) when given, else the absolute position of the data
+    buffer inside `buf` (so `buf` itself is the heap).  DictionaryBatch messages (which the reference rejects,
+    base_stream_reader.cpp:86-96) are decoded with the value type's plan and attached as `dictionary`."""
     a = _u8(buf)
     msgs = walk_stream(a)
     if not msgs or msgs[0]["type"] != MSG_SCHEMA:
         raise IOError("Expected Schema Arrow IPC message but got end of stream")
     fields, ntop, _ = decode_schema(a[msgs[0]["meta_off"]: msgs[0]["meta_off"] + msgs[0]["meta_len"]])
-    if len(fields) != ntop:
-        raise NotImplementedError("nested schema")
-    plans = [plan_column(f) for f in fields]
+    tops = _flatten_fields(fields)
+    top_fields = [fields[i] for i in tops]
     dicts = {}
     batches = []
     bi = 0
     for m in msgs[1:]:
         rb = decode_record_batch(a[m["meta_off"]: m["meta_off"] + m["meta_len"]])
-        body = a[m["body_off"]: m["body_off"] + m["body_len"]]
-        if m["type"] == MSG_DICTIONARY_BATCH:
-            f = [x for x in fields if x["has_dict"] and x["dict_id"] == rb["dict_id"]][0]
-            vf = Field.from_buffer_copy(f["_c"])
-            vf.has_dict = 0
-            kind, param, nbuf = plan_column(dict(f, _c=vf))
-            bl = rb["buffers"][:nbuf]
-            v, b1, b2 = _slice_column(body, bl, nbuf)
-            nrows, null_count = rb["nodes"][0]
-            base = m["body_off"] + (bl[2][0] if nbuf > 2 else bl[1][0])
-            d, val, rc = decode_column(kind, param, nrows, v, b1, b2, null_count, base)
-            dicts[rb["dict_id"]] = dict(kind=kind, param=param, width=out_width(kind, param), data=d, validity=val,
-                                        rc=rc, nrows=nrows, ptr_base=base, is_delta=rb["is_delta"])
-            continue
-        if m["type"] != MSG_RECORD_BATCH:
+        if m["type"] not in (MSG_DICTIONARY_BATCH, MSG_RECORD_BATCH):
             raise IOError("Expected RecordBatch Arrow IPC message but got type %d" % m["type"])
+        base_fn = (lambda body_off, boff, _bi=bi: ptr_base_of(_bi, body_off, boff)) if ptr_base_of else (lambda body_off, boff: body_off + boff)
+        if m["type"] == MSG_DICTIONARY_BATCH:
+            fi = [i for i in tops if fields[i]["has_dict"] and fields[i]["dict_id"] == rb["dict_id"]][0]
+            cur = dict(field=fi, node=0, buf=0, variadic=0, dicts=dicts)
+            n = rb["nodes"][0][0]
+            dicts[rb["dict_id"]] = _decode_node(a, fields, cur, rb, m, (lambda body_off, boff: body_off + boff), _windows(n),
+                                                value_only=True)
+            dicts[rb["dict_id"]]["is_delta"] = rb["is_delta"]
+            continue
         cols = []
-        k = 0
-        for ci, (f, (kind, param, nbuf)) in enumerate(zip(fields, plans)):
-            bl = rb["buffers"][k: k + nbuf]
-            k += nbuf
-            if columns is not None and f["name"] not in columns:
-                continue
-            nrows, null_count = rb["nodes"][ci]
-            v, b1, b2 = _slice_column(body, bl, nbuf)
-            boff = bl[2][0] if nbuf > 2 else (bl[1][0] if nbuf else 0)
-            base = ptr_base_of(bi, m["body_off"], boff) if ptr_base_of else m["body_off"] + boff
-            dictionary = dicts.get(f["dict_id"]) if f["has_dict"] else None
-            d, val, rc = decode_column(kind, param, nrows, v, b1, b2, null_count, base,
-                                       param2=(dictionary["nrows"] if dictionary else 0))
-            cols.append(dict(name=f["name"], kind=kind, param=param, width=out_width(kind, param), data=d,
-                             validity=val, rc=rc, buffers=bl, ptr_base=base, null_count=null_count,
-                             dictionary=dictionary))
+        cur = dict(field=0, node=0, buf=0, variadic=0, dicts=dicts)
+        for ti, fi in enumerate(tops):
+            assert cur["field"] == fi
+            node = _decode_node(a, fields, cur, rb, m, base_fn, _windows(rb["length"]))
+            if columns is None or fields[fi]["name"] in columns:
+                cols.append(node)
         batches.append(dict(nrows=rb["length"], columns=cols, body_off=m["body_off"], body_len=m["body_len"]))
         bi += 1
-    return fields, batches
+    return top_fields, batches
 
 
 def scan_stream(buf, max_batches=1 << 30, want_checksum=False):

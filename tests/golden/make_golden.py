@@ -37,6 +37,12 @@ def canon_value(v):
     """Canonical JSON-able logical value. Temporal values are reduced to the integer DuckDB stores."""
     if v is None or isinstance(v, (bool, int, str)):
         return v
+    if isinstance(v, list):
+        return [canon_value(x) for x in v]
+    if isinstance(v, tuple):
+        return [canon_value(x) for x in v]  # map entries (key, value)
+    if isinstance(v, dict):
+        return {k: canon_value(x) for k, x in v.items()}
     if isinstance(v, float):
         return "nan" if v != v else repr(v)
     if isinstance(v, bytes):
@@ -259,6 +265,40 @@ def main():
     p = os.path.join(HERE, "edge_types2.arrows")
     write_stream(p, b2[0].schema, b2)
     exp["edge_types2.arrows"] = table_expectation(read_any(p))
+
+    # 3b''. nested types and string views: lists, lists of lists, structs, lists of structs,
+    #       fixed-size lists, maps, large lists, utf8_view / binary_view -- with NULLs at every level
+    def nested_batch(n):
+        def maybe(v, p=0.15):
+            return None if rng.random() < p else v
+        words = ["", "a", "hello", "twelve bytes", "thirteen byte", "a considerably longer string value"]
+        ints = lambda k: [maybe(int(x)) for x in rng.integers(-1000, 1000, k)]
+        cols = {
+            "l_i": pa.array([maybe(ints(int(rng.integers(0, 6)))) for _ in range(n)], pa.list_(pa.int32())),
+            "l_s": pa.array([maybe([maybe(words[int(i)]) for i in rng.integers(0, len(words), int(rng.integers(0, 4)))]) for _ in range(n)],
+                            pa.list_(pa.string())),
+            "ll": pa.array([maybe([maybe(ints(int(rng.integers(0, 4)))) for _ in range(int(rng.integers(0, 4)))]) for _ in range(n)],
+                           pa.list_(pa.list_(pa.int64()))),
+            "st": pa.array([maybe({"a": maybe(int(rng.integers(0, 100))), "b": maybe(words[int(rng.integers(0, len(words)))])}) for _ in range(n)],
+                           pa.struct([("a", pa.int32()), ("b", pa.string())])),
+            "l_st": pa.array([maybe([maybe({"x": maybe(int(rng.integers(0, 10**9))), "y": maybe(words[int(rng.integers(0, len(words)))])})
+                                     for _ in range(int(rng.integers(0, 4)))]) for _ in range(n)],
+                             pa.list_(pa.struct([("x", pa.int64()), ("y", pa.string())]))),
+            "fl": pa.array([maybe([maybe(int(x)) for x in rng.integers(-100, 100, 3)]) for _ in range(n)], pa.list_(pa.int16(), 3)),
+            "mp": pa.array([maybe([(words[int(i)] + str(j), maybe(int(rng.integers(0, 50)))) for j, i in
+                                   enumerate(rng.integers(0, len(words), int(rng.integers(0, 4))))]) for _ in range(n)],
+                           pa.map_(pa.string(), pa.int32())),
+            "lgl": pa.array([maybe([float(x) for x in rng.integers(0, 100, int(rng.integers(0, 5)))]) for _ in range(n)],
+                            pa.large_list(pa.float64())),
+            "sv": pa.array([maybe(words[int(i)]) for i in rng.integers(0, len(words), n)], pa.string_view()),
+            "bv": pa.array([maybe(words[int(i)].encode() * 2) for i in rng.integers(0, len(words), n)], pa.binary_view()),
+        }
+        return pa.record_batch(list(cols.values()), names=list(cols.keys()))
+
+    nb = [nested_batch(n) for n in (5, 2100, 4500)]
+    p = os.path.join(HERE, "edge_nested.arrows")
+    write_stream(p, nb[0].schema, nb)
+    exp["edge_nested.arrows"] = table_expectation(read_any(p))
 
     # 3c. empty batches, all-null and all-valid columns, zero-length validity
     sch = pa.schema([("a", pa.int32()), ("s", pa.string()), ("n", pa.int64())])

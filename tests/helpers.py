@@ -53,17 +53,56 @@ def canon_flat(field, kind, param, width, data, validity, n, heap, heap_base=0):
     return _fixed(data, ok, dt)
 
 
-def canon_oracle_column(field, col, n, heap, heap_base=0):
-    """A column dict from pyoracle.decode_stream (or the GPU equivalent) -> canonical logical list."""
-    if col["kind"] == po.K_DICT:
-        d = col["dictionary"]
-        vf = dict(field, has_dict=0)
-        base = canon_flat(vf, d["kind"], d["param"], d["width"], d["data"], d["validity"], d["nrows"], heap,
-                          heap_base) + [None]
-        sel = col["data"].view(np.uint32)
+def canon_node(node, heap, heap_base=0):
+    """A decoded node (flat or nested) -> canonical logical values for ALL its rows (batch level)."""
+    f = node["field"] if "field" in node else None
+    n = node["nrows"]
+    kind = node["kind"]
+    ok = po.valid_bits(node["validity"], n) if n else np.zeros(0, bool)
+    if kind in (po.K_LIST32, po.K_LIST64):
+        child = canon_node(node["children"][0], heap, heap_base)
+        ent = node["data"].view(np.uint64).reshape(-1, 2) if n else np.zeros((0, 2), np.uint64)
+        win, cwin = node["win"], node["children"][0]["win"]
+        out = []
+        k = 0
+        is_map = f is not None and f["type"] == 17
+        for r in range(n):
+            while r >= win[k + 1]:
+                k += 1
+            if not ok[r]:
+                out.append(None)
+                continue
+            start = cwin[k] + int(ent[r, 0])
+            vals = child[start: start + int(ent[r, 1])]
+            out.append([[v["key"], v["value"]] for v in vals] if is_map else vals)
+        return out
+    if kind == po.K_STRUCT:
+        kids = [canon_node(c, heap, heap_base) for c in node["children"]]
+        if f is not None and f["type"] == 16:  # fixed_size_list
+            size = int(node["param"])
+            return [kids[0][r * size: (r + 1) * size] if ok[r] else None for r in range(n)]
+        names = [c["name"] for c in node["children"]]
+        return [{nm: kid[r] for nm, kid in zip(names, kids)} if ok[r] else None for r in range(n)]
+    if kind == po.K_STRVIEW:
+        as_bytes = f["type"] == 23
+        vals = po.strings_to_pylist(node["data"], node["validity"], n, heap, heap_base, as_bytes=as_bytes)
+        return [("b:" + v.hex()) if (as_bytes and v is not None) else v for v in vals]
+    if kind == po.K_DICT:
+        d = node["dictionary"]
+        vf = dict(f, has_dict=0)
+        base = canon_flat(vf, d["kind"], d["param"], d["width"], d["data"], d["validity"], d["nrows"], heap, heap_base) + [None]
+        sel = node["data"].view(np.uint32)
         return [base[int(sel[i])] for i in range(n)]
-    return canon_flat(field, col["kind"], col["param"], col["width"], col["data"], col["validity"], n, heap,
-                      heap_base)
+    return canon_flat(f, kind, node["param"], node["width"], node["data"], node["validity"], n, heap, heap_base)
+
+
+def canon_oracle_column(field, col, n, heap, heap_base=0):
+    """A column node from pyoracle.decode_stream (or the GPU equivalent) -> canonical logical list."""
+    if "field" not in col:
+        col = dict(col, field=field)
+    if "nrows" not in col:
+        col = dict(col, nrows=n)
+    return canon_node(col, heap, heap_base)
 
 
 def canon_stream(fields, batches, heap, heap_base=0):

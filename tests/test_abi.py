@@ -41,7 +41,7 @@ def test_struct_sizes_match_header():
 #include "mi_arrow_ipc.h"
 #include "mi_synth.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(mi_field), sizeof(mi_ipc_buffer), sizeof(mi_batch),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(mi_batch_node), sizeof(mi_field), sizeof(mi_ipc_buffer), sizeof(mi_batch),
          sizeof(mi_batch_index_entry), sizeof(mi_col_task), sizeof(mi_scan_options), sizeof(mi_vector),
          sizeof(mi_data_chunk), sizeof(mi_write_options), sizeof(mi_synth_options), sizeof(mi_string_t));
   return 0;
@@ -54,7 +54,7 @@ int main(void) {
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
         sizes = [int(x) for x in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
     import ctypes as C
-    mine = [C.sizeof(x) for x in (_ffi.Field, _ffi.IpcBuffer, _ffi.Batch, _ffi.BatchIndexEntry, _ffi.ColTask,
+    mine = [C.sizeof(x) for x in (_ffi.BatchNode, _ffi.Field, _ffi.IpcBuffer, _ffi.Batch, _ffi.BatchIndexEntry, _ffi.ColTask,
                                   _ffi.ScanOptions, _ffi.Vector, _ffi.DataChunk, _ffi.WriteOptions, _ffi.SynthOptions)] + [16]
     assert sizes == mine
 

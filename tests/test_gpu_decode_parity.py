@@ -28,24 +28,32 @@ def torch():
     return torch
 
 
+def assert_nodes_equal(gc, wc, where):
+    assert wc["rc"] == 0, where
+    assert gc["kind"] == wc["kind"] and gc["width"] == wc["width"] and gc["nrows"] == wc["nrows"], where
+    assert np.array_equal(gc["validity"], wc["validity"]), (where, "validity")
+    if not np.array_equal(gc["data"], wc["data"]):
+        w = max(gc["width"], 1)
+        bad = np.nonzero(np.any(gc["data"].reshape(-1, w) != wc["data"].reshape(-1, w), axis=1))[0]
+        raise AssertionError("%s: %d rows differ, first row %d: got %s want %s" % (
+            where, len(bad), bad[0], gc["data"].reshape(-1, w)[bad[0]].tolist(), wc["data"].reshape(-1, w)[bad[0]].tolist()))
+    if gc["kind"] == po.K_DICT:
+        assert_nodes_equal(gc["dictionary"], wc["dictionary"], where + ".dictionary")
+    assert len(gc["children"]) == len(wc["children"]), where
+    if gc["children"]:
+        assert gc["win"] == wc["win"], where
+    for g, w_ in zip(gc["children"], wc["children"]):
+        assert_nodes_equal(g, w_, where + "." + g["name"])
+    gc["field"] = wc["field"]  # lets helpers.canon_node interpret the GPU result with the oracle's schema info
+
+
 def assert_streams_equal(got, want):
     assert len(got) == len(want)
     for bi, (gb, wb) in enumerate(zip(got, want)):
         assert gb["nrows"] == wb["nrows"]
         assert [c["name"] for c in gb["columns"]] == [c["name"] for c in wb["columns"]]
         for gc, wc in zip(gb["columns"], wb["columns"]):
-            assert wc["rc"] == 0
-            assert gc["kind"] == wc["kind"] and gc["width"] == wc["width"]
-            assert np.array_equal(gc["validity"], wc["validity"]), (bi, gc["name"], "validity")
-            if not np.array_equal(gc["data"], wc["data"]):
-                w = gc["width"]
-                bad = np.nonzero(np.any(gc["data"].reshape(-1, w) != wc["data"].reshape(-1, w), axis=1))[0]
-                raise AssertionError("batch %d column %s: %d rows differ, first row %d: got %s want %s" % (
-                    bi, gc["name"], len(bad), bad[0], gc["data"].reshape(-1, w)[bad[0]].tolist(),
-                    wc["data"].reshape(-1, w)[bad[0]].tolist()))
-            if gc["kind"] == po.K_DICT:
-                gd, wd = gc["dictionary"], wc["dictionary"]
-                assert np.array_equal(gd["data"], wd["data"]) and np.array_equal(gd["validity"], wd["validity"])
+            assert_nodes_equal(gc, wc, "batch %d column %s" % (bi, gc["name"]))
 
 
 @pytest.mark.parametrize("rel", STREAM_FILES)

@@ -18,7 +18,7 @@ STREAM_FILES = [
     "ref_data/multifile/fruit_extra.arrows", "ref_data/multifile/hive/part=a/f1.arrow",
     "ref_data/multifile/hive/part=a/f2.arrow", "ref_data/multifile/hive/part=b/f1.arrow",
     "ref_data/multifile/hive/part=b/f3.arrow", "lineitem_sf0_01_q6.arrows", "lineitem_sf0_01_head.arrows",
-    "edge_reftest.arrows", "edge_types.arrows", "edge_types2.arrows", "edge_empty.arrows", "edge_dict.arrows", "edge_file_format.arrow",
+    "edge_reftest.arrows", "edge_types.arrows", "edge_types2.arrows", "edge_nested.arrows", "edge_empty.arrows", "edge_dict.arrows", "edge_file_format.arrow",
 ]
 
 
