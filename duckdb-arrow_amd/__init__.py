@@ -237,11 +237,12 @@ def filter_range(ctx, values_ptr, width, validity_ptr, nrows, lo, hi, sel_ptr, c
 
 
 # ---------------------------------------------------------------------------------------------------- logical views
-def _valid_bits(validity_ptr, n):
+def _valid_bits(validity_ptr, n, shift=0):
+    """`shift`: bit of the first word that belongs to row 0 (mi_vector.validity_shift, nested children only)."""
     if not validity_ptr:
         return np.ones(n, bool)
-    words = np.ctypeslib.as_array(C.cast(validity_ptr, C.POINTER(C.c_uint64)), shape=((n + 63) // 64,))
-    return np.unpackbits(words.view(np.uint8), bitorder="little")[:n].astype(bool)
+    words = np.ctypeslib.as_array(C.cast(validity_ptr, C.POINTER(C.c_uint64)), shape=((n + shift + 63) // 64 or 1,))
+    return np.unpackbits(words.view(np.uint8), bitorder="little")[shift: shift + n].astype(bool)
 
 
 def _string_values(data_ptr, n, ok, as_bytes):
@@ -265,9 +266,9 @@ _INT_TYPES = {"TINYINT": np.int8, "UTINYINT": np.uint8, "SMALLINT": np.int16, "U
               "TIMESTAMP_MS": np.int64, "TIMESTAMP_NS": np.int64, "TIMESTAMP WITH TIME ZONE": np.int64}
 
 
-def _flat_values(duck_type, width, data_ptr, validity_ptr, n):
+def _flat_values(duck_type, width, data_ptr, validity_ptr, n, shift=0):
     """One host DuckDB flat vector -> python list of the raw stored values (ints for temporal / decimal types)."""
-    ok = _valid_bits(validity_ptr, n)
+    ok = _valid_bits(validity_ptr, n, shift)
     if n == 0:
         return []
     if duck_type in ("VARCHAR", "BLOB"):
@@ -293,21 +294,86 @@ def _flat_values(duck_type, width, data_ptr, validity_ptr, n):
     return [vals[i].item() if ok[i] else None for i in range(n)]
 
 
+def _split_top(text, sep=","):
+    """Split on `sep` outside parentheses / quotes."""
+    parts, depth, cur, quoted = [], 0, [], False
+    for ch in text:
+        if ch == '"':
+            quoted = not quoted
+        if not quoted:
+            depth += ch == "("
+            depth -= ch == ")"
+            if ch == sep and depth == 0:
+                parts.append("".join(cur).strip())
+                cur = []
+                continue
+        cur.append(ch)
+    if cur or parts:
+        parts.append("".join(cur).strip())
+    return parts
+
+
+def parse_duck_type(text):
+    """'STRUCT(a INTEGER, b VARCHAR)[]' -> ('list', ('struct', [('a', ('leaf', 'INTEGER')), ...])).  Mirrors the
+    LogicalType the reference binds for the column (ArrowType::GetDuckType)."""
+    text = text.strip()
+    if text.endswith("]"):
+        i = text.rindex("[")
+        inner, size = parse_duck_type(text[:i]), text[i + 1: -1]
+        return ("list", inner) if size == "" else ("array", inner, int(size))
+    if text.startswith("STRUCT(") and text.endswith(")"):
+        kids = []
+        for part in _split_top(text[7:-1]):
+            if part.startswith('"'):
+                j = part.index('"', 1)
+                name, rest = part[1:j], part[j + 1:]
+            else:
+                name, _, rest = part.partition(" ")
+            kids.append((name, parse_duck_type(rest)))
+        return ("struct", kids)
+    if text.startswith("MAP(") and text.endswith(")"):
+        k, v = _split_top(text[4:-1])
+        return ("map", parse_duck_type(k), parse_duck_type(v))
+    return ("leaf", text)
+
+
+def _vector_values(v, ty, n):
+    """One host mi_vector (flat, dictionary or nested) of n rows -> python values."""
+    shift = v.validity_shift
+    if v.kind == _ffi.K_DICT:
+        dt = ty[1]
+        base = _flat_values(dt, {"VARCHAR": 16, "BLOB": 16}.get(dt, _dict_width(dt)), v.dictionary, v.dictionary_validity,
+                            v.dict_len + 1)
+        sel = np.ctypeslib.as_array(C.cast(v.data, C.POINTER(C.c_uint32)), shape=(max(n, 1),))[:n]
+        return [base[int(x)] for x in sel]
+    if ty[0] == "leaf":
+        return _flat_values(ty[1], v.out_width, v.data, v.validity, n, shift)
+    ok = _valid_bits(v.validity, n, shift)
+    if ty[0] in ("list", "map"):
+        child = v.children[0]
+        cty = ty[1] if ty[0] == "list" else ("struct", [("key", ty[1]), ("value", ty[2])])
+        cvals = _vector_values(child, cty, child.count)
+        ent = np.ctypeslib.as_array(C.cast(v.data, C.POINTER(C.c_uint64)), shape=(max(n, 1) * 2,))[: n * 2].reshape(-1, 2)
+        out = []
+        for r in range(n):
+            if not ok[r]:
+                out.append(None)
+                continue
+            vals = cvals[int(ent[r, 0]): int(ent[r, 0]) + int(ent[r, 1])]
+            out.append([(e["key"], e["value"]) for e in vals] if ty[0] == "map" else vals)
+        return out
+    if ty[0] == "array":
+        child = v.children[0]
+        cvals = _vector_values(child, ty[1], child.count)
+        return [cvals[r * ty[2]: (r + 1) * ty[2]] if ok[r] else None for r in range(n)]
+    kids = [_vector_values(v.children[i], kt, n) for i, (_, kt) in enumerate(ty[1])]
+    return [{nm: kid[r] for (nm, _), kid in zip(ty[1], kids)} if ok[r] else None for r in range(n)]
+
+
 def chunk_to_columns(chunk, fields):
-    """mi_data_chunk (host vectors) -> list of python value lists, dictionary vectors flattened."""
-    cols = []
-    n = chunk.size
-    for ci, f in enumerate(fields):
-        v = chunk.columns[ci]
-        dt = f["duck_type"]
-        if v.kind == _ffi.K_DICT:
-            base = _flat_values(dt, {"VARCHAR": 16, "BLOB": 16}.get(dt, _dict_width(dt)), v.dictionary, v.dictionary_validity,
-                                v.dict_len + 1)
-            sel = np.ctypeslib.as_array(C.cast(v.data, C.POINTER(C.c_uint32)), shape=(n,))
-            cols.append([base[int(s)] for s in sel])
-        else:
-            cols.append(_flat_values(dt, v.out_width, v.data, v.validity, n))
-    return cols
+    """mi_data_chunk (host vectors) -> list of python value lists; dictionary vectors flattened, nested vectors as
+    python lists / dicts / (key, value) tuples."""
+    return [_vector_values(chunk.columns[ci], parse_duck_type(f["duck_type"]), chunk.size) for ci, f in enumerate(fields)]
 
 
 def _dict_width(duck_type):

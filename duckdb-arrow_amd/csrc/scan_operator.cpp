@@ -74,6 +74,8 @@ ArrowScan::~ArrowScan() {
     if (s.d_out) (void)hipFree(s.d_out);
     if (s.h_out) (void)hipHostFree(s.h_out);
     if (s.h_status) (void)hipHostFree(s.h_status);
+    if (s.h_aux) (void)hipHostFree(s.h_aux);
+    if (s.d_aux) (void)hipFree(s.d_aux);
     if (s.h2d_done) (void)hipEventDestroy(s.h2d_done);
     if (s.compute_done) (void)hipEventDestroy(s.compute_done);
     if (s.d2h_done) (void)hipEventDestroy(s.d2h_done);
@@ -168,11 +170,9 @@ void ArrowScan::Init(const std::vector<std::string>& projected) {
   }
   for (auto& c : out_columns) {
     if (c.is_filename || c.is_hive) continue;
-    int32_t kind, w, nb;
-    int64_t param;
-    if (!c.field.Plan(&kind, &param, &w, &nb)) {
-      throw NotImplementedException("Column '" + c.name + "' has Arrow type " + c.field.Format() +
-                                    " which the MI355X scan path does not decode yet");
+    std::string why;
+    if (!c.field.Supported(&why)) {
+      throw NotImplementedException("Column '" + c.name + "': " + why + " is not decoded by the MI355X scan path yet");
     }
     if (c.field.has_dictionary && !opts.accept_dictionaries) {
       // the reference cannot read dictionary-encoded IPC at all (base_stream_reader.cpp:86-96)
@@ -337,26 +337,162 @@ void ArrowScan::DecodeDictionary(Source& src, const DecodedBatch& b) {
   dicts[b.dict_id] = d;
 }
 
+// One field node (and, recursively, its children) of a record batch: output slots + the transcode task.
+// `win` = first row of every top-level 2048-row chunk window in this node's row space (+ the end): top-level columns and
+// struct children of them have win[k] = 2048k (the tiles themselves); the child of a list starts its window k at
+// offsets[win[k]], the child of a fixed_size_list at size * win[k].
+int32_t ArrowScan::AddNode(Slot& s, const DecodedBatch& b, int32_t ni, std::vector<int64_t> win, bool win_is_tiles,
+                           int64_t parent_valid_off, int32_t parent_div, size_t* off, std::vector<mi_col_task>* tasks,
+                           std::vector<uint64_t>* aux, std::vector<std::pair<size_t, size_t>>* aux_fixups) {
+  const DecodedNode& nd = b.nodes[static_cast<size_t>(ni)];
+  int32_t kind, w, nb;
+  int64_t param;
+  if (!nd.field->Plan(&kind, &param, &w, &nb, nd.value_only))
+    throw NotImplementedException("Arrow type " + nd.field->Format() + " of field '" + nd.field->name + "' is not decoded by the MI355X scan path");
+  const int64_t n = nd.length;
+  const int32_t idx = static_cast<int32_t>(s.node_out.size());
+  s.node_out.emplace_back();
+  {
+    Slot::NodeOut& o = s.node_out.back();
+    o.kind = kind;
+    o.width = w;
+    o.param = param;
+    o.nrows = n;
+    o.arrow_type = nd.field->type;
+    o.win = win;
+    o.data_off = *off;
+    *off += RoundUp(static_cast<size_t>(n) * static_cast<size_t>(std::max(w, 1)) + 16);
+    o.valid_off = *off;
+    *off += RoundUp(static_cast<size_t>((n + 63) / 64) * 8 + 8);
+  }
+  const size_t data_off = s.node_out[static_cast<size_t>(idx)].data_off, valid_off = s.node_out[static_cast<size_t>(idx)].valid_off;
+  auto span = [&](size_t k) { return k < nd.spans.size() ? nd.spans[k] : mi_buffer_span{0, 0}; };
+  auto consumer_addr = [&](int64_t body_offset) {
+    return opts.device_resident ? reinterpret_cast<uint64_t>(s.d_in) + static_cast<uint64_t>(body_offset)
+                                : reinterpret_cast<uint64_t>(b.body) + static_cast<uint64_t>(body_offset);
+  };
+  mi_col_task t;
+  std::memset(&t, 0, sizeof(t));
+  // out_data / out_validity / out_aux hold OFFSETS until the slot's buffers are final (EnqueueBatch rebases them)
+  t.out_data = reinterpret_cast<void*>(data_off);
+  t.out_validity = reinterpret_cast<void*>(valid_off);
+  t.out_aux = reinterpret_cast<void*>(parent_valid_off >= 0 ? static_cast<size_t>(parent_valid_off) + 1 : 0);  // +1: 0 means none
+  t.flags = parent_div;
+  t.depth = nd.depth;
+  t.validity = span(0).length ? s.d_in + span(0).offset : nullptr;
+  t.buf1 = nd.spans.size() > 1 ? s.d_in + span(1).offset : s.d_in;
+  t.nrows = n;
+  t.null_count = nd.null_count;
+  t.kind = kind;
+  t.param = param;
+  std::vector<int64_t> child_win;
+  switch (kind) {
+    case MI_K_STR32: case MI_K_STR64:
+      t.buf2 = s.d_in + span(2).offset;
+      t.buf2_len = span(2).length;
+      t.ptr_base = consumer_addr(span(2).offset);
+      break;
+    case MI_K_FIXED_BINARY:
+      t.ptr_base = consumer_addr(span(1).offset);
+      break;
+    case MI_K_STRVIEW: {
+      const size_t at = aux->size();
+      for (size_t k = 2; k < nd.spans.size(); k++) {
+        aux->push_back(consumer_addr(nd.spans[k].offset));
+        aux->push_back(static_cast<uint64_t>(nd.spans[k].length));
+      }
+      if (nd.spans.size() <= 2) { aux->push_back(0); aux->push_back(0); }
+      t.buf2_len = static_cast<int64_t>(nd.spans.size() > 2 ? nd.spans.size() - 2 : 0);
+      aux_fixups->emplace_back(tasks->size(), at);
+      break;
+    }
+    case MI_K_DICT: {
+      auto it = dicts.find(nd.field->dict_id);
+      if (it == dicts.end()) throw IOException("RecordBatch uses dictionary id " + std::to_string(nd.field->dict_id) + " before its DictionaryBatch");
+      s.node_out[static_cast<size_t>(idx)].dict = it->second;
+      t.param2 = it->second->dict_len;
+      break;
+    }
+    case MI_K_LIST32: case MI_K_LIST64: {
+      if (nd.children.size() != 1) throw InternalException("list field without exactly one child");
+      t.param = b.nodes[static_cast<size_t>(nd.children[0])].length;
+      if (!win_is_tiles) {
+        const size_t at = aux->size();
+        for (int64_t r : win) aux->push_back(static_cast<uint64_t>(r));
+        t.buf2_len = static_cast<int64_t>(win.size());
+        aux_fixups->emplace_back(tasks->size(), at);
+      }
+      // the child's windows start at offsets[win[k]] (read from the host copy of the body)
+      const uint8_t* offs = b.body + span(1).offset;
+      child_win.reserve(win.size());
+      for (int64_t r : win) {
+        int64_t v = 0;
+        if (n > 0) {
+          if (kind == MI_K_LIST32) { int32_t x; std::memcpy(&x, offs + 4 * r, 4); v = x; }
+          else std::memcpy(&v, offs + 8 * r, 8);
+        }
+        child_win.push_back(v);
+      }
+      break;
+    }
+    default: break;
+  }
+  if (n > 0) tasks->push_back(t);
+  if (kind == MI_K_LIST32 || kind == MI_K_LIST64) {
+    const int32_t c = AddNode(s, b, nd.children[0], child_win, false, -1, 0, off, tasks, aux, aux_fixups);
+    s.node_out[static_cast<size_t>(idx)].children.push_back(c);
+  } else if (kind == MI_K_STRUCT && !nd.children.empty()) {
+    const bool fixed = nd.field->type == MI_AT_FIXED_LIST;
+    const int64_t size = fixed ? param : 1;
+    std::vector<int64_t> cw;
+    for (int64_t r : win) cw.push_back(r * size);
+    for (int32_t cn : nd.children) {
+      const int32_t c = AddNode(s, b, cn, cw, win_is_tiles && !fixed, static_cast<int64_t>(valid_off), static_cast<int32_t>(fixed ? size : 1),
+                                off, tasks, aux, aux_fixups);
+      s.node_out[static_cast<size_t>(idx)].children.push_back(c);
+    }
+  }
+  return idx;
+}
+
 void ArrowScan::EnqueueBatch(Slot& s) {
   ctx->Bind();
   const DecodedBatch& b = s.batch;
   Source& src = sources[static_cast<size_t>(s.source)];
   const int64_t n = b.length;
   s.nrows = n;
-  // output layout
+  std::vector<int64_t> top_win;
+  for (int64_t r = 0; r < n; r += MI_VECTOR_SIZE) top_win.push_back(r);
+  top_win.push_back(n);
+  if (n == 0) top_win.push_back(0);
+  // output layout + tasks (offsets first, rebased once the slot buffers are sized)
   size_t off = 0;
+  s.node_out.clear();
+  s.col_root.assign(out_columns.size(), -1);
   s.col_data_off.assign(out_columns.size(), 0);
   s.col_valid_off.assign(out_columns.size(), 0);
-  s.col_dict.assign(out_columns.size(), nullptr);
-  std::vector<int32_t> kinds(out_columns.size(), 0), widths(out_columns.size(), 0), nbufs(out_columns.size(), 0);
-  std::vector<int64_t> params(out_columns.size(), 0);
+  std::vector<int32_t> widths(out_columns.size(), 0);
+  std::vector<mi_col_task> tasks;
+  std::vector<uint64_t> aux;
+  std::vector<std::pair<size_t, size_t>> aux_fixups;  // (task index, first aux word)
+  // d_in must be final before tasks take addresses inside it
+  EnsureSlotBuffers(s, static_cast<size_t>(b.body_size) + 64, 0);
   for (size_t c = 0; c < out_columns.size(); c++) {
     if (out_columns[c].is_filename || out_columns[c].is_hive) continue;
-    out_columns[c].field.Plan(&kinds[c], &params[c], &widths[c], &nbufs[c]);
-    s.col_data_off[c] = off;
-    off += RoundUp(static_cast<size_t>(n) * static_cast<size_t>(widths[c]) + 16);
-    s.col_valid_off[c] = off;
-    off += RoundUp(static_cast<size_t>((n + 63) / 64) * 8 + 8);
+    const int32_t fc = src.out_to_file_column[c];
+    int32_t kind, nb;
+    int64_t param;
+    out_columns[c].field.Plan(&kind, &param, &widths[c], &nb);
+    if (fc < 0) {  // column absent in this file (union_by_name): an all-NULL vector
+      s.col_data_off[c] = off;
+      off += RoundUp(static_cast<size_t>(n) * static_cast<size_t>(std::max(widths[c], 1)) + 16);
+      s.col_valid_off[c] = off;
+      off += RoundUp(static_cast<size_t>((n + 63) / 64) * 8 + 8);
+      continue;
+    }
+    s.col_root[c] = AddNode(s, b, b.column_node[static_cast<size_t>(fc)], top_win, true, -1, 0, &off, &tasks, &aux, &aux_fixups);
+    s.col_data_off[c] = s.node_out[static_cast<size_t>(s.col_root[c])].data_off;
+    s.col_valid_off[c] = s.node_out[static_cast<size_t>(s.col_root[c])].valid_off;
   }
   if (has_filter) {
     s.sel_off = off;
@@ -365,46 +501,36 @@ void ArrowScan::EnqueueBatch(Slot& s) {
     off += RoundUp(static_cast<size_t>((n + MI_VECTOR_SIZE - 1) / MI_VECTOR_SIZE) * 4 + 16);
   }
   EnsureSlotBuffers(s, static_cast<size_t>(b.body_size) + 64, off + 64);
-  // H2D of the body on the copy stream
-  if (b.body_size > 0) {
-    MI_HIP_CHECK(hipMemcpyAsync(s.d_in, b.body, static_cast<size_t>(b.body_size), hipMemcpyHostToDevice, ctx->h2d_stream));
-  }
-  MI_HIP_CHECK(hipEventRecord(s.h2d_done, ctx->h2d_stream));
-  // tasks
-  std::vector<mi_col_task> tasks;
-  for (size_t c = 0; c < out_columns.size(); c++) {
-    if (out_columns[c].is_filename || out_columns[c].is_hive) continue;
-    const int32_t fc = src.out_to_file_column[c];
-    mi_col_task t;
-    std::memset(&t, 0, sizeof(t));
-    t.out_data = s.d_out + s.col_data_off[c];
-    t.out_validity = s.d_out + s.col_valid_off[c];
-    if (fc < 0 || n == 0) continue;  // column absent in this file (union_by_name): filled with NULLs below
-    const mi_buffer_span* sp = &b.buffers[static_cast<size_t>(fc) * 3];
-    t.validity = sp[0].length ? s.d_in + sp[0].offset : nullptr;
-    t.buf1 = s.d_in + sp[1].offset;
-    t.buf2 = nbufs[c] > 2 ? s.d_in + sp[2].offset : nullptr;
-    t.buf2_len = nbufs[c] > 2 ? sp[2].length : 0;
-    const int64_t data_off = nbufs[c] > 2 ? sp[2].offset : sp[1].offset;
-    t.ptr_base = opts.device_resident ? reinterpret_cast<uint64_t>(s.d_in + data_off) : reinterpret_cast<uint64_t>(b.body + data_off);
-    t.nrows = n;
-    t.null_count = b.null_count[static_cast<size_t>(fc)];
-    t.kind = kinds[c];
-    t.param = params[c];
-    if (kinds[c] == MI_K_DICT) {
-      auto it = dicts.find(out_columns[c].field.dict_id);
-      if (it == dicts.end()) throw IOException("RecordBatch uses dictionary id " + std::to_string(out_columns[c].field.dict_id) + " before its DictionaryBatch");
-      s.col_dict[c] = it->second;
-      t.param2 = it->second->dict_len;
+  // small tables (list windows, string-view buffers) ride in a pinned aux buffer
+  const size_t aux_bytes = aux.size() * 8;
+  if (aux_bytes) {
+    if (aux_bytes > s.h_aux_cap) {
+      if (s.h_aux) MI_HIP_CHECK(hipHostFree(s.h_aux));
+      if (s.d_aux) MI_HIP_CHECK(hipFree(s.d_aux));
+      s.h_aux_cap = s.d_aux_cap = RoundUp(aux_bytes * 2, 4096);
+      MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.h_aux), s.h_aux_cap, hipHostMallocDefault));
+      MI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s.d_aux), s.d_aux_cap));
     }
-    tasks.push_back(t);
+    std::memcpy(s.h_aux, aux.data(), aux_bytes);
   }
+  for (auto& t : tasks) {
+    t.out_data = s.d_out + reinterpret_cast<size_t>(t.out_data);
+    t.out_validity = s.d_out + reinterpret_cast<size_t>(t.out_validity);
+    const size_t pv = reinterpret_cast<size_t>(t.out_aux);
+    t.out_aux = pv ? s.d_out + (pv - 1) : nullptr;
+  }
+  for (auto& fx : aux_fixups) tasks[fx.first].buf2 = s.d_aux + fx.second * 8;
+  // H2D of the body (+ tables) on the copy stream
+  if (b.body_size > 0)
+    MI_HIP_CHECK(hipMemcpyAsync(s.d_in, b.body, static_cast<size_t>(b.body_size), hipMemcpyHostToDevice, ctx->h2d_stream));
+  if (aux_bytes) MI_HIP_CHECK(hipMemcpyAsync(s.d_aux, s.h_aux, aux_bytes, hipMemcpyHostToDevice, ctx->h2d_stream));
+  MI_HIP_CHECK(hipEventRecord(s.h2d_done, ctx->h2d_stream));
   MI_HIP_CHECK(hipStreamWaitEvent(ctx->stream, s.h2d_done, 0));
   // absent columns: all-NULL vectors (data 0, validity 0)
   for (size_t c = 0; c < out_columns.size(); c++) {
     if (out_columns[c].is_filename || out_columns[c].is_hive) continue;
     if (src.out_to_file_column[c] < 0 && n > 0) {
-      MI_HIP_CHECK(hipMemsetAsync(s.d_out + s.col_data_off[c], 0, static_cast<size_t>(n) * static_cast<size_t>(widths[c]), ctx->stream));
+      MI_HIP_CHECK(hipMemsetAsync(s.d_out + s.col_data_off[c], 0, static_cast<size_t>(n) * static_cast<size_t>(std::max(widths[c], 1)), ctx->stream));
       MI_HIP_CHECK(hipMemsetAsync(s.d_out + s.col_valid_off[c], 0, static_cast<size_t>((n + 63) / 64) * 8, ctx->stream));
     }
   }
@@ -424,6 +550,32 @@ void ArrowScan::EnqueueBatch(Slot& s) {
   // the device status word travels with the results instead of costing a stream-wide synchronisation
   MI_HIP_CHECK(hipMemcpyAsync(s.h_status, s.plan->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->d2h_stream));
   MI_HIP_CHECK(hipEventRecord(s.d2h_done, ctx->d2h_stream));
+}
+
+// The vector of node `node` for chunk window `window` (rows win[window] .. win[window + 1] of the node), children included.
+void ArrowScan::BuildVector(Slot& s, int32_t node, size_t window, uint8_t* base, mi_vector* v) {
+  const Slot::NodeOut& o = s.node_out[static_cast<size_t>(node)];
+  std::memset(v, 0, sizeof(*v));
+  const int64_t r0 = o.win[window], r1 = o.win[window + 1];
+  v->data = base + o.data_off + static_cast<size_t>(r0) * static_cast<size_t>(o.width);
+  v->validity = reinterpret_cast<mi_validity_t*>(base + o.valid_off) + r0 / 64;
+  v->validity_shift = static_cast<int32_t>(r0 % 64);
+  v->kind = o.kind;
+  v->out_width = o.width;
+  v->count = r1 - r0;
+  if (o.kind == MI_K_DICT && o.dict) {
+    v->dictionary = opts.device_resident ? o.dict->d_data : o.dict->h_data;
+    v->dictionary_validity = static_cast<const mi_validity_t*>(opts.device_resident ? o.dict->d_validity : o.dict->h_validity);
+    v->dict_len = o.dict->dict_len;
+  }
+  if (!o.children.empty()) {
+    if (child_pool_used + o.children.size() > child_pool.size()) throw InternalException("nested vector pool exhausted");
+    mi_vector* kids = child_pool.data() + child_pool_used;
+    child_pool_used += o.children.size();
+    for (size_t k = 0; k < o.children.size(); k++) BuildVector(s, o.children[k], window, base, &kids[k]);
+    v->children = kids;
+    v->n_children = static_cast<int32_t>(o.children.size());
+  }
 }
 
 bool ArrowScan::SubmitNextBatch() {
@@ -541,6 +693,8 @@ void ArrowScan::Next(mi_data_chunk* out) {
   Slot& s = slots[cur_slot];
   const int64_t n = std::min<int64_t>(MI_VECTOR_SIZE, s.nrows - cur_row);
   uint8_t* base = opts.device_resident ? s.d_out : s.h_out;
+  if (child_pool.size() < s.node_out.size() + 1) child_pool.resize(s.node_out.size() + 1);
+  child_pool_used = 0;
   Source& src = sources[static_cast<size_t>(s.source)];
   for (size_t c = 0; c < out_columns.size(); c++) {
     mi_vector& v = chunk_vectors[c];
@@ -558,20 +712,20 @@ void ArrowScan::Next(mi_data_chunk* out) {
       v.validity = all_valid.data();
       v.kind = MI_K_STR32;
       v.out_width = 16;
+      v.count = n;
       continue;
     }
-    int32_t kind, w, nb;
-    int64_t param;
-    out_columns[c].field.Plan(&kind, &param, &w, &nb);
-    v.data = base + s.col_data_off[c] + static_cast<size_t>(cur_row) * static_cast<size_t>(w);
-    v.validity = reinterpret_cast<mi_validity_t*>(base + s.col_valid_off[c]) + cur_row / 64;
-    v.kind = kind;
-    v.out_width = w;
-    if (kind == MI_K_DICT && s.col_dict[c]) {
-      const DictState& d = *s.col_dict[c];
-      v.dictionary = opts.device_resident ? d.d_data : d.h_data;
-      v.dictionary_validity = static_cast<const mi_validity_t*>(opts.device_resident ? d.d_validity : d.h_validity);
-      v.dict_len = d.dict_len;
+    if (s.col_root[c] >= 0) {
+      BuildVector(s, s.col_root[c], static_cast<size_t>(cur_row / MI_VECTOR_SIZE), base, &v);
+    } else {  // absent in this file: all NULL
+      int32_t kind, w, nb;
+      int64_t param;
+      out_columns[c].field.Plan(&kind, &param, &w, &nb);
+      v.data = base + s.col_data_off[c] + static_cast<size_t>(cur_row) * static_cast<size_t>(std::max(w, 1));
+      v.validity = reinterpret_cast<mi_validity_t*>(base + s.col_valid_off[c]) + cur_row / 64;
+      v.kind = kind;
+      v.out_width = w;
+      v.count = n;
     }
   }
   out->size = n;

@@ -87,6 +87,19 @@ class ArrowScan {
     int64_t batch_index = 0;
     int64_t nrows = 0;
     std::vector<size_t> col_data_off, col_valid_off;   // per output column, offsets into d_out / h_out
+    //! decoded field nodes of the batch (nested columns have children); col_root[c] = node of output column c (-1: absent)
+    struct NodeOut {
+      size_t data_off = 0, valid_off = 0;
+      int32_t kind = 0, width = 0, arrow_type = 0;
+      int64_t param = 0, nrows = 0;
+      std::vector<int64_t> win;       // first row (in this node's row space) of every top-level 2048-row window, + end
+      std::vector<int32_t> children;
+      std::shared_ptr<DictState> dict;
+    };
+    std::vector<NodeOut> node_out;
+    std::vector<int32_t> col_root;
+    uint8_t* h_aux = nullptr;  size_t h_aux_cap = 0;   // pinned: list window tables, string-view buffer tables
+    uint8_t* d_aux = nullptr;  size_t d_aux_cap = 0;
     size_t sel_off = 0, sel_count_off = 0;             // filter outputs
     std::shared_ptr<void> external_body;               // buffer sources: nothing to own, body is caller memory
     std::vector<std::shared_ptr<DictState>> col_dict;  // per output column: the dictionary version this batch uses
@@ -96,6 +109,10 @@ class ArrowScan {
   void BuildOutputSchema();
   bool SubmitNextBatch();   // reads + enqueues one more record batch; false when all sources are exhausted
   void EnqueueBatch(Slot& s);
+  int32_t AddNode(Slot& s, const DecodedBatch& b, int32_t ni, std::vector<int64_t> win, bool win_is_tiles, int64_t parent_valid_off,
+                  int32_t parent_div, size_t* off, std::vector<mi_col_task>* tasks, std::vector<uint64_t>* aux,
+                  std::vector<std::pair<size_t, size_t>>* aux_fixups);
+  void BuildVector(Slot& s, int32_t node, size_t window, uint8_t* base, mi_vector* out);
   void DecodeDictionary(Source& src, const DecodedBatch& b);
   void EnsureSlotBuffers(Slot& s, size_t in_bytes, size_t out_bytes);
   Slot* FreeSlot();
@@ -121,6 +138,8 @@ class ArrowScan {
   int cur_slot = -1;
   int64_t cur_row = 0;
   std::vector<mi_vector> chunk_vectors;
+  std::vector<mi_vector> child_pool;     // children of nested vectors of the current chunk
+  size_t child_pool_used = 0;
   // constant columns (filename / hive): 2048 string_t each, host
   std::vector<std::vector<mi_string_t>> const_vectors;
   std::vector<mi_validity_t> all_valid;

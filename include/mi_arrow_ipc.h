@@ -383,8 +383,8 @@ int mi_write_options_set(mi_write_options* o, const char* name, const char* valu
 int mi_write_options_add_kv(mi_write_options* o, const char* key, const char* value, int32_t value_len);
 int mi_write_options_finalize(mi_write_options* o);
 
-/* ArrowWriteInitializeGlobal (write_arrow_stream.cpp:127-139): creates the file (fails if it exists, like
- * FILE_FLAGS_FILE_CREATE_NEW, arrow_stream_writer.cpp:49-53) and writes the Schema message.
+/* ArrowWriteInitializeGlobal (write_arrow_stream.cpp:127-139): creates the file, truncating an existing one
+ * (FILE_FLAGS_FILE_CREATE_NEW = create-or-truncate in DuckDB, arrow_stream_writer.cpp:49-53) and writes the Schema message.
  * `fields`: name + duck_type (e.g. "BIGINT", "DECIMAL(15,2)", "VARCHAR", "DATE", "BOOLEAN") per column. */
 int mi_writer_open(mi_ctx* ctx, const char* path, const mi_field* fields, int32_t n_fields,
                    const mi_write_options* opts, mi_writer** out);

@@ -16,6 +16,22 @@ def column_digest(values):
     return hashlib.sha256(json.dumps(values, separators=(",", ":")).encode()).hexdigest()
 
 
+def canon_python(v):
+    """Python values as the host mirror returns them (lists / dicts / (key, value) tuples / bytes / floats) -> the
+    canonical JSON-able form of tests/golden/expected.json."""
+    if v is None or isinstance(v, (bool, int, str)):
+        return v
+    if isinstance(v, (list, tuple)):
+        return [canon_python(x) for x in v]
+    if isinstance(v, dict):
+        return {k: canon_python(x) for k, x in v.items()}
+    if isinstance(v, float):
+        return "nan" if v != v else repr(v)
+    if isinstance(v, (bytes, bytearray)):
+        return "b:" + bytes(v).hex()
+    raise TypeError(type(v))
+
+
 def _fixed(data, ok, dtype):
     vals = data.view(dtype)
     return [vals[i].item() if ok[i] else None for i in range(len(ok))]

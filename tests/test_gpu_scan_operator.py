@@ -11,7 +11,7 @@ import pytest
 import duckdb_arrow_amd as da
 from duckdb_arrow_amd import _ffi
 
-from helpers import column_digest
+from helpers import canon_python, column_digest
 
 pytestmark = pytest.mark.gpu
 
@@ -295,3 +295,44 @@ def test_progress_reaches_100(con, golden_dir):
     assert rel.progress() < 100
     rel.count()
     assert rel.progress() == pytest.approx(100.0, abs=0.5)
+
+
+# ---------------------------------------------------------------------------------------- nested types + string views
+def test_nested_types_and_string_views(con, golden_dir, expected):
+    """Lists, lists of lists, structs, lists of structs, fixed-size lists, maps, large lists, utf8_view / binary_view with
+    NULLs at every level (ArrowToDuckDB list / struct / map / array / view branches, arrow_conversion.cpp in DuckDB):
+    every 2048-row chunk carries child vectors whose list entries are relative to the chunk's child window."""
+    rel = con.read_arrow(g(golden_dir, "edge_nested.arrows"))
+    assert rel.types == ["INTEGER[]", "VARCHAR[]", "BIGINT[][]", "STRUCT(a INTEGER, b VARCHAR)", "STRUCT(x BIGINT, y VARCHAR)[]",
+                         "SMALLINT[3]", "MAP(VARCHAR, INTEGER)", "DOUBLE[]", "VARCHAR", "BLOB"]
+    exp = expected["edge_nested.arrows"]
+    cols = rel.fetch_columns()
+    for name, values in zip(rel.columns, cols):
+        assert len(values) == exp["rows"]
+        assert sum(v is None for v in values) == exp["null_counts"][name], name
+        assert column_digest(canon_python(values)) == exp["columns"][name], name
+
+
+def test_nested_projection_and_buffers(con, golden_dir, expected):
+    """scan_arrow_ipc over in-memory buffers with a projection that keeps only nested columns (in another order)."""
+    data = np.fromfile(g(golden_dir, "edge_nested.arrows"), np.uint8)
+    rel = con.scan_arrow_ipc([data]).project(["mp", "ll", "sv"])
+    exp = expected["edge_nested.arrows"]
+    for name, values in zip(rel.columns, rel.fetch_columns()):
+        assert column_digest(canon_python(values)) == exp["columns"][name], name
+
+
+def test_nested_chunks_are_window_relative(con, golden_dir):
+    """Every chunk's list vector addresses its OWN child vector: offsets start at 0 and end at the child's count."""
+    rel = con.read_arrow(g(golden_dir, "edge_nested.arrows")).project(["l_i"])
+    seen = 0
+    for chunk in rel.chunks():
+        v = chunk.columns[0]
+        assert v.kind == _ffi.K_LIST32 and v.n_children == 1
+        n = chunk.size
+        ent = np.ctypeslib.as_array(_ffi.C.cast(v.data, _ffi.C.POINTER(_ffi.C.c_uint64)), shape=(n * 2,)).reshape(-1, 2)
+        assert int(ent[0, 0]) == 0
+        assert int(ent[-1, 0] + ent[-1, 1]) == v.children[0].count
+        assert np.all(ent[1:, 0] == ent[:-1, 0] + ent[:-1, 1])
+        seen += n
+    assert seen == 6605

@@ -20,7 +20,17 @@ def test_reader_matches_oracle_and_pyarrow_metadata(golden_dir, rel):
     rd = da.Reader(buffers=[buf])
     fields = rd.schema()
     ofields, _, _ = po.decode_schema(buf[po.walk_stream(buf)[0]["meta_off"]:][: po.walk_stream(buf)[0]["meta_len"]])
-    assert [f["name"] for f in fields] == [f["name"] for f in ofields]
+    top, i = [], 0   # the oracle lists fields depth first; keep the top-level ones
+    def skip(i):
+        k = ofields[i]["n_children"]
+        i += 1
+        for _ in range(k):
+            i = skip(i)
+        return i
+    while i < len(ofields):
+        top.append(ofields[i]["name"])
+        i = skip(i)
+    assert [f["name"] for f in fields] == top
     try:
         t = ipc.open_stream(pa.py_buffer(buf)).read_all()
     except pa.ArrowInvalid:
@@ -36,14 +46,15 @@ def test_reader_matches_oracle_and_pyarrow_metadata(golden_dir, rel):
         assert bool(b["is_dictionary"]) == (m["type"] == po.MSG_DICTIONARY_BATCH)
         if not b["is_dictionary"]:
             n += b["length"]
-            # every span the product slices equals the oracle's (flat schemas: <=3 buffers per column, in order)
-            flat = [s for s in b["buffers"] if True]
+            # every span the product slices equals the oracle's: field nodes depth first, each node's buffers in order
+            assert len(b["nodes"]) == len(rb["nodes"])
             k = 0
-            for ci, f in enumerate(fields):
-                nb = 3 if f["kind"] in (_ffi.K_STR32, _ffi.K_STR64) else (0 if f["kind"] == _ffi.K_NULL else 2)
-                assert [tuple(x) for x in flat[3 * ci: 3 * ci + nb]] == [tuple(x) for x in rb["buffers"][k: k + nb]]
-                assert b["null_count"][ci] == rb["nodes"][ci][1]
+            for ni, nd in enumerate(b["nodes"]):
+                nb = len(nd["spans"])
+                assert [tuple(x) for x in nd["spans"]] == [tuple(x) for x in rb["buffers"][k: k + nb]], (ni, nd["name"])
+                assert (nd["length"], nd["null_count"]) == tuple(rb["nodes"][ni][:2])
                 k += nb
+            assert k == len(rb["buffers"])
     assert rd.next_batch(accept_dictionaries=True) is None
     assert n == t.num_rows
 
