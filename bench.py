@@ -162,14 +162,19 @@ def main():
             rc, st = po.scan_stream(buf, max_batches=2)
             per_batch = (time.perf_counter() - t1) / max(1, st["batches"])
             nb = int(max(2, min(len(msgs), args.cpu_seconds / max(per_batch, 1e-6))))
-            t1 = time.perf_counter()
-            rc, st = po.scan_stream(buf, max_batches=nb)
-            dt = time.perf_counter() - t1
-            assert rc == 0
-            cpu_baseline = {"value": st["rows"] / dt, "unit": "rows/s", "cores": 1, "kind": "port",
-                            "sample": "first %d record batches (%d rows, %.2f GB of Arrow buffers) of the same stream, "
-                                      "oracle_scan.c: body copy + FULL offset validation + 2048-row pull loop"
-                                      % (st["batches"], st["rows"], st["bytes_in"] / 1e9),
+            # repeat the pass until ~cpu_seconds of CPU work are on the clock (SF10 is ~1.3 s per pass on one core)
+            dt, rows, passes = 0.0, 0, 0
+            while passes == 0 or (dt < args.cpu_seconds * 0.85 and passes < 64):
+                t1 = time.perf_counter()
+                rc, st = po.scan_stream(buf, max_batches=nb)
+                dt += time.perf_counter() - t1
+                assert rc == 0
+                rows += st["rows"]
+                passes += 1
+            cpu_baseline = {"value": rows / dt, "unit": "rows/s", "cores": 1, "kind": "port",
+                            "sample": "%d pass(es) over the first %d record batches (%d rows, %.2f GB of Arrow buffers) of the "
+                                      "same stream, oracle_scan.c: body copy + FULL offset validation + 2048-row pull loop"
+                                      % (passes, st["batches"], st["rows"], st["bytes_in"] / 1e9),
                             "seconds": dt, "host_cpus": os.cpu_count()}
 
     if rank == 0:
