@@ -422,13 +422,7 @@ class Relation:
         return self
 
     def chunks(self):
-        if not self._initialised:
-            if self._projection:
-                arr = (C.c_char_p * len(self._projection))(*[n.encode() for n in self._projection])
-                _ffi.check(_ffi.lib().mi_scan_init(self._h, arr, len(self._projection)))
-            else:
-                _ffi.check(_ffi.lib().mi_scan_init(self._h, None, 0))
-            self._initialised = True
+        self._init()
         ch = _ffi.DataChunk()
         while True:
             _ffi.check(_ffi.lib().mi_scan_next(self._h, C.byref(ch)))
@@ -452,11 +446,21 @@ class Relation:
         cols = self.fetch_columns()
         return list(zip(*cols)) if cols and cols[0] is not None else []
 
-    def count(self):
-        total = 0
-        for ch in self.chunks():
-            total += ch.sel_count if ch.sel else ch.size
-        return total
+    def _init(self):
+        if not self._initialised:
+            if self._projection:
+                arr = (C.c_char_p * len(self._projection))(*[n.encode() for n in self._projection])
+                _ffi.check(_ffi.lib().mi_scan_init(self._h, arr, len(self._projection)))
+            else:
+                _ffi.check(_ffi.lib().mi_scan_init(self._h, None, 0))
+            self._initialised = True
+
+    def count(self, detail=False):
+        """SELECT count(*) (rows passing the pushed-down filter, if any); the pull loop runs natively."""
+        self._init()
+        rows, sel, chunks = C.c_int64(), C.c_int64(), C.c_int64()
+        _ffi.check(_ffi.lib().mi_scan_count(self._h, C.byref(rows), C.byref(sel), C.byref(chunks)))
+        return dict(rows=rows.value, selected=sel.value, chunks=chunks.value) if detail else sel.value
 
     def progress(self):
         return _ffi.lib().mi_scan_progress(self._h)
@@ -570,13 +574,14 @@ class Connection:
     # -- scan ------------------------------------------------------------------------------------------
     @staticmethod
     def _options(union_by_name=False, filename=False, hive_partitioning=False, rank=0, world=1, device_resident=False,
-                 accept_dictionaries=False, **unknown):
+                 accept_dictionaries=False, zero_copy_direct=False, **unknown):
         for k in unknown:
             # MultiFileFunction rejects unknown named parameters (test/sql/read_arrow.test:40-43)
             raise MiError(_ffi.MI_EINVAL, 'Invalid named parameter "%s" for function read_arrow' % k)
         return _ffi.ScanOptions(union_by_name=int(union_by_name), filename=int(filename),
                                 hive_partitioning=int(hive_partitioning), rank=rank, world=world,
-                                device_resident=int(device_resident), accept_dictionaries=int(accept_dictionaries))
+                                device_resident=int(device_resident), accept_dictionaries=int(accept_dictionaries),
+                                zero_copy_direct=int(zero_copy_direct))
 
     def read_arrow(self, paths, **options):
         """FROM read_arrow('file') / read_arrow(['a', 'b']) / read_arrow('dir/*.arrow') (globs expanded here)."""

@@ -71,7 +71,7 @@ class ColTask(C.Structure):
 class ScanOptions(C.Structure):
     _fields_ = [("union_by_name", C.c_int32), ("filename", C.c_int32), ("hive_partitioning", C.c_int32),
                 ("rank", C.c_int32), ("world", C.c_int32), ("device_resident", C.c_int32),
-                ("accept_dictionaries", C.c_int32), ("_reserved", C.c_int32)]
+                ("accept_dictionaries", C.c_int32), ("zero_copy_direct", C.c_int32)]
 
 
 class Vector(C.Structure):
@@ -146,6 +146,7 @@ SIGNATURES = {
     "mi_scan_init": (C.c_int, [P, C.POINTER(C.c_char_p), C.c_int32]),
     "mi_scan_set_filter_range": (C.c_int, [P, C.c_char_p, C.c_int64, C.c_int64]),
     "mi_scan_next": (C.c_int, [P, C.POINTER(DataChunk)]),
+    "mi_scan_count": (C.c_int, [P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "mi_scan_progress": (C.c_double, [P]),
     "mi_write_options_init": (C.c_int, [C.POINTER(WriteOptions)]),
     "mi_write_options_set": (C.c_int, [C.POINTER(WriteOptions), C.c_char_p, C.c_char_p]),

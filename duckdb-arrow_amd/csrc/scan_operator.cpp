@@ -360,11 +360,21 @@ int32_t ArrowScan::AddNode(Slot& s, const DecodedBatch& b, int32_t ni, std::vect
     o.nrows = n;
     o.arrow_type = nd.field->type;
     o.win = win;
+    // reference behaviour for plain fixed-width columns: the vector aliases the Arrow buffer (DirectConversion) and an
+    // array without NULLs leaves the ValidityMask unset
+    if (opts.zero_copy_direct && kind == MI_K_COPY && nd.null_count == 0 && parent_valid_off < 0 && nd.spans.size() > 1 &&
+        !(has_filter && nd.depth == 0 && ni == filter_node)) {
+      o.alias = (opts.device_resident ? s.d_in : b.body) + nd.spans[1].offset;
+      if (opts.device_resident) s.upload.emplace_back(nd.spans[1].offset, nd.spans[1].length);
+      return idx;
+    }
     o.data_off = *off;
     *off += RoundUp(static_cast<size_t>(n) * static_cast<size_t>(std::max(w, 1)) + 16);
     o.valid_off = *off;
     *off += RoundUp(static_cast<size_t>((n + 63) / 64) * 8 + 8);
   }
+  for (const auto& sp : nd.spans)
+    if (sp.length > 0) s.upload.emplace_back(sp.offset, sp.length);
   const size_t data_off = s.node_out[static_cast<size_t>(idx)].data_off, valid_off = s.node_out[static_cast<size_t>(idx)].valid_off;
   auto span = [&](size_t k) { return k < nd.spans.size() ? nd.spans[k] : mi_buffer_span{0, 0}; };
   auto consumer_addr = [&](int64_t body_offset) {
@@ -475,6 +485,10 @@ void ArrowScan::EnqueueBatch(Slot& s) {
   std::vector<mi_col_task> tasks;
   std::vector<uint64_t> aux;
   std::vector<std::pair<size_t, size_t>> aux_fixups;  // (task index, first aux word)
+  s.upload.clear();
+  filter_node = -1;
+  if (has_filter && src.out_to_file_column[static_cast<size_t>(filter_out_col)] >= 0)
+    filter_node = b.column_node[static_cast<size_t>(src.out_to_file_column[static_cast<size_t>(filter_out_col)])];
   // d_in must be final before tasks take addresses inside it
   EnsureSlotBuffers(s, static_cast<size_t>(b.body_size) + 64, 0);
   for (size_t c = 0; c < out_columns.size(); c++) {
@@ -521,8 +535,30 @@ void ArrowScan::EnqueueBatch(Slot& s) {
   }
   for (auto& fx : aux_fixups) tasks[fx.first].buf2 = s.d_aux + fx.second * 8;
   // H2D of the body (+ tables) on the copy stream
-  if (b.body_size > 0)
-    MI_HIP_CHECK(hipMemcpyAsync(s.d_in, b.body, static_cast<size_t>(b.body_size), hipMemcpyHostToDevice, ctx->h2d_stream));
+  if (b.body_size > 0) {
+    if (!opts.zero_copy_direct) {
+      MI_HIP_CHECK(hipMemcpyAsync(s.d_in, b.body, static_cast<size_t>(b.body_size), hipMemcpyHostToDevice, ctx->h2d_stream));
+    } else {
+      // only what the kernels read: merge the buffer ranges (gaps below 64 KiB are cheaper to copy than to split)
+      std::sort(s.upload.begin(), s.upload.end());
+      int64_t lo = -1, hi = -1;
+      auto flush = [&]() {
+        if (lo < 0) return;
+        hi = std::min<int64_t>((hi + 63) & ~int64_t(63), b.body_size);
+        MI_HIP_CHECK(hipMemcpyAsync(s.d_in + lo, b.body + lo, static_cast<size_t>(hi - lo), hipMemcpyHostToDevice, ctx->h2d_stream));
+      };
+      for (const auto& r : s.upload) {
+        if (lo >= 0 && r.first <= hi + (64 << 10)) {
+          hi = std::max(hi, r.first + r.second);
+          continue;
+        }
+        flush();
+        lo = r.first & ~int64_t(63);
+        hi = r.first + r.second;
+      }
+      flush();
+    }
+  }
   if (aux_bytes) MI_HIP_CHECK(hipMemcpyAsync(s.d_aux, s.h_aux, aux_bytes, hipMemcpyHostToDevice, ctx->h2d_stream));
   MI_HIP_CHECK(hipEventRecord(s.h2d_done, ctx->h2d_stream));
   MI_HIP_CHECK(hipStreamWaitEvent(ctx->stream, s.h2d_done, 0));
@@ -557,9 +593,14 @@ void ArrowScan::BuildVector(Slot& s, int32_t node, size_t window, uint8_t* base,
   const Slot::NodeOut& o = s.node_out[static_cast<size_t>(node)];
   std::memset(v, 0, sizeof(*v));
   const int64_t r0 = o.win[window], r1 = o.win[window + 1];
-  v->data = base + o.data_off + static_cast<size_t>(r0) * static_cast<size_t>(o.width);
-  v->validity = reinterpret_cast<mi_validity_t*>(base + o.valid_off) + r0 / 64;
-  v->validity_shift = static_cast<int32_t>(r0 % 64);
+  if (o.alias) {
+    v->data = const_cast<uint8_t*>(o.alias) + static_cast<size_t>(r0) * static_cast<size_t>(o.width);
+    v->validity = nullptr;  // all valid
+  } else {
+    v->data = base + o.data_off + static_cast<size_t>(r0) * static_cast<size_t>(o.width);
+    v->validity = reinterpret_cast<mi_validity_t*>(base + o.valid_off) + r0 / 64;
+    v->validity_shift = static_cast<int32_t>(r0 % 64);
+  }
   v->kind = o.kind;
   v->out_width = o.width;
   v->count = r1 - r0;
@@ -832,6 +873,24 @@ int mi_scan_next(mi_scan* s, mi_data_chunk* out) {
   return WrapC([&] {
     if (!s || !out) throw InvalidInputException("mi_scan_next: NULL argument");
     s->scan->Next(out);
+  });
+}
+
+int mi_scan_count(mi_scan* s, int64_t* rows, int64_t* selected, int64_t* chunks) {
+  return WrapC([&] {
+    if (!s) throw InvalidInputException("mi_scan_count: NULL argument");
+    int64_t r = 0, sel = 0, n = 0;
+    mi_data_chunk ch;
+    while (true) {
+      s->scan->Next(&ch);
+      if (ch.size == 0) break;
+      r += ch.size;
+      sel += ch.sel ? ch.sel_count : ch.size;
+      n++;
+    }
+    if (rows) *rows = r;
+    if (selected) *selected = sel;
+    if (chunks) *chunks = n;
   });
 }
 

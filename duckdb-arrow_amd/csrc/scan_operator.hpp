@@ -95,7 +95,9 @@ class ArrowScan {
       std::vector<int64_t> win;       // first row (in this node's row space) of every top-level 2048-row window, + end
       std::vector<int32_t> children;
       std::shared_ptr<DictState> dict;
+      const uint8_t* alias = nullptr;  // zero_copy_direct: the values live in the record-batch body, validity = all valid
     };
+    std::vector<std::pair<int64_t, int64_t>> upload;   // body byte ranges the kernels read (everything unless aliasing)
     std::vector<NodeOut> node_out;
     std::vector<int32_t> col_root;
     uint8_t* h_aux = nullptr;  size_t h_aux_cap = 0;   // pinned: list window tables, string-view buffer tables
@@ -140,6 +142,7 @@ class ArrowScan {
   std::vector<mi_vector> chunk_vectors;
   std::vector<mi_vector> child_pool;     // children of nested vectors of the current chunk
   size_t child_pool_used = 0;
+  int32_t filter_node = -1;              // field node of the filter column in the batch being enqueued
   // constant columns (filename / hive): 2048 string_t each, host
   std::vector<std::vector<mi_string_t>> const_vectors;
   std::vector<mi_validity_t> all_valid;

@@ -54,8 +54,10 @@ class HbmStream:
             self.dict_layout[did] = self._add_node(b, b["column_node"][0], _windows(b["length"]), True, extra_rows=1)
         self.layout = []
         for b in self.batches:
+            arena0 = self._off
             cols = [self._add_node(b, ni, _windows(b["length"]), True) for ni in b["column_node"]]
-            self.layout.append(dict(nrows=b["length"], columns=cols, body_off=b["body_file_offset"], body_len=b["body_size"]))
+            self.layout.append(dict(nrows=b["length"], columns=cols, body_off=b["body_file_offset"], body_len=b["body_size"],
+                                    arena=(arena0, self._off)))
         self.out_bytes = self._off
         self.d_out = torch.zeros(max(self._off, 256), dtype=torch.uint8, device=device)
         aux = np.zeros(max(self._aux_bytes // 8, 1), np.uint64)
@@ -159,15 +161,20 @@ class HbmStream:
     def stats(self):
         return self.plan.stats()
 
-    def fetch(self):
-        """D2H of the output arena -> per record batch, per column a node: data bytes + validity words (numpy) + children."""
+    def fetch(self, batches=None):
+        """D2H of the output arena -> per record batch, per column a node: data bytes + validity words (numpy) + children.
+        `batches`: only these record batches (their arena ranges are copied one by one; the result keeps list positions,
+        other entries are None) -- what a sampled check of a table much larger than host memory needs."""
         self.torch.cuda.synchronize()
-        out = self.d_out[: max(self.out_bytes, 1)].cpu().numpy()
+        if batches is None:
+            base = 0
+            out = self.d_out[: max(self.out_bytes, 1)].cpu().numpy()
+        want = None if batches is None else set(batches)
 
         def node(e, dict_extra=0):
             n = e["nrows"]
-            d = out[e["data_off"]: e["data_off"] + n * e["width"]].copy()
-            v = out[e["valid_off"]: e["valid_off"] + ((n + 63) // 64) * 8].copy().view(np.uint64)
+            d = out[e["data_off"] - base: e["data_off"] - base + n * e["width"]].copy()
+            v = out[e["valid_off"] - base: e["valid_off"] - base + ((n + 63) // 64) * 8].copy().view(np.uint64)
             r = dict(name=e["name"], kind=e["kind"], param=e["param"], width=e["width"], data=d, validity=v, rc=0, nrows=n,
                      buffers=e["buffers"], ptr_base=e["ptr_base"], null_count=e["null_count"], win=e["win"],
                      children=[node(c) for c in e["children"]])
@@ -175,6 +182,17 @@ class HbmStream:
                 r["dictionary"] = dicts[e["dict_id"]]
             return r
 
+        if batches is not None:   # dictionaries sit at the start of the arena, before the first record batch
+            base, end = 0, (self.layout[0]["arena"][0] if self.layout else self.out_bytes)
+            out = self.d_out[base: max(end, 1)].cpu().numpy()
         dicts = {did: node(e) for did, e in self.dict_layout.items()}
-        return [dict(nrows=b["nrows"], columns=[node(e) for e in b["columns"]], body_off=b["body_off"], body_len=b["body_len"])
-                for b in self.layout]
+        res = []
+        for bi, b in enumerate(self.layout):
+            if want is not None:
+                if bi not in want:
+                    res.append(None)
+                    continue
+                base, end = b["arena"]
+                out = self.d_out[base: max(end, base + 1)].cpu().numpy()
+            res.append(dict(nrows=b["nrows"], columns=[node(e) for e in b["columns"]], body_off=b["body_off"], body_len=b["body_len"]))
+        return res

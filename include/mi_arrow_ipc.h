@@ -300,7 +300,11 @@ typedef struct mi_scan_options {
   int32_t world;                /* 0 or 1 = no sharding */
   int32_t device_resident;      /* 1: chunks stay in HBM (pointers are device addresses), no D2H */
   int32_t accept_dictionaries;  /* 1: decode DictionaryBatch + dictionary-encoded columns (beyond the reference) */
-  int32_t _reserved;
+  int32_t zero_copy_direct;     /* 1: fixed-width columns that need no conversion and hold no NULLs are not copied: the
+                                 * vector's data points INTO the record-batch body (host body for host consumers, which
+                                 * then is not DMA'd to the GPU at all; HBM copy of the body when device_resident) and
+                                 * its validity is NULL = all valid -- the reference's zero-copy DirectConversion +
+                                 * unset ValidityMask.  The body stays alive until the chunk after the batch's last. */
 } mi_scan_options;
 
 /* read_arrow('path') / read_arrow(['a','b']) (read_arrow.cpp:78-83).  Globs are expanded by the caller. */
@@ -350,6 +354,9 @@ typedef struct mi_data_chunk {
  * yields the same rows).  Chunks then carry a selection vector. Call between bind and the first next. */
 int mi_scan_set_filter_range(mi_scan* s, const char* column, int64_t lo, int64_t hi);
 int mi_scan_next(mi_scan* s, mi_data_chunk* out);
+/* SELECT count(*) FROM read_arrow(...) (test/sql/read_arrow.test:35-38): pulls every remaining chunk natively.
+ * rows = scanned, selected = rows passing the pushed-down filter (== rows without one), chunks = DataChunks seen. */
+int mi_scan_count(mi_scan* s, int64_t* rows, int64_t* selected, int64_t* chunks);
 double mi_scan_progress(mi_scan* s);
 
 /* ---------------------------------------------------------------------------------------------------------

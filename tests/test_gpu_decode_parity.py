@@ -81,6 +81,9 @@ def test_synthetic_lineitem_bit_exact(ctx, with_validity):
     assert hs.status() == 0
     _, want = po.decode_stream(buf)
     assert_streams_equal(hs.fetch(), want)
+    part = hs.fetch(batches=[1, len(want) - 1])   # sampled fetch (what bench.py uses for tables larger than host memory)
+    assert part[0] is None and [i for i, b in enumerate(part) if b is not None] == [1, len(want) - 1]
+    assert_streams_equal([part[1], part[-1]], [want[1], want[-1]])
     st = hs.stats()
     assert st["rows"] == 16 * info["n_rows"]
     # algorithmic bytes: 158 B/row written; ~174.85 (172.85 without bitmaps, which are skipped when null_count = 0)
