@@ -130,6 +130,27 @@ def main():
     status = hs.status()
     assert status == 0, "device status %d" % status
 
+    # ---- secondary, never `value`: the same scan when plain fixed-width columns alias the IPC body in HBM (the
+    # reference's zero-copy DirectConversion, mi_scan_options.zero_copy_direct) -- only columns that need work run ----
+    zc = None
+    if world == 1:
+        zp = hs.zero_copy_plan()
+        for _ in range(max(1, args.warmup)):
+            zp.launch(stream)
+        torch.cuda.synchronize()
+        t_z = time.perf_counter()
+        for _ in range(args.steps):
+            zp.launch(stream)
+        torch.cuda.synchronize()
+        dz = time.perf_counter() - t_z
+        zst = zp.stats()
+        zc = {"ms_per_step": dz / args.steps * 1e3, "rows_per_s": info["n_rows"] * args.steps / dz,
+              "algorithmic_bytes_per_row": (zst["bytes_read"] + zst["bytes_written"]) / info["n_rows"],
+              "achieved_GBps": (zst["bytes_read"] + zst["bytes_written"]) * args.steps / dz / 1e9,
+              "tasks": zp.n_tasks, "of_tasks": hs.plan.n_tasks,
+              "note": "secondary figure, not `value`: int64 keys and date32 columns are not materialised, their vectors "
+                      "point into the record-batch body in HBM exactly as the reference's vectors point into the Arrow buffer"}
+
     # ---- per-kernel HIP-event timings (same stream, same launches, outside the timed region) ----
     per_class = np.zeros(6)
     reps = max(3, min(args.steps, 10))
@@ -226,7 +247,7 @@ def main():
                          "whole_step_frac": alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "kernels": kernels,
             "cpu_baseline": cpu_baseline,
-            "parity": parity,
+            "parity": parity, "zero_copy_direct": zc,
             "setup_seconds": {"generate": t_gen, "parse_upload_plan": t_upload},
         }
         print(json.dumps(out))

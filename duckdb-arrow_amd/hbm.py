@@ -66,7 +66,10 @@ class HbmStream:
         self.d_aux = torch.from_numpy(aux.view(np.uint8).copy()).to(device)
         ibase, obase, abase = self.d_in.data_ptr(), self.d_out.data_ptr(), self.d_aux.data_ptr()
         ctasks = []
+        self._aliasable = []   # plain fixed-width top-level columns without NULLs: zero-copy candidates
         for e, t in self._tasks:
+            self._aliasable.append(t["kind"] == _ffi.K_COPY and t["null_count"] == 0 and t["depth"] == 0)
+            e["alias_addr"] = (ibase + t["buf1"]) if self._aliasable[-1] else 0
             ctasks.append(make_task(
                 t["kind"], t["nrows"], ibase + t["buf1"] if t["buf1"] is not None else 0, obase + e["data_off"],
                 validity=(ibase + t["validity"]) if t["validity"] is not None else 0,
@@ -76,7 +79,17 @@ class HbmStream:
                 ptr_base=t.get("ptr_base", 0), buf2_len=t.get("buf2_len", 0), param=t.get("param", 0), param2=t.get("param2", 0),
                 null_count=t["null_count"], depth=t["depth"], parent_div=t.get("parent_div", 0)))
         self.plan = Plan(ctx, ctasks)
+        self._ctasks = ctasks
+        self._zero_copy_plan = None
         self.n_rows = sum(b["length"] for b in self.batches)
+
+    def zero_copy_plan(self):
+        """The plan a device-resident consumer needs when plain fixed-width columns alias the IPC body in HBM (the
+        reference's zero-copy DirectConversion; mi_scan_options.zero_copy_direct): only the columns that really need a
+        transcode keep their task; the aliased vectors are entry["alias_addr"] with validity = all valid."""
+        if self._zero_copy_plan is None:
+            self._zero_copy_plan = Plan(self.ctx, [t for t, a in zip(self._ctasks, self._aliasable) if not a])
+        return self._zero_copy_plan
 
     # ------------------------------------------------------------------------------------------------ layout
     def _alloc(self, rows, width):

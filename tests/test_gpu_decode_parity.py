@@ -301,3 +301,29 @@ def test_sf1_lineitem_properties_and_sampled_parity(ctx, torch):
         shift = m["prefix_off"] - msgs[0]["prefix_off"]
         _, want = po.decode_stream(sub, ptr_base_of=lambda i, body_off, boff: body_off + boff + shift)
         assert_streams_equal([got[bi]], want)
+
+
+def test_zero_copy_plan_leaves_direct_columns_in_the_body(ctx):
+    """HbmStream.zero_copy_plan(): int64 / date32 columns without NULLs get no task -- their vector is the Arrow buffer in
+    HBM (alias_addr) -- and every other column is transcoded exactly as in the full plan."""
+    import torch
+    from duckdb_arrow_amd.hbm import HbmStream
+    buf, info = da.synth_lineitem_stream(scale_factor=0.02, seed=5)
+    hs = HbmStream(ctx, buf)
+    _, want = po.decode_stream(buf)
+    zp = hs.zero_copy_plan()
+    assert zp.n_tasks == hs.plan.n_tasks * 9 // 16        # 7 of lineitem's 16 columns are plain fixed width
+    hs.d_out.zero_()
+    zp.launch(torch.cuda.current_stream().cuda_stream)
+    assert zp.status() == 0
+    got = hs.fetch()
+    base = hs.d_in.data_ptr()
+    d_in = hs.d_in.cpu().numpy()
+    for gb, wb, lay in zip(got, want, hs.layout):
+        for gc, wc, e in zip(gb["columns"], wb["columns"], lay["columns"]):
+            if e["alias_addr"]:
+                assert not gc["data"].any()   # untouched arena
+                a = e["alias_addr"] - base
+                assert np.array_equal(d_in[a: a + wc["data"].size], wc["data"]), gc["name"]
+            else:
+                assert_nodes_equal(gc, wc, gc["name"])
