@@ -268,7 +268,7 @@ void Plan::Set(const mi_col_task* in_tasks, int32_t n_tasks, hipStream_t upload_
         const uint64_t nt = static_cast<uint64_t>((t.nrows + tile_rows - 1) / tile_rows);
         tiles += nt;
         if (tiles > 0xFFFFFFF0ull) throw InvalidInputException("plan has too many tiles");
-        if (c < device::kClassEncFixed) tile_task.insert(tile_task.end(), static_cast<size_t>(nt), local_task);
+        tile_task.insert(tile_task.end(), static_cast<size_t>(nt), local_task);
         order[i] = {static_cast<int>(slices.size()), static_cast<int32_t>(local_task)};
         local_task++;
         tasks.push_back(t);
@@ -347,17 +347,18 @@ void Plan::LaunchSlice(const ClassSlice& cs, hipStream_t s) {
   if (cs.total_tiles == 0) return;
   const mi_col_task* t = d_tasks + cs.first_task;
   const uint32_t* tb = d_tile_begin + cs.tile_begin_at;
+  const uint32_t* tt = d_tile_task + cs.tile_task_at;
   switch (cs.cls) {
     case device::kClassEncFixed:
-      MI_HIP_CHECK(device::LaunchEncodeFixed(t, tb, cs.n_tasks, cs.total_tiles, d_null_counts, grid, s));
+      MI_HIP_CHECK(device::LaunchEncodeFixed(t, tb, tt, cs.n_tasks, cs.total_tiles, d_null_counts, grid, s));
       break;
     case device::kClassEncString:
-      MI_HIP_CHECK(device::LaunchEncodeStringTileSums(t, tb, cs.n_tasks, cs.total_tiles, d_tile_sums, grid, s));
+      MI_HIP_CHECK(device::LaunchEncodeStringTileSums(t, tb, tt, cs.n_tasks, cs.total_tiles, d_tile_sums, grid, s));
       MI_HIP_CHECK(device::LaunchEncodeStringScan(t, tb, cs.n_tasks, d_tile_sums, d_status, s));
-      MI_HIP_CHECK(device::LaunchEncodeString(t, tb, cs.n_tasks, cs.total_tiles, d_tile_sums, d_null_counts, grid, s));
+      MI_HIP_CHECK(device::LaunchEncodeString(t, tb, tt, cs.n_tasks, cs.total_tiles, d_tile_sums, d_null_counts, grid, s));
       break;
     default:
-      MI_HIP_CHECK(device::LaunchTranscode(cs.cls, t, tb, d_tile_task + cs.tile_task_at, cs.n_tasks, cs.total_tiles, d_status,
+      MI_HIP_CHECK(device::LaunchTranscode(cs.cls, t, tb, tt, cs.n_tasks, cs.total_tiles, d_status,
                                            ctx->num_cus, s));
       break;
   }

@@ -792,7 +792,8 @@ __global__ __launch_bounds__(kBlockThreads) void filter_range(const T* __restric
 
 // K7a: DuckDB validity words have Arrow's bit order and polarity, so the bitmap is a byte copy of the words with
 // the pad bits of the last byte forced to 1 (ResizeValidity fills with 0xFF) and NULLs counted on the way.
-__device__ __forceinline__ void enc_tile_validity(const mi_col_task& t, int64_t row0, int n, int64_t* null_counts) {
+__device__ __forceinline__ void enc_tile_validity(const mi_col_task& t, int64_t row0, int n, int64_t* null_counts,
+                                                  uint64_t* s_valid = nullptr) {
   const int lane = threadIdx.x;
   const int nwords = (n + 63) >> 6;
   if (lane >= nwords) return;
@@ -800,6 +801,7 @@ __device__ __forceinline__ void enc_tile_validity(const mi_col_task& t, int64_t 
   if (t.validity != nullptr) w = GC<uint64_t>(t.validity)[(row0 >> 6) + lane];
   const int rem = n - 64 * lane;
   if (rem < 64) w |= ~0ull << rem;
+  if (s_valid) s_valid[lane] = w;
   const int nulls = 64 - __builtin_popcountll(w);
   if (nulls) atomicAdd(reinterpret_cast<unsigned long long*>(null_counts + t.param2), static_cast<unsigned long long>(nulls));
   gptr<uint8_t> out = GM<uint8_t>(t.out_validity) + (row0 >> 3) + 8 * lane;
@@ -849,9 +851,8 @@ __device__ __forceinline__ void enc_tile_bool(const mi_col_task& t, int64_t row0
 }
 
 __global__ __launch_bounds__(kBlockThreads) void encode_fixed(const mi_col_task* __restrict__ tasks,
-                                                              const uint32_t* __restrict__ tile_begin, int n_tasks,
+                                                              const uint32_t* __restrict__ tile_begin, const uint32_t* __restrict__ tile_task, int n_tasks,
                                                               uint32_t total_tiles, int64_t* __restrict__ null_counts) {
-  const uint32_t* tile_task = nullptr;
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     MI_TILE_PROLOGUE();
     enc_tile_validity(t, row0, n, null_counts);
@@ -895,11 +896,10 @@ __device__ __forceinline__ int64_t block_exclusive_scan(int64_t v, int64_t* tota
 
 // K7d pass 1: payload bytes per tile (valid rows only) -> tile_sums[tile]
 __global__ __launch_bounds__(kBlockThreads) void encode_string_tile_sums(const mi_col_task* __restrict__ tasks,
-                                                                         const uint32_t* __restrict__ tile_begin,
+                                                                         const uint32_t* __restrict__ tile_begin, const uint32_t* __restrict__ tile_task,
                                                                          int n_tasks, uint32_t total_tiles,
                                                                          int64_t* __restrict__ tile_sums) {
   __shared__ int64_t lds4[kBlockThreads / 64];
-  const uint32_t* tile_task = nullptr;
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     MI_TILE_PROLOGUE();
     gptr<const uint32_t> lens = GC<uint32_t>(t.buf1) + 4 * row0;  // string_t.length every 16 B
@@ -943,87 +943,297 @@ __global__ __launch_bounds__(kBlockThreads) void encode_string_scan(const mi_col
 // payload exceeds the LDS stage falls back to direct byte stores.
 constexpr int kEncStage = 16 * 1024;  // bytes of payload staged per 256-row sub-block (16 KB x 8 workgroups per CU)
 
+// One tile of K7d pass 3 with 64-bit positions: sub-block by sub-block (256 rows), byte-wise LDS assembly, a sub-block
+// whose payload exceeds the stage falls back to direct byte stores.  The original formulation; now the fallback of
+// encode_string_v5 for tiles that hold a string of >= 8 MiB, and variant 0 of the A/B knob.
+__device__ __forceinline__ void encode_string_tile_generic(const mi_col_task& t, int64_t row0, int n, int64_t base,
+                                                           int64_t* lds4, uint8_t* stage) {
+  gptr<const u32x4> str = GC<u32x4>(t.buf1) + row0;
+  gptr<const uint64_t> valid = GC<uint64_t>(t.validity);
+  const bool has = t.validity != nullptr;
+  gptr<const uint8_t> heap = GC<uint8_t>(t.buf2);
+  gptr<int32_t> off = GM<int32_t>(t.out_data);
+  gptr<uint8_t> data = GM<uint8_t>(t.out_aux);
+  if (row0 == 0 && threadIdx.x == 0) off[0] = 0;
+  for (int k = 0; k < kTileRows / kBlockThreads; k++) {
+    const int r = threadIdx.x + k * kBlockThreads;
+    if (k * kBlockThreads >= n) break;  // uniform
+    u32x4 s = {0u, 0u, 0u, 0u};
+    uint32_t len = 0;
+    if (r < n) {
+      s = str[r];
+      len = enc_row_valid(valid, has, row0 + r) ? s.x : 0u;
+    }
+    int64_t total;
+    const int64_t ex = block_exclusive_scan(static_cast<int64_t>(len), &total, lds4);
+    const int64_t pos = base + ex;
+    if (r < n) off[row0 + r + 1] = static_cast<int32_t>(pos + len);
+    // LDS image: byte i of the sub-block's payload lives at stage[shift + i], shift = base mod 16, so that 16-byte
+    // aligned global addresses are 16-byte aligned LDS addresses
+    const int shift = static_cast<int>(base & 15);
+    const bool staged = total + shift <= kEncStage;
+    uint8_t* dst_l = stage + shift + static_cast<int>(ex);
+    gptr<uint8_t> dst_g = data + pos;
+    if (len != 0) {
+      if (s.x <= 12) {
+        const uint32_t w0 = s.y, w1 = s.z, w2 = s.w;
+        for (uint32_t j = 0; j < len; j++) {
+          const uint32_t w = j < 4 ? w0 : (j < 8 ? w1 : w2);
+          const uint8_t byte = static_cast<uint8_t>(w >> (8 * (j & 3)));
+          if (staged) dst_l[j] = byte; else dst_g[j] = byte;
+        }
+      } else {
+        const uint64_t p = static_cast<uint64_t>(s.z) | (static_cast<uint64_t>(s.w) << 32);
+        gptr<const uint8_t> src = heap + (p - t.ptr_base);
+        const uint32_t mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(src) & 3);
+        gptr<const uint32_t> q = (gptr<const uint32_t>)(src - mis);
+        const uint32_t ndw = (mis + len + 3) >> 2;
+        uint32_t j = 0;
+        for (uint32_t d = 0; d < ndw; d++) {
+          const uint32_t w = q[d];
+          const uint32_t first = d == 0 ? mis : 0;
+          for (uint32_t bidx = first; bidx < 4 && j < len; bidx++, j++) {
+            const uint8_t byte = static_cast<uint8_t>(w >> (8 * bidx));
+            if (staged) dst_l[j] = byte; else dst_g[j] = byte;
+          }
+        }
+      }
+    }
+    if (staged) {
+      __syncthreads();
+      // stage[shift .. shift+total) -> data[base .. base+total): unaligned head and tail bytewise, the middle as 16-byte rows
+      const int64_t g0 = base, g1 = base + total;
+      const int64_t a0 = (g0 + 15) & ~static_cast<int64_t>(15), a1 = g1 & ~static_cast<int64_t>(15);
+      if (a0 >= a1) {
+        for (int64_t i = g0 + threadIdx.x; i < g1; i += kBlockThreads) data[i] = stage[shift + (i - g0)];
+      } else {
+        for (int64_t i = g0 + threadIdx.x; i < a0; i += kBlockThreads) data[i] = stage[shift + (i - g0)];
+        for (int64_t i = a1 + threadIdx.x; i < g1; i += kBlockThreads) data[i] = stage[shift + (i - g0)];
+        const int nvec = static_cast<int>((a1 - a0) >> 4);
+        const u32x4* ls = reinterpret_cast<const u32x4*>(stage + shift + (a0 - g0));
+        gptr<u32x4> gd = (gptr<u32x4>)(data + a0);
+        for (int i = threadIdx.x; i < nvec; i += kBlockThreads) __builtin_nontemporal_store(ls[i], gd + i);
+      }
+      __syncthreads();
+    }
+    base += total;
+  }
+}
+
 __global__ __launch_bounds__(kBlockThreads) void encode_string(const mi_col_task* __restrict__ tasks,
-                                                               const uint32_t* __restrict__ tile_begin, int n_tasks,
+                                                               const uint32_t* __restrict__ tile_begin,
+                                                               const uint32_t* __restrict__ tile_task, int n_tasks,
                                                                uint32_t total_tiles, const int64_t* __restrict__ tile_sums,
                                                                int64_t* __restrict__ null_counts) {
   __shared__ int64_t lds4[kBlockThreads / 64];
   __shared__ __attribute__((aligned(16))) uint8_t stage[kEncStage + 16];
-  const uint32_t* tile_task = nullptr;
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     MI_TILE_PROLOGUE();
     enc_tile_validity(t, row0, n, null_counts);
+    encode_string_tile_generic(t, row0, n, tile_sums[tile], lds4, stage);
+    __syncthreads();
+  }
+}
+
+// ---- dword-granular LDS assembly ------------------------------------------------------------------------------
+// W[0..N] hold a source byte stream that starts at byte `sh` (0..3) of W[0] (W[N+1] readable, zero); writes its first
+// cnt <= 4N bytes at dst (LDS): <= 3 head bytes up to dst's 4-byte boundary, whole dwords funnel-shifted to the
+// destination phase with v_alignbyte_b32, <= 3 tail bytes.  Straight-line code (predicated stores, no loops): the
+// kernel is bound by VALU issue, not by memory.  W is consumed (shifted in place).
+template <int N>
+__device__ __forceinline__ void lds_put_stream(uint8_t* dst, uint32_t (&W)[N + 2], uint32_t sh, uint32_t cnt) {
+  const uint32_t dm = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dst)) & 3u;
+  uint32_t head = (4u - dm) & 3u;
+  if (head > cnt) head = cnt;
+  const uint32_t first = __builtin_amdgcn_alignbyte(W[1], W[0], sh);
+  if (head > 0) dst[0] = static_cast<uint8_t>(first);
+  if (head > 1) dst[1] = static_cast<uint8_t>(first >> 8);
+  if (head > 2) dst[2] = static_cast<uint8_t>(first >> 16);
+  uint32_t tsh = sh + head;  // 0..6: where the dword stream starts inside W
+  if (tsh >= 4) {
+#pragma unroll
+    for (int i = 0; i <= N; i++) W[i] = W[i + 1];
+    tsh -= 4;
+  }
+  const uint32_t nd = (cnt - head) >> 2;
+  uint32_t* d4 = reinterpret_cast<uint32_t*>(dst + head);
+  uint32_t tailw = 0;
+#pragma unroll
+  for (int i = 0; i <= N; i++) {
+    const uint32_t v = __builtin_amdgcn_alignbyte(W[i + 1], W[i], tsh);
+    if (static_cast<uint32_t>(i) < nd) d4[i] = v;
+    if (static_cast<uint32_t>(i) == nd) tailw = v;
+  }
+  const uint32_t tc = (cnt - head) & 3u;
+  uint8_t* tp = dst + head + 4 * nd;
+  if (tc > 0) tp[0] = static_cast<uint8_t>(tailw);
+  if (tc > 1) tp[1] = static_cast<uint8_t>(tailw >> 8);
+  if (tc > 2) tp[2] = static_cast<uint8_t>(tailw >> 16);
+}
+
+// The first <= 48 bytes of a heap string starting at `src`: 13 aligned dwords cover them at any misalignment.
+__device__ __forceinline__ void heap_load13(gptr<const uint8_t> src, uint32_t cnt, uint32_t (&W)[14]) {
+  const uint32_t mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(src) & 3);
+  gptr<const uint32_t> q = (gptr<const uint32_t>)(src - mis);
+  const uint32_t ndw = (mis + (cnt < 48u ? cnt : 48u) + 3) >> 2;
+#pragma unroll
+  for (int d = 0; d < 13; d++) W[d] = static_cast<uint32_t>(d) < ndw ? __builtin_nontemporal_load(q + d) : 0u;
+  W[13] = 0u;
+}
+
+// Bytes [c0, c0 + cnt) of one string -> LDS at dst.  W: the string's first 48 heap bytes (heap_load13 of the string
+// start) when it is a long string; it is used when c0 == 0 and is scratch otherwise.
+__device__ __forceinline__ void string_bytes_to_lds(uint8_t* dst, const u32x4& s, gptr<const uint8_t> heap, uint64_t ptr_base,
+                                                    uint32_t c0, uint32_t cnt, uint32_t (&W)[14]) {
+  if (s.x <= 12) {
+    uint32_t a = s.y, b = s.z, c = s.w;
+    if (c0 >= 8) { a = c; b = 0u; c = 0u; }
+    else if (c0 >= 4) { a = b; b = c; c = 0u; }
+    uint32_t S[5] = {a, b, c, 0u, 0u};
+    lds_put_stream<3>(dst, S, c0 & 3u, cnt);
+    return;
+  }
+  const uint64_t p = static_cast<uint64_t>(s.z) | (static_cast<uint64_t>(s.w) << 32);
+  gptr<const uint8_t> src = heap + (p - ptr_base) + c0;
+  const uint32_t mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(src) & 3);
+  uint32_t done = 0;
+  if (c0 == 0) {
+    lds_put_stream<12>(dst, W, mis, cnt < 48u ? cnt : 48u);
+    done = 48;
+  }
+#pragma clang loop unroll(disable)
+  for (; done < cnt; done += 48) {
+    heap_load13(src + done, cnt - done, W);
+    lds_put_stream<12>(dst + done, W, mis, cnt - done < 48u ? cnt - done : 48u);
+  }
+}
+
+// Inclusive wave64 scan on the DPP crossbar (no LDS traffic): row_shr 1/2/4/8 inside each 16-lane row, then
+// row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3.
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v) {
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x111, 0xf, 0xf, false));
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x112, 0xf, 0xf, false));
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x114, 0xf, 0xf, false));
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x118, 0xf, 0xf, false));
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x142, 0xa, 0xf, false));
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x143, 0xc, 0xf, false));
+  return v;
+}
+
+// K7d pass 3, the shipped formulation.  Same outputs as encode_string (kept as variant 0 of the A/B knob and as the
+// fallback for sub-blocks with huge strings).  rocprofv3 counters showed the first formulations bound by VALU issue
+// (1.1 G wave-instructions per SF10 table, 165 per 64 one-byte strings), not by HBM, so everything here is about fewer
+// instructions per row and fewer dependent round trips:
+//  * the tile's validity words are fetched once (LDS); the NEXT sub-block's string_t is requested (clamped address,
+//    so unconditionally) before this one is touched;
+//  * a long string's first 48 heap bytes arrive as ONE batch of 13 aligned dword loads (the original walked the string
+//    one dependent dword at a time: 7 HBM round trips for a 27-byte l_comment);
+//  * the scan is a 6-step DPP wave scan + one LDS exchange of the 4 wave totals, in 32-bit arithmetic (a sub-block
+//    holding a string of >= 8 MiB is handed to the 64-bit formulation);
+//  * payload is assembled in LDS with dword stores (source stream funnel-shifted with v_alignbyte_b32 to the string
+//    start, then to the destination's 4-byte phase; <= 3 head and <= 3 tail byte stores, all predicated straight-line
+//    code), in windows of <= 8 KiB so a sub-block of any size is staged; two stage buffers alternate: one barrier per
+//    window; all positions inside a sub-block are 32-bit;
+//  * the stage leaves as coalesced 16-byte nontemporal stores through a 16-byte aligned uniform base pointer.
+constexpr uint32_t kEncBigLen = 1u << 23;
+constexpr int kEncStage5 = 8 * 1024;       // bytes per stage buffer
+constexpr int kEncStageBuf = kEncStage5 + 64;
+static_assert(2 * kEncStageBuf >= kEncStage + 16, "the 64-bit formulation borrows both stage buffers");
+
+template <int OCC>
+__global__ __launch_bounds__(kBlockThreads, OCC) void encode_string_v5(const mi_col_task* __restrict__ tasks,
+                                                                  const uint32_t* __restrict__ tile_begin,
+                                                                  const uint32_t* __restrict__ tile_task, int n_tasks,
+                                                                  uint32_t total_tiles, const int64_t* __restrict__ tile_sums,
+                                                                  int64_t* __restrict__ null_counts) {
+  constexpr int kWaves = kBlockThreads / 64;
+  static_assert(kWaves == 4, "wave totals travel as one 16-byte LDS row");
+  __shared__ int64_t lds4[kWaves];
+  __shared__ uint64_t s_valid[kTileRows / 64];
+  __shared__ __attribute__((aligned(16))) uint32_t s_tot[2][kWaves];
+  __shared__ __attribute__((aligned(16))) uint8_t stage[2 * kEncStageBuf];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    MI_TILE_PROLOGUE();
+    enc_tile_validity(t, row0, n, null_counts, s_valid);
     gptr<const u32x4> str = GC<u32x4>(t.buf1) + row0;
-    gptr<const uint64_t> valid = GC<uint64_t>(t.validity);
-    const bool has = t.validity != nullptr;
     gptr<const uint8_t> heap = GC<uint8_t>(t.buf2);
-    gptr<int32_t> off = GM<int32_t>(t.out_data);
+    gptr<int32_t> offp = GM<int32_t>(t.out_data) + row0 + 1;
     gptr<uint8_t> data = GM<uint8_t>(t.out_aux);
     int64_t base = tile_sums[tile];
-    if (row0 == 0 && threadIdx.x == 0) off[0] = 0;
-    for (int k = 0; k < kTileRows / kBlockThreads; k++) {
+    if (row0 == 0 && threadIdx.x == 0) offp[-1] = 0;
+    const int nsub = (n + kBlockThreads - 1) / kBlockThreads;
+    u32x4 nxt = __builtin_nontemporal_load(str + (static_cast<int>(threadIdx.x) < n ? static_cast<int>(threadIdx.x) : n - 1));
+    __syncthreads();  // s_valid
+    uint32_t buf = 0;
+#pragma clang loop unroll(disable)
+    for (int k = 0; k < nsub; k++) {
       const int r = threadIdx.x + k * kBlockThreads;
-      if (k * kBlockThreads >= n) break;  // uniform
-      u32x4 s = {0u, 0u, 0u, 0u};
-      uint32_t len = 0;
-      if (r < n) {
-        s = str[r];
-        len = enc_row_valid(valid, has, row0 + r) ? s.x : 0u;
+      const u32x4 s = nxt;
+      {
+        const int rn = r + kBlockThreads;
+        nxt = __builtin_nontemporal_load(str + (rn < n ? rn : n - 1));
       }
-      int64_t total;
-      const int64_t ex = block_exclusive_scan(static_cast<int64_t>(len), &total, lds4);
-      const int64_t pos = base + ex;
-      if (r < n) off[row0 + r + 1] = static_cast<int32_t>(pos + len);
-      // LDS image: byte i of the sub-block's payload lives at stage[shift + i], shift = base mod 16, so that 16-byte
-      // aligned global addresses are 16-byte aligned LDS addresses
-      const int shift = static_cast<int>(base & 15);
-      const bool staged = total + shift <= kEncStage;
-      uint8_t* dst_l = stage + shift + static_cast<int>(ex);
-      gptr<uint8_t> dst_g = data + pos;
-      if (len != 0) {
-        if (s.x <= 12) {
-          const uint32_t w0 = s.y, w1 = s.z, w2 = s.w;
-          for (uint32_t j = 0; j < len; j++) {
-            const uint32_t w = j < 4 ? w0 : (j < 8 ? w1 : w2);
-            const uint8_t byte = static_cast<uint8_t>(w >> (8 * (j & 3)));
-            if (staged) dst_l[j] = byte; else dst_g[j] = byte;
-          }
-        } else {
-          const uint64_t p = static_cast<uint64_t>(s.z) | (static_cast<uint64_t>(s.w) << 32);
-          gptr<const uint8_t> src = heap + (p - t.ptr_base);
-          const uint32_t mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(src) & 3);
-          gptr<const uint32_t> q = (gptr<const uint32_t>)(src - mis);
-          const uint32_t ndw = (mis + len + 3) >> 2;
-          uint32_t j = 0;
-          for (uint32_t d = 0; d < ndw; d++) {
-            const uint32_t w = q[d];
-            const uint32_t first = d == 0 ? mis : 0;
-            for (uint32_t bidx = first; bidx < 4 && j < len; bidx++, j++) {
-              const uint8_t byte = static_cast<uint8_t>(w >> (8 * bidx));
-              if (staged) dst_l[j] = byte; else dst_g[j] = byte;
-            }
-          }
-        }
+      const bool ok = r < n && ((s_valid[r >> 6] >> (r & 63)) & 1);
+      const uint32_t len = ok ? s.x : 0u;
+      uint32_t W[14];
+      if (len > 12) {
+        const uint64_t p = static_cast<uint64_t>(s.z) | (static_cast<uint64_t>(s.w) << 32);
+        heap_load13(heap + (p - t.ptr_base), len, W);
       }
-      if (staged) {
+      // exclusive scan of the sub-block's lengths
+      const uint32_t incl = wave_inclusive_scan_u32(len);
+      const bool wave_big = __any(len >= kEncBigLen);
+      if (lane == 63) s_tot[k & 1][wave] = wave_big ? 0x80000000u : incl;
+      __syncthreads();
+      const u32x4 tot = *reinterpret_cast<const u32x4*>(&s_tot[k & 1][0]);
+      if ((tot.x | tot.y | tot.z | tot.w) & 0x80000000u) {
+        // uniform: a string of >= 8 MiB in this sub-block -- 32-bit sums may wrap; the 64-bit formulation does the rows
         __syncthreads();
-        // stage[shift .. shift+total) -> data[base .. base+total): unaligned head and tail bytewise, the middle as 16-byte rows
-        const int64_t g0 = base, g1 = base + total;
-        const int64_t a0 = (g0 + 15) & ~static_cast<int64_t>(15), a1 = g1 & ~static_cast<int64_t>(15);
-        if (a0 >= a1) {
-          for (int64_t i = g0 + threadIdx.x; i < g1; i += kBlockThreads) data[i] = stage[shift + (i - g0)];
-        } else {
-          for (int64_t i = g0 + threadIdx.x; i < a0; i += kBlockThreads) data[i] = stage[shift + (i - g0)];
-          for (int64_t i = a1 + threadIdx.x; i < g1; i += kBlockThreads) data[i] = stage[shift + (i - g0)];
-          const int nvec = static_cast<int>((a1 - a0) >> 4);
-          const u32x4* ls = reinterpret_cast<const u32x4*>(stage + shift + (a0 - g0));
-          gptr<u32x4> gd = (gptr<u32x4>)(data + a0);
-          for (int i = threadIdx.x; i < nvec; i += kBlockThreads) __builtin_nontemporal_store(ls[i], gd + i);
+        int64_t total64;
+        block_exclusive_scan(static_cast<int64_t>(len), &total64, lds4);
+        const int64_t sub0 = static_cast<int64_t>(k) * kBlockThreads;
+        encode_string_tile_generic(t, row0 + sub0, n - static_cast<int>(sub0) < kBlockThreads ? n - static_cast<int>(sub0) : kBlockThreads,
+                                   base, lds4, stage);
+        __syncthreads();
+        base += total64;
+        continue;
+      }
+      const uint32_t before = (wave > 0 ? tot.x : 0u) + (wave > 1 ? tot.y : 0u) + (wave > 2 ? tot.z : 0u);
+      const uint32_t total = tot.x + tot.y + tot.z + tot.w;
+      const uint32_t ex = before + incl - len;
+      if (r < n) offp[r] = static_cast<int32_t>(base + ex + len);
+      for (uint32_t w0 = 0; w0 < total;) {  // uniform: stage windows
+        const uint32_t shiftw = static_cast<uint32_t>((base + w0) & 15);
+        const uint32_t room = static_cast<uint32_t>(kEncStage5) - shiftw;
+        const uint32_t w1 = total - w0 < room ? total : w0 + room;
+        uint8_t* st = stage + buf * kEncStageBuf;
+        const uint32_t lo = ex > w0 ? ex : w0, hi = ex + len < w1 ? ex + len : w1;
+        if (lo < hi) string_bytes_to_lds(st + shiftw + (lo - w0), s, heap, t.ptr_base, lo - ex, hi - lo, W);
+        __syncthreads();
+        // stage bytes [shiftw, end) -> gbase[shiftw, end); gbase is 16-byte aligned
+        const uint32_t end = shiftw + (w1 - w0);
+        gptr<uint8_t> gbase = data + (base + w0) - shiftw;
+        const uint32_t nch = (end + 15) >> 4;
+        for (uint32_t c = threadIdx.x; c < nch; c += kBlockThreads) {
+          const uint32_t clo = c << 4;
+          if (clo >= shiftw && clo + 16 <= end)
+            __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(st + clo), (gptr<u32x4>)(gbase + clo));
         }
-        __syncthreads();
+        if (threadIdx.x < 32) {  // the (at most two) partial 16-byte rows, one byte per lane
+          const uint32_t lastlo = (end - 1) & ~15u;
+          const uint32_t idx = threadIdx.x < 16 ? threadIdx.x : lastlo + (threadIdx.x - 16);
+          const bool first_partial = shiftw != 0 || end < 16;
+          const bool last_partial = (end & 15u) != 0 && lastlo != 0;
+          const bool mine = threadIdx.x < 16 ? first_partial : last_partial;
+          if (mine && idx >= shiftw && idx < end) gbase[idx] = st[idx];
+        }
+        buf ^= 1u;
+        w0 = w1;
       }
       base += total;
     }
+    __syncthreads();  // s_valid / stage are rewritten by the next tile
   }
 }
 
@@ -1063,6 +1273,7 @@ struct Tune {
   int string_variant = 2;  // 1: 8 rows per lane in flight; 2: + nontemporal stores
   int blocks_per_cu = 0;   // 0: one workgroup per tile (the hardware dispatcher balances the tiles)
   int use_tile_table = 1;
+  int enc_string_variant = 1;  // 1: encode_string_v5 (batched heap loads, dword LDS assembly, windows); 0: encode_string
 };
 static Tune& TuneRef() {
   static Tune t = [] {
@@ -1073,6 +1284,7 @@ static Tune& TuneRef() {
     x.string_variant = env("MI_TUNE_STRING", x.string_variant);
     x.blocks_per_cu = env("MI_TUNE_GRID", x.blocks_per_cu);
     x.use_tile_table = env("MI_TUNE_TILE_TABLE", x.use_tile_table);
+    x.enc_string_variant = env("MI_TUNE_ENC_STRING", x.enc_string_variant);
     return x;
   }();
   return t;
@@ -1085,6 +1297,7 @@ bool SetTune(const char* knob, int value) {
   else if (k == "string") t.string_variant = value;
   else if (k == "grid") t.blocks_per_cu = value;
   else if (k == "tile_table") t.use_tile_table = value;
+  else if (k == "enc_string") t.enc_string_variant = value;
   else return false;
   return true;
 }
@@ -1148,11 +1361,19 @@ hipError_t LaunchFilterRange(const void* values, int32_t width, const void* vali
   return hipGetLastError();
 }
 
-hipError_t LaunchEncodeStringTileSums(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, int32_t n_tasks,
-                                      uint32_t total_tiles, int64_t* d_tile_sums, int grid_blocks, hipStream_t stream) {
+// Encode launches follow the decode rule: one workgroup per tile (the dispatcher balances them) and the tile -> task
+// table, unless the measurement knobs ask for the persistent grid / binary search.
+static uint32_t enc_grid(uint32_t total_tiles, int grid_blocks) {
+  return TuneRef().blocks_per_cu > 0 ? grid_for(total_tiles, grid_blocks) : total_tiles;
+}
+
+hipError_t LaunchEncodeStringTileSums(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
+                                      int32_t n_tasks, uint32_t total_tiles, int64_t* d_tile_sums, int grid_blocks,
+                                      hipStream_t stream) {
   if (total_tiles == 0) return hipSuccess;
-  hipLaunchKernelGGL(encode_string_tile_sums, dim3(grid_for(total_tiles, grid_blocks)), dim3(kBlockThreads), 0, stream,
-                     d_tasks, d_tile_begin, n_tasks, total_tiles, d_tile_sums);
+  const uint32_t* tt = TuneRef().use_tile_table ? d_tile_task : nullptr;
+  hipLaunchKernelGGL(encode_string_tile_sums, dim3(enc_grid(total_tiles, grid_blocks)), dim3(kBlockThreads), 0, stream,
+                     d_tasks, d_tile_begin, tt, n_tasks, total_tiles, d_tile_sums);
   return hipGetLastError();
 }
 
@@ -1165,20 +1386,34 @@ hipError_t LaunchEncodeStringScan(const mi_col_task* d_tasks, const uint32_t* d_
   return hipGetLastError();
 }
 
-hipError_t LaunchEncodeFixed(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, int32_t n_tasks,
-                             uint32_t total_tiles, int64_t* d_null_counts, int grid_blocks, hipStream_t stream) {
+hipError_t LaunchEncodeFixed(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
+                             int32_t n_tasks, uint32_t total_tiles, int64_t* d_null_counts, int grid_blocks,
+                             hipStream_t stream) {
   if (total_tiles == 0) return hipSuccess;
-  hipLaunchKernelGGL(encode_fixed, dim3(grid_for(total_tiles, grid_blocks)), dim3(kBlockThreads), 0, stream, d_tasks,
-                     d_tile_begin, n_tasks, total_tiles, d_null_counts);
+  const uint32_t* tt = TuneRef().use_tile_table ? d_tile_task : nullptr;
+  hipLaunchKernelGGL(encode_fixed, dim3(enc_grid(total_tiles, grid_blocks)), dim3(kBlockThreads), 0, stream, d_tasks,
+                     d_tile_begin, tt, n_tasks, total_tiles, d_null_counts);
   return hipGetLastError();
 }
 
-hipError_t LaunchEncodeString(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, int32_t n_tasks,
-                              uint32_t total_tiles, const int64_t* d_tile_sums, int64_t* d_null_counts, int grid_blocks,
-                              hipStream_t stream) {
+hipError_t LaunchEncodeString(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
+                              int32_t n_tasks, uint32_t total_tiles, const int64_t* d_tile_sums, int64_t* d_null_counts,
+                              int grid_blocks, hipStream_t stream) {
   if (total_tiles == 0) return hipSuccess;
-  hipLaunchKernelGGL(encode_string, dim3(grid_for(total_tiles, grid_blocks)), dim3(kBlockThreads), 0, stream, d_tasks,
-                     d_tile_begin, n_tasks, total_tiles, d_tile_sums, d_null_counts);
+  const uint32_t* tt = TuneRef().use_tile_table ? d_tile_task : nullptr;
+  const int ev = TuneRef().enc_string_variant;
+  if (ev == 1)
+    hipLaunchKernelGGL(encode_string_v5<4>, dim3(enc_grid(total_tiles, grid_blocks)), dim3(kBlockThreads), 0, stream, d_tasks,
+                       d_tile_begin, tt, n_tasks, total_tiles, d_tile_sums, d_null_counts);
+  else if (ev == 2)
+    hipLaunchKernelGGL(encode_string_v5<5>, dim3(enc_grid(total_tiles, grid_blocks)), dim3(kBlockThreads), 0, stream, d_tasks,
+                       d_tile_begin, tt, n_tasks, total_tiles, d_tile_sums, d_null_counts);
+  else if (ev == 3)
+    hipLaunchKernelGGL(encode_string_v5<6>, dim3(enc_grid(total_tiles, grid_blocks)), dim3(kBlockThreads), 0, stream, d_tasks,
+                       d_tile_begin, tt, n_tasks, total_tiles, d_tile_sums, d_null_counts);
+  else
+    hipLaunchKernelGGL(encode_string, dim3(enc_grid(total_tiles, grid_blocks)), dim3(kBlockThreads), 0, stream, d_tasks,
+                       d_tile_begin, tt, n_tasks, total_tiles, d_tile_sums, d_null_counts);
   return hipGetLastError();
 }
 

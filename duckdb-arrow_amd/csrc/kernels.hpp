@@ -43,14 +43,16 @@ hipError_t LaunchFilterRange(const void* values, int32_t width, const void* vali
                              int64_t hi, mi_sel_t* sel_out, uint32_t* count_out, hipStream_t stream);
 
 // K7d helpers (string encode needs a scan across the batch): per-tile payload byte sums, then per-task exclusive scan
-hipError_t LaunchEncodeStringTileSums(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, int32_t n_tasks,
-                                      uint32_t total_tiles, int64_t* d_tile_sums, int grid_blocks, hipStream_t stream);
+hipError_t LaunchEncodeStringTileSums(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
+                                      int32_t n_tasks, uint32_t total_tiles, int64_t* d_tile_sums, int grid_blocks,
+                                      hipStream_t stream);
 hipError_t LaunchEncodeStringScan(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, int32_t n_tasks,
                                   int64_t* d_tile_sums, uint32_t* d_status, hipStream_t stream);
-hipError_t LaunchEncodeFixed(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, int32_t n_tasks,
-                             uint32_t total_tiles, int64_t* d_null_counts, int grid_blocks, hipStream_t stream);
-hipError_t LaunchEncodeString(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, int32_t n_tasks,
-                              uint32_t total_tiles, const int64_t* d_tile_sums, int64_t* d_null_counts, int grid_blocks,
+hipError_t LaunchEncodeFixed(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
+                             int32_t n_tasks, uint32_t total_tiles, int64_t* d_null_counts, int grid_blocks,
+                             hipStream_t stream);
+hipError_t LaunchEncodeString(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
+                              int32_t n_tasks, uint32_t total_tiles, const int64_t* d_tile_sums, int64_t* d_null_counts, int grid_blocks,
                               hipStream_t stream);
 
 }  // namespace device

@@ -140,6 +140,67 @@ def test_encode_kernels_match_oracle_with_nulls(con, torch):
     assert nc == nulls.value
 
 
+def _string_vectors(lens, heap_bytes, rng):
+    """DuckDB string_t rows (n x 16 bytes) whose long payloads live in `heap` at arbitrary (unaligned) positions."""
+    n = len(lens)
+    heap = rng.integers(32, 127, heap_bytes, dtype=np.uint8)
+    ln = np.asarray(lens, np.int64)
+    starts = np.concatenate([[0], np.cumsum(ln)[:-1]])   # payload of row i = heap[starts[i] : starts[i] + ln[i]]
+    str16 = np.zeros((n, 16), np.uint8)
+    str16[:, :4] = ln.astype(np.uint32).view(np.uint8).reshape(n, 4)
+    for i in np.nonzero(ln <= 12)[0]:
+        str16[i, 4: 4 + ln[i]] = heap[starts[i]: starts[i] + ln[i]]
+    big = np.nonzero(ln > 12)[0]
+    for i in big:
+        str16[i, 4:8] = heap[starts[i]: starts[i] + 4]
+    str16[big, 8:16] = starts[big].astype(np.uint64).view(np.uint8).reshape(-1, 8)
+    return str16, heap
+
+
+@pytest.mark.parametrize("shape", ["long_mean_90", "one_9MiB_string", "mixed_with_empty_tiles", "all_inline"])
+def test_encode_string_windows_and_huge_strings_match_oracle(con, torch, shape):
+    """K7d beyond lineitem's shapes: sub-blocks whose payload exceeds one LDS window (mean 90 B), a string of 9 MiB
+    (the 32-bit in-tile positions hand that sub-block to the 64-bit formulation), tiles without payload, NULLs."""
+    rng = np.random.default_rng({"long_mean_90": 1, "one_9MiB_string": 2, "mixed_with_empty_tiles": 3, "all_inline": 4}[shape])
+    n = 7000
+    if shape == "long_mean_90":
+        lens = rng.integers(0, 181, n)
+    elif shape == "one_9MiB_string":
+        lens = rng.integers(0, 30, n)
+        lens[2500] = 9 * 2**20 + 3
+    elif shape == "mixed_with_empty_tiles":
+        lens = rng.integers(0, 600, n)
+        lens[2048:4096] = 0
+    else:
+        lens = rng.integers(0, 13, n)
+    ok = rng.random(n) < 0.85
+    valid = np.packbits(np.concatenate([ok, np.ones((-n) % 64, bool)]), bitorder="little").view(np.uint64).copy()
+    str16, heap = _string_vectors(lens, int(np.sum(lens)) + 64, rng)
+    payload = int(np.asarray(lens)[ok].sum())
+    d_valid = torch.from_numpy(valid.view(np.uint8).copy()).cuda()
+    d_src = torch.from_numpy(str16.reshape(-1).copy()).cuda()
+    d_heap = torch.from_numpy(heap).cuda()
+    o_valid = torch.zeros((n + 7) // 8 + 16, dtype=torch.uint8, device="cuda")
+    o_off = torch.zeros(4 * (n + 1) + 16, dtype=torch.uint8, device="cuda")
+    o_data = torch.full((payload + 64,), 0xEE, dtype=torch.uint8, device="cuda")
+    t = da.make_task(_ffi.K_ENC_STR32, n, d_src.data_ptr(), o_off.data_ptr(), validity=d_valid.data_ptr(),
+                     out_validity=o_valid.data_ptr(), out_aux=o_data.data_ptr(), buf2=d_heap.data_ptr(), ptr_base=0,
+                     buf2_len=heap.size)
+    plan = da.Plan(con.ctx, [t])
+    plan.launch(torch.cuda.current_stream().cuda_stream)
+    assert plan.status() == 0
+    want_off = np.zeros(n + 1, np.int32)
+    want_data = np.zeros(payload + 1, np.uint8)
+    rc = po.lib().orc_enc_varchar32(str16.ctypes.data, valid.ctypes.data, n, 0, 0, heap.ctypes.data, want_off.ctypes.data,
+                                    want_data.ctypes.data)
+    assert rc == 0
+    assert np.array_equal(o_off.cpu().numpy()[: 4 * (n + 1)].view(np.int32), want_off)
+    got = o_data.cpu().numpy()
+    assert np.array_equal(got[:payload], want_data[:payload])
+    assert np.all(got[payload:] == 0xEE)          # nothing written past the payload
+    assert plan.null_counts()[0] == int(n - ok.sum())
+
+
 # ---------------------------------------------------------------------------------------- test_arrow_ipc_writer.py
 def create_table():
     return da.Table(["f0", "f1", "f2"], ["INTEGER", "VARCHAR", "BOOLEAN"],

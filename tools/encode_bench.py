@@ -16,6 +16,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sf", type=float, default=1.0)
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--per-column", action="store_true", help="also time one plan per column (diagnostic)")
     args = ap.parse_args()
     import torch
     import duckdb_arrow_amd as da
@@ -45,7 +46,9 @@ def main():
     arena = torch.zeros(total + 256, dtype=torch.uint8, device="cuda")
     ab = arena.data_ptr()
     tasks = []
+    names = []
     for lay, e, offs, sz in spans:
+        names.append(e["name"])
         n = lay["nrows"]
         is_str = e["kind"] == _ffi.K_STR32
         tasks.append(da.make_task(enc_kind[e["kind"]], n, out_base + e["data_off"], ab + offs[1], validity=out_base + e["valid_off"],
@@ -70,6 +73,16 @@ def main():
     body = lay["body_off"]
     want = buf[body + e["buffers"][2][0]: body + e["buffers"][2][0] + sz[2]]
     out["payload_matches_source"] = bool(np.array_equal(got, want))
+    if args.per_column:
+        out["per_column"] = {}
+        for nm in dict.fromkeys(names):
+            p1 = da.Plan(ctx, [t for t, x in zip(tasks, names) if x == nm])
+            p1.launch(stream)
+            ts = np.array([p1.launch_timed(stream) for _ in range(args.rounds)])
+            st = p1.stats()
+            ms = float(np.median(ts.sum(axis=1)))
+            out["per_column"][nm] = {"ms": ms, "GBps": (st["bytes_read"] + st["bytes_written"]) / ms / 1e6}
+            p1.close()
     print(json.dumps(out))
 
 
