@@ -824,14 +824,14 @@ __device__ __forceinline__ void enc_tile_dec128(const mi_col_task& t, int64_t ro
   gptr<u32x4> out = GM<u32x4>(t.out_data) + row0;
 #pragma unroll 4
   for (int r = threadIdx.x; r < n; r += kBlockThreads) {
-    const int64_t v = static_cast<int64_t>(src[r]);
+    const int64_t v = static_cast<int64_t>(__builtin_nontemporal_load(src + r));
     const uint32_t sign = static_cast<uint32_t>(v >> 63);
     u32x4 o;
     o.x = static_cast<uint32_t>(static_cast<uint64_t>(v));
     o.y = static_cast<uint32_t>(static_cast<uint64_t>(v) >> 32);
     o.z = sign;
     o.w = sign;
-    out[r] = o;
+    __builtin_nontemporal_store(o, out + r);
   }
 }
 
@@ -859,7 +859,7 @@ __global__ __launch_bounds__(kBlockThreads) void encode_fixed(const mi_col_task*
     switch (t.kind) {
       case MI_K_ENC_COPY: {  // NULL slots copy whatever the source slot holds, like ArrowScalarData::Append
         const int w = static_cast<int>(t.param);
-        copy_bytes(GC<uint8_t>(t.buf1) + row0 * w, GM<uint8_t>(t.out_data) + row0 * w, n * w);
+        copy_bytes(GC<uint8_t>(t.buf1) + row0 * w, GM<uint8_t>(t.out_data) + row0 * w, n * w, 2);
         break;
       }
       case MI_K_ENC_DEC128:
