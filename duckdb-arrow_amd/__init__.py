@@ -534,19 +534,64 @@ def _vector_from_python(values, duck_type, keep):
     return np.array([0 if v is None else v for v in values], _INT_TYPES[t]), validity
 
 
+def _fill_vector(vec, values, ty, keep):
+    """python values -> one mi_vector (flat, or nested with child vectors) in DuckDB layout; `ty` from parse_duck_type."""
+    n = len(values)
+    vec.count = n
+    if ty[0] == "leaf":
+        data, validity = _vector_from_python(values, ty[1], keep)
+        keep.append(data)
+        vec.data = data.ctypes.data
+    else:
+        ok = np.array([v is not None for v in values], dtype=bool)
+        validity = None
+        if not ok.all():
+            validity = np.packbits(np.concatenate([ok, np.ones((-n) % 64, bool)]), bitorder="little").view(np.uint64).copy()
+        if ty[0] in ("list", "map"):
+            ent = np.zeros((max(n, 1), 2), np.uint64)
+            flat = []
+            for i, v in enumerate(values):
+                if v is None:
+                    continue
+                items = list(v.items()) if isinstance(v, dict) else list(v)
+                ent[i] = (len(flat), len(items))
+                flat.extend(items)
+            keep.append(ent)
+            vec.data = ent.ctypes.data
+            kids = (_ffi.Vector * 1)()
+            if ty[0] == "map":
+                cty = ("struct", [("key", ty[1]), ("value", ty[2])])
+                flat = [None if e is None else {"key": e[0], "value": e[1]} for e in flat]
+            else:
+                cty = ty[1]
+            _fill_vector(kids[0], flat, cty, keep)
+        elif ty[0] == "array":
+            flat = []
+            for v in values:
+                flat.extend([None] * ty[2] if v is None else list(v))
+            kids = (_ffi.Vector * 1)()
+            _fill_vector(kids[0], flat, ty[1], keep)
+        else:  # struct
+            kids = (_ffi.Vector * len(ty[1]))()
+            for k, (nm, kt) in enumerate(ty[1]):
+                _fill_vector(kids[k], [None if v is None else v.get(nm) for v in values], kt, keep)
+        keep.append(kids)
+        vec.children = kids
+        vec.n_children = len(kids)
+    if validity is not None:
+        keep.append(validity)
+        vec.validity = validity.ctypes.data
+
+
 def _chunks_from_table(table, keep, chunk_rows=VECTOR_SIZE):
     """Table -> list of mi_data_chunk (host vectors, <= 2048 rows each) the way DuckDB feeds a sink."""
     chunks = []
+    trees = [parse_duck_type(t) for t in table.types]
     for r0 in range(0, max(table.num_rows, 0), chunk_rows):
         r1 = min(table.num_rows, r0 + chunk_rows)
         vecs = (_ffi.Vector * len(table.names))()
-        for ci, (t, col) in enumerate(zip(table.types, table.columns)):
-            data, validity = _vector_from_python(col[r0:r1], t, keep)
-            keep.append(data)
-            vecs[ci].data = data.ctypes.data
-            if validity is not None:
-                keep.append(validity)
-                vecs[ci].validity = validity.ctypes.data
+        for ci, (ty, col) in enumerate(zip(trees, table.columns)):
+            _fill_vector(vecs[ci], col[r0:r1], ty, keep)
         keep.append(vecs)
         ch = _ffi.DataChunk(size=r1 - r0, n_columns=len(table.names), columns=vecs)
         chunks.append(ch)
@@ -678,7 +723,11 @@ class Connection:
         _ffi.check(L.mi_write_options_finalize(C.byref(o)))
         rotate = o.row_groups_per_file > 0 or file_size_bytes is not None
         files, keep = [], []
-        fields = _c_fields(table.names, table.types)
+        if isinstance(table, Relation):   # COPY (FROM read_arrow(...)) TO ...: the scan's chunks go straight into the sink
+            names, types, source = table.columns, table.types, table.chunks()
+        else:
+            names, types, source = table.names, table.types, _chunks_from_table(table, keep)
+        fields = _c_fields(names, types)
 
         def open_writer():
             if rotate:
@@ -687,13 +736,13 @@ class Connection:
             else:
                 p = path
             w = C.c_void_p()
-            _ffi.check(L.mi_writer_open(self.ctx._h, os.fsencode(p), fields, len(table.names), C.byref(o), C.byref(w)))
+            _ffi.check(L.mi_writer_open(self.ctx._h, os.fsencode(p), fields, len(names), C.byref(o), C.byref(w)))
             files.append(p)
             return w
 
         w = open_writer()
         try:
-            for ch in _chunks_from_table(table, keep):
+            for ch in source:
                 _ffi.check(L.mi_writer_sink(w, C.byref(ch)))
                 if rotate and L.mi_writer_rotate_next_file(w, -1 if file_size_bytes is None else file_size_bytes):
                     _ffi.check(L.mi_writer_finalize(w))

@@ -134,7 +134,8 @@ static void ValidateTask(const mi_col_task& t, size_t i) {
       break;
     default: break;
   }
-  if (t.kind >= MI_K_ENC_COPY && t.out_validity == nullptr) fail("encode tasks need out_validity (the bitmap is always emitted)");
+  if (t.kind >= MI_K_ENC_COPY && t.kind != MI_K_ENC_COPY && t.out_validity == nullptr)
+    fail("encode tasks need out_validity (the bitmap is always emitted; only a bare ENC_COPY of list offsets has none)");
 }
 
 static int64_t TaskBytesRead(const mi_col_task& t) {
@@ -179,7 +180,7 @@ static int64_t TaskBytesWritten(const mi_col_task& t) {
   if (t.kind < MI_K_ENC_COPY) {
     return n * OutWidth(t.kind, t.param) + (t.out_validity ? ((n + 63) / 64) * 8 : 0);
   }
-  int64_t b = (n + 7) / 8;  // bitmap
+  int64_t b = t.out_validity ? (n + 7) / 8 : 0;  // bitmap
   switch (t.kind) {
     case MI_K_ENC_COPY: b += n * t.param; break;
     case MI_K_ENC_DEC128: b += n * 16; break;

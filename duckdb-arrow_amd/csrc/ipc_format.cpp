@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cctype>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "flatbuf.hpp"
@@ -543,11 +544,105 @@ static std::string Upper(std::string s) {
   return s;
 }
 
+// Split "a INTEGER, b STRUCT(x INT, y INT)" on top-level commas (outside parentheses and double quotes).
+static std::vector<std::string> SplitTopLevel(const std::string& text) {
+  std::vector<std::string> parts;
+  std::string cur;
+  int depth = 0;
+  bool quoted = false;
+  for (char ch : text) {
+    if (ch == '"') quoted = !quoted;
+    if (!quoted) {
+      if (ch == '(') depth++;
+      if (ch == ')') depth--;
+      if (ch == ',' && depth == 0) {
+        parts.push_back(cur);
+        cur.clear();
+        continue;
+      }
+    }
+    cur += ch;
+  }
+  if (!cur.empty() || !parts.empty()) parts.push_back(cur);
+  for (auto& p : parts) {
+    size_t a = p.find_first_not_of(" \t"), b = p.find_last_not_of(" \t");
+    p = a == std::string::npos ? std::string() : p.substr(a, b - a + 1);
+  }
+  return parts;
+}
+
+// Nested DuckDB types the way ArrowConverter::ToArrowSchema exports them: LIST -> list<l: T>, ARRAY -> fixed_size_list
+// <l: T>[N], STRUCT -> struct with the field names, MAP -> map<entries: struct<key: K not null, value: V> not null>.
+static bool NestedFieldFromDuckType(const std::string& name, const std::string& duck_type, ArrowField* out) {
+  std::string t = duck_type;
+  while (!t.empty() && std::isspace(static_cast<unsigned char>(t.back()))) t.pop_back();
+  if (t.empty()) return false;
+  ArrowField f;
+  f.name = name;
+  f.nullable = true;
+  if (t.back() == ']') {
+    const size_t open = t.rfind('[');
+    if (open == std::string::npos) throw InvalidInputException("Malformed type '" + duck_type + "'");
+    const std::string size = t.substr(open + 1, t.size() - open - 2);
+    f.children.push_back(FieldFromDuckType("l", t.substr(0, open)));
+    if (size.empty()) {
+      f.type = MI_AT_LIST;
+    } else {
+      f.type = MI_AT_FIXED_LIST;
+      f.byte_width = std::atoi(size.c_str());
+      if (f.byte_width <= 0) throw InvalidInputException("Malformed array size in '" + duck_type + "'");
+    }
+    *out = f;
+    return true;
+  }
+  const std::string up = Upper(t);
+  if (up.rfind("STRUCT(", 0) == 0 && t.back() == ')') {
+    f.type = MI_AT_STRUCT;
+    for (auto& part : SplitTopLevel(t.substr(7, t.size() - 8))) {
+      std::string child_name, rest;
+      if (!part.empty() && part[0] == '"') {
+        const size_t q = part.find('"', 1);
+        if (q == std::string::npos) throw InvalidInputException("Malformed struct field in '" + duck_type + "'");
+        child_name = part.substr(1, q - 1);
+        rest = part.substr(q + 1);
+      } else {
+        const size_t sp = part.find(' ');
+        if (sp == std::string::npos) throw InvalidInputException("Malformed struct field in '" + duck_type + "'");
+        child_name = part.substr(0, sp);
+        rest = part.substr(sp + 1);
+      }
+      f.children.push_back(FieldFromDuckType(child_name, rest));
+    }
+    if (f.children.empty()) throw InvalidInputException("STRUCT without fields: '" + duck_type + "'");
+    *out = f;
+    return true;
+  }
+  if (up.rfind("MAP(", 0) == 0 && t.back() == ')') {
+    auto kv = SplitTopLevel(t.substr(4, t.size() - 5));
+    if (kv.size() != 2) throw InvalidInputException("MAP needs a key and a value type: '" + duck_type + "'");
+    f.type = MI_AT_MAP;
+    ArrowField entries;
+    entries.name = "entries";
+    entries.type = MI_AT_STRUCT;
+    entries.nullable = false;
+    entries.children.push_back(FieldFromDuckType("key", kv[0]));
+    entries.children[0].nullable = false;
+    entries.children.push_back(FieldFromDuckType("value", kv[1]));
+    f.children.push_back(entries);
+    *out = f;
+    return true;
+  }
+  return false;
+}
+
 ArrowField FieldFromDuckType(const std::string& name, const std::string& duck_type) {
   ArrowField f;
   f.name = name;
   f.nullable = true;  // ArrowConverter::ToArrowSchema sets ARROW_FLAG_NULLABLE on every column
+  if (NestedFieldFromDuckType(name, duck_type, &f)) return f;
   std::string t = Upper(duck_type);
+  while (!t.empty() && std::isspace(static_cast<unsigned char>(t.back()))) t.pop_back();
+  while (!t.empty() && std::isspace(static_cast<unsigned char>(t.front()))) t.erase(t.begin());
   auto integer = [&](int bits, bool sign) { f.type = MI_AT_INT; f.bit_width = bits; f.is_signed = sign; return f; };
   if (t == "BOOLEAN" || t == "BOOL") { f.type = MI_AT_BOOL; return f; }
   if (t == "TINYINT") return integer(8, true);

@@ -796,12 +796,13 @@ __device__ __forceinline__ void enc_tile_validity(const mi_col_task& t, int64_t 
                                                   uint64_t* s_valid = nullptr) {
   const int lane = threadIdx.x;
   const int nwords = (n + 63) >> 6;
-  if (lane >= nwords) return;
+  if (lane >= nwords || (t.out_validity == nullptr && s_valid == nullptr)) return;
   uint64_t w = ~0ull;
   if (t.validity != nullptr) w = GC<uint64_t>(t.validity)[(row0 >> 6) + lane];
   const int rem = n - 64 * lane;
   if (rem < 64) w |= ~0ull << rem;
   if (s_valid) s_valid[lane] = w;
+  if (t.out_validity == nullptr) return;
   const int nulls = 64 - __builtin_popcountll(w);
   if (nulls) atomicAdd(reinterpret_cast<unsigned long long*>(null_counts + t.param2), static_cast<unsigned long long>(nulls));
   gptr<uint8_t> out = GM<uint8_t>(t.out_validity) + (row0 >> 3) + 8 * lane;
@@ -1259,7 +1260,7 @@ int ClassOfKind(int32_t kind) {
     case MI_K_BOOL: case MI_K_DATE64: case MI_K_MUL_I32: case MI_K_MUL_I64: case MI_K_DIV_I64: case MI_K_DURATION:
     case MI_K_DICT: case MI_K_INTERVAL_MONTHS: case MI_K_INTERVAL_MDN: case MI_K_NARROW: case MI_K_HALF_FLOAT:
     case MI_K_NULL: case MI_K_STRVIEW: case MI_K_LIST32: case MI_K_LIST64: case MI_K_STRUCT: return kClassMisc;
-    case MI_K_ENC_COPY: case MI_K_ENC_DEC128: case MI_K_ENC_BOOL: return kClassEncFixed;
+    case MI_K_ENC_COPY: case MI_K_ENC_DEC128: case MI_K_ENC_BOOL: case MI_K_ENC_VALIDITY: return kClassEncFixed;
     case MI_K_ENC_STR32: return kClassEncString;
     default: return -1;
   }

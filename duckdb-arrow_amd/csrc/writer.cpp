@@ -61,19 +61,18 @@ void EncodePlanFor(const ArrowField& f, int32_t* enc_kind, int64_t* param, int32
   }
 }
 
-// append `n` bits of `src` (NULL = all ones) to `dst` at bit position `pos`
-void AppendBits(uint64_t* dst, int64_t pos, const uint64_t* src, int64_t n) {
+// append `n` bits of `src` starting at bit `spos` (src NULL = all ones) to `dst` at bit position `pos`
+void AppendBits(uint64_t* dst, int64_t pos, const uint64_t* src, int64_t spos, int64_t n) {
   for (int64_t i = 0; i < n;) {
     const int64_t dw = (pos + i) >> 6;
     const int dsh = static_cast<int>((pos + i) & 63);
     const int64_t take = std::min<int64_t>(64 - dsh, n - i);
-    // gather `take` bits of src starting at bit i
     uint64_t bits;
     if (!src) {
       bits = ~0ull;
     } else {
-      const int64_t sw = i >> 6;
-      const int ssh = static_cast<int>(i & 63);
+      const int64_t sw = (spos + i) >> 6;
+      const int ssh = static_cast<int>((spos + i) & 63);
       bits = src[sw] >> ssh;
       if (ssh && ssh + take > 64) bits |= src[sw + 1] << (64 - ssh);
     }
@@ -82,15 +81,33 @@ void AppendBits(uint64_t* dst, int64_t pos, const uint64_t* src, int64_t n) {
     i += take;
   }
 }
+inline bool BitAt(const uint64_t* v, int64_t i) { return !v || ((v[i >> 6] >> (i & 63)) & 1); }
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ collection
 ChunkCollection::ChunkCollection(Context* ctx_p, const std::vector<ArrowField>& fields) : ctx(ctx_p) {
-  for (auto& f : fields) {
-    Column c;
-    EncodePlanFor(f, &c.enc_kind, &c.param, &c.width);
-    columns.push_back(c);
+  for (auto& f : fields) roots.push_back(AddField(f, 0));
+}
+
+int32_t ChunkCollection::AddField(const ArrowField& f, int32_t depth) {
+  const int32_t idx = static_cast<int32_t>(columns.size());
+  columns.emplace_back();
+  {
+    Column& c = columns.back();
+    c.arrow_type = f.type;
+    c.depth = depth;
+    switch (f.type) {
+      case MI_AT_STRUCT: break;
+      case MI_AT_FIXED_LIST: c.param = f.byte_width; break;
+      case MI_AT_LIST: case MI_AT_MAP: c.enc_kind = MI_K_ENC_COPY; c.param = 4; c.width = 4; break;
+      default: EncodePlanFor(f, &c.enc_kind, &c.param, &c.width); break;
+    }
   }
+  for (auto& ch : f.children) {
+    const int32_t k = AddField(ch, depth + 1);
+    columns[static_cast<size_t>(idx)].children.push_back(k);
+  }
+  return idx;
 }
 
 ChunkCollection::~ChunkCollection() {
@@ -103,12 +120,14 @@ ChunkCollection::~ChunkCollection() {
 
 void ChunkCollection::Reserve(Column& c, int64_t rows, int64_t extra_heap) {
   ctx->Bind();
-  GrowPinned(&c.data, &c.data_cap, static_cast<size_t>(rows) * static_cast<size_t>(c.width) + 64,
-             static_cast<size_t>(count) * static_cast<size_t>(c.width));
+  const int64_t lead = c.IsList() ? 1 : 0;  // a list stages count + 1 offsets
+  if (c.width > 0)
+    GrowPinned(&c.data, &c.data_cap, static_cast<size_t>(rows + lead) * static_cast<size_t>(c.width) + 64,
+               static_cast<size_t>(c.count + lead) * static_cast<size_t>(c.width));
   const size_t old_vcap = c.validity_cap;
-  GrowPinned(&c.validity, &c.validity_cap, static_cast<size_t>((rows + 63) / 64) * 8 + 16, static_cast<size_t>((count + 63) / 64) * 8);
+  GrowPinned(&c.validity, &c.validity_cap, static_cast<size_t>((rows + 63) / 64) * 8 + 16, static_cast<size_t>((c.count + 63) / 64) * 8);
   if (c.validity_cap != old_vcap) {
-    const size_t used = static_cast<size_t>((count + 63) / 64) * 8;
+    const size_t used = static_cast<size_t>((c.count + 63) / 64) * 8;
     std::memset(reinterpret_cast<uint8_t*>(c.validity) + used, 0xFF, c.validity_cap - used);
   }
   if (extra_heap > 0)
@@ -116,60 +135,105 @@ void ChunkCollection::Reserve(Column& c, int64_t rows, int64_t extra_heap) {
 }
 
 void ChunkCollection::Append(const mi_data_chunk& chunk) {
-  if (chunk.n_columns != static_cast<int32_t>(columns.size()))
-    throw InvalidInputException("DataChunk has " + std::to_string(chunk.n_columns) + " columns, the writer expects " + std::to_string(columns.size()));
+  if (chunk.n_columns != static_cast<int32_t>(roots.size()))
+    throw InvalidInputException("DataChunk has " + std::to_string(chunk.n_columns) + " columns, the writer expects " + std::to_string(roots.size()));
   const int64_t n = chunk.size;
   if (n <= 0) return;
   if (n > MI_VECTOR_SIZE * 1024) throw InvalidInputException("DataChunk too large");
-  for (size_t ci = 0; ci < columns.size(); ci++) {
-    Column& c = columns[ci];
-    const mi_vector& v = chunk.columns[ci];
-    if (!v.data) throw InvalidInputException("DataChunk column " + std::to_string(ci) + " has no data");
-    int64_t extra_heap = 0;
-    if (c.enc_kind == MI_K_ENC_STR32) {
-      const mi_string_t* s = static_cast<const mi_string_t*>(v.data);
-      for (int64_t i = 0; i < n; i++) {
-        const bool valid = !v.validity || ((v.validity[i >> 6] >> (i & 63)) & 1);
-        if (valid && s[i].value.inlined.length > 12) extra_heap += s[i].value.inlined.length;
-      }
-    }
-    Reserve(c, count + n, extra_heap);
-    std::memcpy(c.data + static_cast<size_t>(count) * static_cast<size_t>(c.width), v.data, static_cast<size_t>(n) * static_cast<size_t>(c.width));
-    AppendBits(c.validity, count, v.validity, n);
-    if (v.validity) {
-      for (int64_t i = 0; i < n && !c.has_nulls; i += 64) {
-        uint64_t w = v.validity[i >> 6];
-        const int64_t rem = n - i;
-        if (rem < 64) w |= ~0ull << rem;
-        if (w != ~0ull) c.has_nulls = true;
-      }
-    }
-    if (c.enc_kind == MI_K_ENC_STR32) {
-      mi_string_t* dst = reinterpret_cast<mi_string_t*>(c.data) + count;
-      for (int64_t i = 0; i < n; i++) {
-        const bool valid = !v.validity || ((v.validity[i >> 6] >> (i & 63)) & 1);
-        if (!valid) {
-          std::memset(&dst[i], 0, sizeof(mi_string_t));
-          continue;
-        }
-        const uint32_t len = dst[i].value.inlined.length;
-        c.payload_bytes += len;
-        if (len > 12) {
-          // long string: move the payload into the staging heap, the pointer becomes the heap offset (ptr_base = 0)
-          std::memcpy(c.heap + c.heap_used, reinterpret_cast<const void*>(static_cast<uintptr_t>(dst[i].value.pointer.ptr)), len);
-          dst[i].value.pointer.ptr = static_cast<uint64_t>(c.heap_used);
-          c.heap_used += len;
-        }
-      }
-      size_in_bytes += extra_heap;
-    }
-    size_in_bytes += n * c.width;
-  }
+  for (size_t ci = 0; ci < roots.size(); ci++) AppendNode(roots[ci], chunk.columns[ci], 0, n);
   count += n;
+}
+
+// rows [start, start + n) of vector `v` -> node `ni` (and, for nested types, the rows they own in the child nodes)
+void ChunkCollection::AppendNode(int32_t ni, const mi_vector& v, int64_t start, int64_t n) {
+  if (n <= 0) return;
+  const int64_t vbit = static_cast<int64_t>(v.validity_shift) + start;  // bit of v.validity that belongs to row `start`
+  {
+    Column& c = columns[static_cast<size_t>(ni)];
+    if (!c.IsGroup() && !v.data) throw InvalidInputException("DataChunk column " + std::to_string(ni) + " has no data");
+    if ((c.IsList() || c.IsGroup()) && (v.n_children < (c.arrow_type == MI_AT_STRUCT ? static_cast<int32_t>(c.children.size()) : 1) || !v.children))
+      throw InvalidInputException("nested vector without child vectors");
+  }
+  int64_t extra_heap = 0;
+  if (columns[static_cast<size_t>(ni)].enc_kind == MI_K_ENC_STR32) {
+    const mi_string_t* s = static_cast<const mi_string_t*>(v.data) + start;
+    for (int64_t i = 0; i < n; i++)
+      if (BitAt(v.validity, vbit + i) && s[i].value.inlined.length > 12) extra_heap += s[i].value.inlined.length;
+  }
+  Reserve(columns[static_cast<size_t>(ni)], columns[static_cast<size_t>(ni)].count + n, extra_heap);
+  Column& c = columns[static_cast<size_t>(ni)];  // (children are appended after this block: `columns` never grows here)
+  AppendBits(c.validity, c.count, v.validity, vbit, n);
+  if (v.validity && !c.has_nulls) {
+    for (int64_t i = 0; i < n; i++)
+      if (!BitAt(v.validity, vbit + i)) { c.has_nulls = true; break; }
+  }
+  if (c.IsGroup()) {
+    const int64_t mult = c.arrow_type == MI_AT_FIXED_LIST ? c.param : 1;
+    c.count += n;
+    for (size_t k = 0; k < c.children.size(); k++) AppendNode(c.children[k], v.children[k], start * mult, n * mult);
+    return;
+  }
+  if (c.IsList()) {
+    // Arrow offsets are staged here; the child rows of every valid list are gathered in order (ArrowListData::Append)
+    const uint64_t* ent = static_cast<const uint64_t*>(v.data) + 2 * start;
+    int32_t* offs = reinterpret_cast<int32_t*>(c.data);
+    if (c.count == 0) offs[0] = 0;
+    int64_t last = offs[c.count];
+    int64_t run_start = 0, run_len = 0;
+    const int32_t child = c.children[0];
+    const int64_t row_base = c.count;
+    c.count += n;
+    size_in_bytes += n * 4;
+    for (int64_t i = 0; i < n; i++) {
+      if (BitAt(v.validity, vbit + i)) {
+        const int64_t o = static_cast<int64_t>(ent[2 * i]), l = static_cast<int64_t>(ent[2 * i + 1]);
+        if (l > 0) {
+          if (run_len > 0 && o == run_start + run_len) {
+            run_len += l;
+          } else {
+            if (run_len > 0) AppendNode(child, v.children[0], run_start, run_len);
+            run_start = o;
+            run_len = l;
+          }
+          last += l;
+          if (last > 0x7FFFFFFFll)
+            throw InvalidInputException("Arrow Appender: The maximum combined list offset for regular list buffers is 2147483647 but the offset of " +
+                                        std::to_string(last) + " exceeds this.\n* SET arrow_large_buffer_size=true to use large list buffers");
+        }
+      }
+      reinterpret_cast<int32_t*>(columns[static_cast<size_t>(ni)].data)[row_base + i + 1] = static_cast<int32_t>(last);
+    }
+    if (run_len > 0) AppendNode(child, v.children[0], run_start, run_len);
+    return;
+  }
+  std::memcpy(c.data + static_cast<size_t>(c.count) * static_cast<size_t>(c.width),
+              static_cast<const uint8_t*>(v.data) + static_cast<size_t>(start) * static_cast<size_t>(c.width),
+              static_cast<size_t>(n) * static_cast<size_t>(c.width));
+  if (c.enc_kind == MI_K_ENC_STR32) {
+    mi_string_t* dst = reinterpret_cast<mi_string_t*>(c.data) + c.count;
+    for (int64_t i = 0; i < n; i++) {
+      if (!BitAt(v.validity, vbit + i)) {
+        std::memset(&dst[i], 0, sizeof(mi_string_t));
+        continue;
+      }
+      const uint32_t len = dst[i].value.inlined.length;
+      c.payload_bytes += len;
+      if (len > 12) {
+        // long string: move the payload into the staging heap, the pointer becomes the heap offset (ptr_base = 0)
+        std::memcpy(c.heap + c.heap_used, reinterpret_cast<const void*>(static_cast<uintptr_t>(dst[i].value.pointer.ptr)), len);
+        dst[i].value.pointer.ptr = static_cast<uint64_t>(c.heap_used);
+        c.heap_used += len;
+      }
+    }
+    size_in_bytes += extra_heap;
+  }
+  size_in_bytes += n * c.width;
+  c.count += n;
 }
 
 void ChunkCollection::Reset() {
   for (auto& c : columns) {
+    c.count = 0;
     c.heap_used = 0;
     c.payload_bytes = 0;
     c.has_nulls = false;
@@ -198,41 +262,51 @@ void ColumnDataCollectionSerializer::SerializeSchema() {
 idx_t ColumnDataCollectionSerializer::Serialize(ChunkCollection& buffer) {
   header.clear();
   body_size = 0;
-  const int64_t n = buffer.Count();
-  if (n == 0) return 0;
+  const int64_t n_top = buffer.Count();
+  if (n_top == 0) return 0;
   ctx->Bind();
   if (!plan) plan = std::make_unique<Plan>(ctx);
-  if (n > 0x7FFFFFFFll) throw InvalidInputException("record batch too large");
+  if (n_top > 0x7FFFFFFFll) throw InvalidInputException("record batch too large");
 
-  // body layout (buffers in schema order: validity, then data | offsets + data), device staging layout
+  // body layout: field nodes depth first, per node validity, then (offsets) / data -- the order
+  // ArrowIpcEncoderEncodeSimpleRecordBatch walks the ArrowArray tree; device staging layout beside it
+  const size_t n_nodes = buffer.columns.size();
   std::vector<mi_buffer_span> spans;
-  struct InOff { size_t data, validity, heap; };
-  std::vector<InOff> in_off(buffer.columns.size());
+  struct InOff { size_t data, validity, heap; size_t first_span; };
+  std::vector<InOff> in_off(n_nodes);
   size_t body_off = 0, in_bytes = 0;
   auto add_span = [&](int64_t len) {
     spans.push_back(mi_buffer_span{static_cast<int64_t>(body_off), len});
     body_off += RoundUp(static_cast<size_t>(len), kBufferAlign);
   };
-  for (size_t ci = 0; ci < buffer.columns.size(); ci++) {
+  for (size_t ci = 0; ci < n_nodes; ci++) {
     auto& c = buffer.columns[ci];
+    const int64_t n = c.count;
+    if (n > 0x7FFFFFFFll) throw InvalidInputException("record batch too large");
+    in_off[ci].first_span = spans.size();
     add_span((n + 7) / 8);  // validity: always emitted (ArrowAppender::FinalizeChild)
-    switch (c.enc_kind) {
-      case MI_K_ENC_COPY: add_span(n * c.param); break;
-      case MI_K_ENC_DEC128: add_span(n * 16); break;
-      case MI_K_ENC_BOOL: add_span((n + 7) / 8); break;
-      case MI_K_ENC_STR32:
-        if (c.payload_bytes > 0x7FFFFFFFll) {
-          throw InvalidInputException(
-              "Arrow Appender: The maximum total string size for regular string buffers is 2147483647 but the offset of " +
-              std::to_string(c.payload_bytes) + " exceeds this.\n* SET arrow_large_buffer_size=true to use large string buffers");
-        }
-        add_span((n + 1) * 4);
-        add_span(c.payload_bytes);
-        break;
-      default: break;
+    if (c.IsList()) {
+      add_span((n + 1) * 4);
+    } else if (!c.IsGroup()) {
+      switch (c.enc_kind) {
+        case MI_K_ENC_COPY: add_span(n * c.param); break;
+        case MI_K_ENC_DEC128: add_span(n * 16); break;
+        case MI_K_ENC_BOOL: add_span((n + 7) / 8); break;
+        case MI_K_ENC_STR32:
+          if (c.payload_bytes > 0x7FFFFFFFll) {
+            throw InvalidInputException(
+                "Arrow Appender: The maximum total string size for regular string buffers is 2147483647 but the offset of " +
+                std::to_string(c.payload_bytes) + " exceeds this.\n* SET arrow_large_buffer_size=true to use large string buffers");
+          }
+          add_span((n + 1) * 4);
+          add_span(c.payload_bytes);
+          break;
+        default: break;
+      }
     }
+    const int64_t staged_rows = n + (c.IsList() ? 1 : 0);
     in_off[ci].data = in_bytes;
-    in_bytes += RoundUp(static_cast<size_t>(n) * static_cast<size_t>(c.width) + 16, 256);
+    in_bytes += RoundUp(static_cast<size_t>(staged_rows) * static_cast<size_t>(c.width) + 16, 256);
     in_off[ci].validity = in_bytes;
     in_bytes += RoundUp(static_cast<size_t>((n + 63) / 64) * 8 + 8, 256);
     in_off[ci].heap = in_bytes;
@@ -246,31 +320,52 @@ idx_t ColumnDataCollectionSerializer::Serialize(ChunkCollection& buffer) {
   hipStream_t s = ctx->stream;
   MI_HIP_CHECK(hipMemsetAsync(d_body, 0, body_off, s));  // the padding bytes of every buffer are zero
   std::vector<mi_col_task> tasks;
-  size_t span_i = 0;
-  for (size_t ci = 0; ci < buffer.columns.size(); ci++) {
+  std::vector<int32_t> validity_task(n_nodes, -1);  // task whose NULL counter belongs to node ci
+  for (size_t ci = 0; ci < n_nodes; ci++) {
     auto& c = buffer.columns[ci];
-    MI_HIP_CHECK(hipMemcpyAsync(d_in + in_off[ci].data, c.data, static_cast<size_t>(n) * static_cast<size_t>(c.width), hipMemcpyHostToDevice, s));
+    const int64_t n = c.count;
+    if (n == 0) continue;  // zero-length buffers, no work
+    const size_t sp = in_off[ci].first_span;
+    const int64_t staged_rows = n + (c.IsList() ? 1 : 0);
+    if (c.width > 0)
+      MI_HIP_CHECK(hipMemcpyAsync(d_in + in_off[ci].data, c.data, static_cast<size_t>(staged_rows) * static_cast<size_t>(c.width), hipMemcpyHostToDevice, s));
     if (c.has_nulls)
       MI_HIP_CHECK(hipMemcpyAsync(d_in + in_off[ci].validity, c.validity, static_cast<size_t>((n + 63) / 64) * 8, hipMemcpyHostToDevice, s));
     if (c.heap_used)
       MI_HIP_CHECK(hipMemcpyAsync(d_in + in_off[ci].heap, c.heap, static_cast<size_t>(c.heap_used), hipMemcpyHostToDevice, s));
     mi_col_task t;
     std::memset(&t, 0, sizeof(t));
-    t.kind = c.enc_kind;
-    t.param = c.param;
     t.nrows = n;
     t.validity = c.has_nulls ? d_in + in_off[ci].validity : nullptr;
+    t.out_validity = d_body + spans[sp].offset;
+    validity_task[ci] = static_cast<int32_t>(tasks.size());
+    if (c.IsGroup() || c.IsList()) {
+      // struct / fixed_size_list / list / map: the node's own bitmap + NULL count
+      t.kind = MI_K_ENC_VALIDITY;
+      t.buf1 = d_in + in_off[ci].validity;
+      t.out_data = d_body + spans[sp].offset;
+      tasks.push_back(t);
+      if (c.IsList()) {  // the staged int32 offsets
+        mi_col_task o;
+        std::memset(&o, 0, sizeof(o));
+        o.kind = MI_K_ENC_COPY;
+        o.param = 4;
+        o.nrows = n + 1;
+        o.buf1 = d_in + in_off[ci].data;
+        o.out_data = d_body + spans[sp + 1].offset;
+        tasks.push_back(o);
+      }
+      continue;
+    }
+    t.kind = c.enc_kind;
+    t.param = c.param;
     t.buf1 = d_in + in_off[ci].data;
-    t.out_validity = d_body + spans[span_i].offset;
-    t.out_data = d_body + spans[span_i + 1].offset;
+    t.out_data = d_body + spans[sp + 1].offset;
     if (c.enc_kind == MI_K_ENC_STR32) {
       t.buf2 = d_in + in_off[ci].heap;
       t.buf2_len = c.payload_bytes;
       t.ptr_base = 0;
-      t.out_aux = d_body + spans[span_i + 2].offset;
-      span_i += 3;
-    } else {
-      span_i += 2;
+      t.out_aux = d_body + spans[sp + 2].offset;
     }
     tasks.push_back(t);
   }
@@ -280,8 +375,9 @@ idx_t ColumnDataCollectionSerializer::Serialize(ChunkCollection& buffer) {
   ThrowForStatus(plan->Status());  // synchronises the stream
   std::vector<int64_t> null_counts = plan->NullCounts(/*reset*/ true);
   std::vector<std::pair<int64_t, int64_t>> nodes;
-  for (size_t ci = 0; ci < buffer.columns.size(); ci++) nodes.emplace_back(n, null_counts[ci]);
-  header = EncodeRecordBatchMessage(n, nodes, spans, body_size);
+  for (size_t ci = 0; ci < n_nodes; ci++)
+    nodes.emplace_back(buffer.columns[ci].count, validity_task[ci] >= 0 ? null_counts[static_cast<size_t>(validity_task[ci])] : 0);
+  header = EncodeRecordBatchMessage(n_top, nodes, spans, body_size);
   return 1;
 }
 

@@ -104,7 +104,9 @@ enum mi_kind {
   MI_K_ENC_COPY = 32,     /* K7b fixed-width copy; param = width */
   MI_K_ENC_DEC128 = 33,   /* K7b int16/32/64 -> decimal128 sign extension; param = in width */
   MI_K_ENC_BOOL = 34,     /* K7c byte -> bit, bits start as 1 */
-  MI_K_ENC_STR32 = 35     /* K7d string_t -> int32 offsets + data */
+  MI_K_ENC_STR32 = 35,    /* K7d string_t -> int32 offsets + data */
+  MI_K_ENC_VALIDITY = 36  /* K7a alone: validity words -> always-present bitmap + NULL count (the node of a struct /
+                           * list / map / fixed_size_list; their offsets travel as MI_K_ENC_COPY with out_validity NULL) */
 };
 
 typedef struct mi_field {
@@ -392,7 +394,9 @@ int mi_write_options_finalize(mi_write_options* o);
 
 /* ArrowWriteInitializeGlobal (write_arrow_stream.cpp:127-139): creates the file, truncating an existing one
  * (FILE_FLAGS_FILE_CREATE_NEW = create-or-truncate in DuckDB, arrow_stream_writer.cpp:49-53) and writes the Schema message.
- * `fields`: name + duck_type (e.g. "BIGINT", "DECIMAL(15,2)", "VARCHAR", "DATE", "BOOLEAN") per column. */
+ * `fields`: name + duck_type per column: "BIGINT", "DECIMAL(15,2)", "VARCHAR", "DATE", "BOOLEAN", ... and the nested
+ * types "T[]" (LIST), "T[N]" (ARRAY), "STRUCT(a T, b U)", "MAP(K, V)", exported the way ArrowConverter::ToArrowSchema
+ * does (list child "l", map child "entries" {key not null, value}).  Nested vectors arrive as mi_vector trees. */
 int mi_writer_open(mi_ctx* ctx, const char* path, const mi_field* fields, int32_t n_fields,
                    const mi_write_options* opts, mi_writer** out);
 /* ArrowWriteSink (write_arrow_stream.cpp:141-159): appends one DataChunk (host vectors, DuckDB layout); flushes
