@@ -462,6 +462,17 @@ class Relation:
         _ffi.check(_ffi.lib().mi_scan_count(self._h, C.byref(rows), C.byref(sel), C.byref(chunks)))
         return dict(rows=rows.value, selected=sel.value, chunks=chunks.value) if detail else sel.value
 
+    def sum_product(self, a, b, filters=()):
+        """SELECT sum(a * b), count(*) WHERE lo <= f < hi ... evaluated on the GPU (mi_scan_sum_product); `filters` =
+        [(column, lo, hi), ...] on stored integers.  Returns (sum as python int, rows selected, rows scanned)."""
+        arr = (_ffi.RangeFilter * max(len(filters), 1))()
+        for i, (c, lo, hi) in enumerate(filters):
+            arr[i].column, arr[i].lo, arr[i].hi = c.encode(), lo, hi
+        r = _ffi.SumProductResult()
+        _ffi.check(_ffi.lib().mi_scan_sum_product(self._h, a.encode(), b.encode(), arr, len(filters), C.byref(r)))
+        self._initialised = True
+        return (r.sum_hi << 64) + r.sum_lo, r.rows_selected, r.rows_scanned
+
     def progress(self):
         return _ffi.lib().mi_scan_progress(self._h)
 

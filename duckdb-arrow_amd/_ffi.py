@@ -74,6 +74,14 @@ class ScanOptions(C.Structure):
                 ("accept_dictionaries", C.c_int32), ("zero_copy_direct", C.c_int32)]
 
 
+class RangeFilter(C.Structure):
+    _fields_ = [("column", C.c_char_p), ("lo", C.c_int64), ("hi", C.c_int64)]
+
+
+class SumProductResult(C.Structure):
+    _fields_ = [("sum_lo", C.c_uint64), ("sum_hi", C.c_int64), ("rows_scanned", C.c_int64), ("rows_selected", C.c_int64)]
+
+
 class Vector(C.Structure):
     pass
 
@@ -147,6 +155,7 @@ SIGNATURES = {
     "mi_scan_set_filter_range": (C.c_int, [P, C.c_char_p, C.c_int64, C.c_int64]),
     "mi_scan_next": (C.c_int, [P, C.POINTER(DataChunk)]),
     "mi_scan_count": (C.c_int, [P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "mi_scan_sum_product": (C.c_int, [P, C.c_char_p, C.c_char_p, C.POINTER(RangeFilter), C.c_int32, C.POINTER(SumProductResult)]),
     "mi_scan_progress": (C.c_double, [P]),
     "mi_write_options_init": (C.c_int, [C.POINTER(WriteOptions)]),
     "mi_write_options_set": (C.c_int, [C.POINTER(WriteOptions), C.c_char_p, C.c_char_p]),

@@ -23,6 +23,7 @@
 
 #include "kernels.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <string>
 
@@ -1036,6 +1037,55 @@ __global__ __launch_bounds__(kBlockThreads) void encode_string(const mi_col_task
   }
 }
 
+// ---------------------------------------------------------------------------------------------------- fused Q6-style consumer
+// sum(a * b) WHERE lo_k <= f_k < hi_k (all k) over decoded fixed-width vectors; NULL in any filter column drops the
+// row (SQL comparison semantics), NULL in a or b makes the product NULL, which SUM ignores.  128-bit accumulation
+// (DuckDB sums DECIMAL products in a hugeint).  28 bytes per row for TPC-H Q6: HBM / L2 bound.
+__device__ __forceinline__ int64_t load_sint(const void* p, int width, int64_t i) {
+  switch (width) {
+    case 1: return GC<int8_t>(p)[i];
+    case 2: return GC<int16_t>(p)[i];
+    case 4: return GC<int32_t>(p)[i];
+    default: return GC<int64_t>(p)[i];
+  }
+}
+
+__global__ __launch_bounds__(kBlockThreads) void agg_sum_product(AggSumProductArgs a, unsigned long long* __restrict__ acc) {
+  __int128 sum = 0;
+  unsigned long long selected = 0;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlockThreads;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlockThreads + threadIdx.x; i < a.nrows; i += stride) {
+    bool keep = true;
+    for (int k = 0; k < a.n_filters; k++) {
+      const bool valid = a.fvalid[k] == nullptr || ((GC<uint64_t>(a.fvalid[k])[i >> 6] >> (i & 63)) & 1);
+      const int64_t v = load_sint(a.fcol[k], a.fwidth[k], i);
+      keep = keep && valid && v >= a.lo[k] && v < a.hi[k];
+    }
+    if (keep) {
+      selected++;
+      const bool va = a.avalid == nullptr || ((GC<uint64_t>(a.avalid)[i >> 6] >> (i & 63)) & 1);
+      const bool vb = a.bvalid == nullptr || ((GC<uint64_t>(a.bvalid)[i >> 6] >> (i & 63)) & 1);
+      if (va && vb) sum += static_cast<__int128>(load_sint(a.a, a.awidth, i)) * static_cast<__int128>(load_sint(a.b, a.bwidth, i));
+    }
+  }
+  unsigned long long lo = static_cast<unsigned long long>(sum), hi = static_cast<unsigned long long>(sum >> 64);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned long long olo = __shfl_down(lo, d, 64), ohi = __shfl_down(hi, d, 64);
+    const unsigned long long osel = __shfl_down(selected, d, 64);
+    const unsigned long long nlo = lo + olo;
+    hi += ohi + (nlo < lo ? 1ull : 0ull);
+    lo = nlo;
+    selected += osel;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned long long old = atomicAdd(&acc[0], lo);
+    const unsigned long long carry = (old + lo < old) ? 1ull : 0ull;
+    if (hi + carry) atomicAdd(&acc[1], hi + carry);
+    if (selected) atomicAdd(&acc[2], selected);
+  }
+}
+
 // ---- dword-granular LDS assembly ------------------------------------------------------------------------------
 // W[0..N] hold a source byte stream that starts at byte `sh` (0..3) of W[0] (W[N+1] readable, zero); writes its first
 // cnt <= 4N bytes at dst (LDS): <= 3 head bytes up to dst's 4-byte boundary, whole dwords funnel-shifted to the
@@ -1335,6 +1385,14 @@ hipError_t LaunchTranscode(int cls, const mi_col_task* d_tasks, const uint32_t* 
       return hipErrorInvalidValue;
   }
 #undef MI_LAUNCH
+  return hipGetLastError();
+}
+
+hipError_t LaunchAggSumProduct(const AggSumProductArgs& args, unsigned long long* d_acc, int num_cus, hipStream_t stream) {
+  if (args.nrows <= 0) return hipSuccess;
+  const int64_t want = (args.nrows + kBlockThreads * 8 - 1) / (kBlockThreads * 8);   // ~8 rows per lane
+  const uint32_t grid = static_cast<uint32_t>(std::min<int64_t>(want, static_cast<int64_t>(num_cus) * 16));
+  hipLaunchKernelGGL(agg_sum_product, dim3(grid ? grid : 1), dim3(kBlockThreads), 0, stream, args, d_acc);
   return hipGetLastError();
 }
 

@@ -39,6 +39,23 @@ hipError_t LaunchTranscode(int cls, const mi_col_task* d_tasks, const uint32_t* 
 bool SetTune(const char* knob, int value);
 
 // K6: range filter -> selection vector, one workgroup per 2048-row window.
+//! Fused consumer: sum(a * b) over the rows that pass up to 4 conjunctive range filters, straight
+//! from the decoded vectors in HBM.  acc = {sum low 64 bits, sum high 64 bits (two's complement), rows selected}.
+struct AggSumProductArgs {
+  const void* fcol[4];
+  const uint64_t* fvalid[4];
+  int32_t fwidth[4];
+  int64_t lo[4], hi[4];
+  int32_t n_filters;
+  const void* a;
+  const void* b;
+  const uint64_t* avalid;
+  const uint64_t* bvalid;
+  int32_t awidth, bwidth;
+  int64_t nrows;
+};
+hipError_t LaunchAggSumProduct(const AggSumProductArgs& args, unsigned long long* d_acc, int num_cus, hipStream_t stream);
+
 hipError_t LaunchFilterRange(const void* values, int32_t width, const void* validity, int64_t nrows, int64_t lo,
                              int64_t hi, mi_sel_t* sel_out, uint32_t* count_out, hipStream_t stream);
 

@@ -362,7 +362,7 @@ int32_t ArrowScan::AddNode(Slot& s, const DecodedBatch& b, int32_t ni, std::vect
     o.win = win;
     // reference behaviour for plain fixed-width columns: the vector aliases the Arrow buffer (DirectConversion) and an
     // array without NULLs leaves the ValidityMask unset
-    if (opts.zero_copy_direct && kind == MI_K_COPY && nd.null_count == 0 && parent_valid_off < 0 && nd.spans.size() > 1 &&
+    if (opts.zero_copy_direct && !agg.on && kind == MI_K_COPY && nd.null_count == 0 && parent_valid_off < 0 && nd.spans.size() > 1 &&
         !(has_filter && nd.depth == 0 && ni == filter_node)) {
       o.alias = (opts.device_resident ? s.d_in : b.body) + nd.spans[1].offset;
       if (opts.device_resident) s.upload.emplace_back(nd.spans[1].offset, nd.spans[1].length);
@@ -579,9 +579,32 @@ void ArrowScan::EnqueueBatch(Slot& s) {
                                            filter_hi, reinterpret_cast<mi_sel_t*>(s.d_out + s.sel_off),
                                            reinterpret_cast<uint32_t*>(s.d_out + s.sel_count_off), ctx->stream));
   }
+  if (agg.on && n > 0) {
+    // fused consumer: the decoded vectors are read once more by the aggregate kernel and never leave HBM
+    device::AggSumProductArgs a;
+    std::memset(&a, 0, sizeof(a));
+    auto column = [&](int32_t c, const void** data, const uint64_t** valid, int32_t* width) {
+      if (s.col_root[static_cast<size_t>(c)] < 0) throw InvalidInputException("aggregate column '" + out_columns[static_cast<size_t>(c)].name + "' is absent from a file of the scan");
+      const Slot::NodeOut& o = s.node_out[static_cast<size_t>(s.col_root[static_cast<size_t>(c)])];
+      *data = s.d_out + o.data_off;
+      *valid = reinterpret_cast<const uint64_t*>(s.d_out + o.valid_off);
+      *width = o.width;
+    };
+    a.n_filters = static_cast<int32_t>(agg.filter_cols.size());
+    for (int32_t k = 0; k < a.n_filters; k++) {
+      column(agg.filter_cols[static_cast<size_t>(k)], &a.fcol[k], &a.fvalid[k], &a.fwidth[k]);
+      a.lo[k] = agg.lo[static_cast<size_t>(k)];
+      a.hi[k] = agg.hi[static_cast<size_t>(k)];
+    }
+    column(agg.col_a, &a.a, &a.avalid, &a.awidth);
+    column(agg.col_b, &a.b, &a.bvalid, &a.bwidth);
+    a.nrows = n;
+    MI_HIP_CHECK(device::LaunchAggSumProduct(a, agg.d_acc, ctx->num_cus, ctx->stream));
+    agg.rows_scanned += n;
+  }
   MI_HIP_CHECK(hipEventRecord(s.compute_done, ctx->stream));
   MI_HIP_CHECK(hipStreamWaitEvent(ctx->d2h_stream, s.compute_done, 0));
-  if (!opts.device_resident && off > 0)
+  if (!opts.device_resident && !agg.on && off > 0)
     MI_HIP_CHECK(hipMemcpyAsync(s.h_out, s.d_out, off, hipMemcpyDeviceToHost, ctx->d2h_stream));
   // the device status word travels with the results instead of costing a stream-wide synchronisation
   MI_HIP_CHECK(hipMemcpyAsync(s.h_status, s.plan->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->d2h_stream));
@@ -789,6 +812,65 @@ void ArrowScan::Next(mi_data_chunk* out) {
   cur_row += n;
 }
 
+void ArrowScan::SumProduct(const std::string& a, const std::string& b, const std::vector<std::string>& filter_columns,
+                           const std::vector<int64_t>& lo, const std::vector<int64_t>& hi, mi_sum_product_result* out) {
+  if (initialized) throw InvalidInputException("mi_scan_sum_product replaces mi_scan_init / mi_scan_next: call it right after bind");
+  if (filter_columns.size() > 4) throw InvalidInputException("at most 4 range filters");
+  if (has_filter) throw InvalidInputException("give the filters to mi_scan_sum_product instead of mi_scan_set_filter_range");
+  ctx->Bind();
+  // project exactly the columns the aggregate reads
+  std::vector<std::string> proj;
+  auto slot_of = [&](const std::string& name) {
+    for (size_t i = 0; i < proj.size(); i++)
+      if (proj[i] == name) return static_cast<int32_t>(i);
+    proj.push_back(name);
+    return static_cast<int32_t>(proj.size() - 1);
+  };
+  agg.col_a = slot_of(a);
+  agg.col_b = slot_of(b);
+  for (auto& f : filter_columns) agg.filter_cols.push_back(slot_of(f));
+  agg.lo = lo;
+  agg.hi = hi;
+  Init(proj);
+  for (auto& name : proj) {
+    const ScanColumn& c = out_columns[static_cast<size_t>(slot_of(name))];
+    int32_t kind, w, nb;
+    int64_t param;
+    const bool ok = !c.is_filename && !c.is_hive && c.field.Plan(&kind, &param, &w, &nb) &&
+                    (kind == MI_K_COPY || kind == MI_K_DEC128 || kind == MI_K_DATE64 || kind == MI_K_MUL_I32 || kind == MI_K_MUL_I64 ||
+                     kind == MI_K_DIV_I64 || kind == MI_K_NARROW) &&
+                    (w == 1 || w == 2 || w == 4 || w == 8) && c.field.type != MI_AT_FLOAT;
+    if (!ok) throw InvalidInputException("Column '" + name + "' (" + c.field.DuckType() + ") is not a fixed-width integer-like column: the fused aggregate takes integers, DATE, TIME/TIMESTAMP and DECIMAL(<=18)");
+  }
+  MI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&agg.d_acc), 4 * sizeof(unsigned long long)));
+  MI_HIP_CHECK(hipMemsetAsync(agg.d_acc, 0, 4 * sizeof(unsigned long long), ctx->stream));
+  agg.on = true;
+  agg.rows_scanned = 0;
+  mi_data_chunk ch;
+  try {
+    while (true) {   // the pull loop only recycles slots: nothing is copied back
+      Next(&ch);
+      if (ch.size == 0) break;
+      cur_row = slots[cur_slot].nrows;  // the whole batch is consumed on the device
+    }
+    unsigned long long acc[4] = {0, 0, 0, 0};
+    MI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    MI_HIP_CHECK(hipMemcpy(acc, agg.d_acc, sizeof(acc), hipMemcpyDeviceToHost));
+    out->sum_lo = acc[0];
+    out->sum_hi = static_cast<int64_t>(acc[1]);
+    out->rows_selected = static_cast<int64_t>(acc[2]);
+    out->rows_scanned = agg.rows_scanned;
+  } catch (...) {
+    (void)hipFree(agg.d_acc);
+    agg.d_acc = nullptr;
+    agg.on = false;
+    throw;
+  }
+  MI_HIP_CHECK(hipFree(agg.d_acc));
+  agg.d_acc = nullptr;
+  agg.on = false;
+}
+
 double ArrowScan::Progress() {
   if (sources.empty()) return 100;
   double done = static_cast<double>(std::min(cur_source, sources.size()));
@@ -891,6 +973,23 @@ int mi_scan_count(mi_scan* s, int64_t* rows, int64_t* selected, int64_t* chunks)
     if (rows) *rows = r;
     if (selected) *selected = sel;
     if (chunks) *chunks = n;
+  });
+}
+
+int mi_scan_sum_product(mi_scan* s, const char* column_a, const char* column_b, const mi_range_filter* filters,
+                        int32_t n_filters, mi_sum_product_result* out) {
+  return WrapC([&] {
+    if (!s || !column_a || !column_b || !out || (n_filters > 0 && !filters)) throw InvalidInputException("mi_scan_sum_product: NULL argument");
+    std::vector<std::string> cols;
+    std::vector<int64_t> lo, hi;
+    for (int32_t i = 0; i < n_filters; i++) {
+      if (!filters[i].column) throw InvalidInputException("mi_scan_sum_product: filter without a column");
+      cols.emplace_back(filters[i].column);
+      lo.push_back(filters[i].lo);
+      hi.push_back(filters[i].hi);
+    }
+    std::memset(out, 0, sizeof(*out));
+    s->scan->SumProduct(column_a, column_b, cols, lo, hi, out);
   });
 }
 

@@ -111,6 +111,11 @@ class ArrowScan {
   void BuildOutputSchema();
   bool SubmitNextBatch();   // reads + enqueues one more record batch; false when all sources are exhausted
   void EnqueueBatch(Slot& s);
+ public:
+  //! sum(a * b) over rows passing the range filters, all on the GPU; drains the scan (mi_scan_sum_product)
+  void SumProduct(const std::string& a, const std::string& b, const std::vector<std::string>& filter_columns,
+                  const std::vector<int64_t>& lo, const std::vector<int64_t>& hi, mi_sum_product_result* out);
+ private:
   int32_t AddNode(Slot& s, const DecodedBatch& b, int32_t ni, std::vector<int64_t> win, bool win_is_tiles, int64_t parent_valid_off,
                   int32_t parent_div, size_t* off, std::vector<mi_col_task>* tasks, std::vector<uint64_t>* aux,
                   std::vector<std::pair<size_t, size_t>>* aux_fixups);
@@ -143,6 +148,15 @@ class ArrowScan {
   std::vector<mi_vector> child_pool;     // children of nested vectors of the current chunk
   size_t child_pool_used = 0;
   int32_t filter_node = -1;              // field node of the filter column in the batch being enqueued
+  // fused aggregate (mi_scan_sum_product): output columns the kernel reads, bounds, device accumulator
+  struct Aggregate {
+    bool on = false;
+    int32_t col_a = -1, col_b = -1;
+    std::vector<int32_t> filter_cols;
+    std::vector<int64_t> lo, hi;
+    unsigned long long* d_acc = nullptr;   // {sum lo, sum hi, rows selected}
+    int64_t rows_scanned = 0;
+  } agg;
   // constant columns (filename / hive): 2048 string_t each, host
   std::vector<std::vector<mi_string_t>> const_vectors;
   std::vector<mi_validity_t> all_valid;

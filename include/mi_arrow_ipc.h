@@ -359,6 +359,25 @@ int mi_scan_next(mi_scan* s, mi_data_chunk* out);
 /* SELECT count(*) FROM read_arrow(...) (test/sql/read_arrow.test:35-38): pulls every remaining chunk natively.
  * rows = scanned, selected = rows passing the pushed-down filter (== rows without one), chunks = DataChunks seen. */
 int mi_scan_count(mi_scan* s, int64_t* rows, int64_t* selected, int64_t* chunks);
+/* Fused consumer (the reference's benchmark query is TPC-H Q6, benchmark/lineitem.py:22-34):
+ *   SELECT sum(a * b), count(*) FROM scan WHERE lo_k <= f_k < hi_k  (k < n_filters <= 4)
+ * evaluated on the GPU over the decoded vectors of every record batch, which never leave HBM: the only D2H traffic is
+ * this 32-byte result.  Columns must be fixed-width integer-like after the scan (integers, DATE, TIME/TIMESTAMP,
+ * DECIMAL(<=18)); values are the stored integers (DECIMAL(15,2) 0.05 is 5).  NULL in a filter column drops the row,
+ * NULL in a or b contributes nothing (SQL SUM).  Call after bind instead of init/next: it projects the columns it
+ * needs itself and drains the scan. */
+typedef struct mi_range_filter {
+  const char* column;
+  int64_t lo, hi;            /* lo <= value < hi */
+} mi_range_filter;
+typedef struct mi_sum_product_result {
+  uint64_t sum_lo;           /* 128-bit two's complement sum of a*b: low / high half (DuckDB sums DECIMAL products in a hugeint) */
+  int64_t sum_hi;
+  int64_t rows_scanned;
+  int64_t rows_selected;
+} mi_sum_product_result;
+int mi_scan_sum_product(mi_scan* s, const char* column_a, const char* column_b, const mi_range_filter* filters,
+                        int32_t n_filters, mi_sum_product_result* out);
 double mi_scan_progress(mi_scan* s);
 
 /* ---------------------------------------------------------------------------------------------------------

@@ -365,3 +365,53 @@ def test_zero_copy_direct_columns(con, golden_dir, expected):
     rel = con.read_arrow(g(golden_dir, "lineitem_sf0_01_q6.arrows"), zero_copy_direct=True).project(["l_shipdate", "l_discount"])
     ship, _ = rel.filter_range("l_shipdate", 8766, 9131).fetch_columns()
     assert len(ship) == expected["kat"]["shipdate_1994_selected"]
+
+
+# ---------------------------------------------------------------------------------------- fused consumer (TPC-H Q6)
+Q6_FILTERS = [("l_shipdate", 8766, 9131), ("l_discount", 5, 8), ("l_quantity", -2**63, 2400)]
+
+
+def test_q6_fused_on_the_gpu_known_answer(con, golden_dir, expected):
+    """benchmark/lineitem.py:22-34 / test/nodejs/arrow_test.js:423-424: sum(l_extendedprice * l_discount) with the Q6
+    predicates = 1193053.2253 on lineitem SF0.01, computed on the GPU; only 32 bytes come back."""
+    rel = con.read_arrow(g(golden_dir, "lineitem_sf0_01_q6.arrows"))
+    total, selected, scanned = rel.sum_product("l_extendedprice", "l_discount", Q6_FILTERS)
+    assert total == 11930532253 and selected == 1191
+    assert scanned == expected["lineitem_sf0_01_q6.arrows"]["rows"]
+
+
+def test_q6_fused_matches_numpy_on_synthetic_lineitem(con, tmp_path):
+    buf, info = da.synth_lineitem_stream(scale_factor=0.05, seed=9)
+    path = str(tmp_path / "li.arrows")
+    buf.tofile(path)
+    cols = con.read_arrow(path).project(["l_extendedprice", "l_discount", "l_quantity", "l_shipdate"]).fetch_columns()
+    price, disc, qty, ship = (np.array(c, dtype=object) for c in cols)
+    keep = [(8766 <= s < 9131) and (5 <= d < 8) and q < 2400 for s, d, q in zip(ship, disc, qty)]
+    want = sum(int(p) * int(d) for p, d, k in zip(price, disc, keep) if k)
+    total, selected, scanned = con.read_arrow(path).sum_product("l_extendedprice", "l_discount", Q6_FILTERS)
+    assert (total, selected, scanned) == (want, sum(keep), info["n_rows"])
+    # sharded: the partial sums of two ranks add up
+    parts = [con.read_arrow(path, rank=r, world=2).sum_product("l_extendedprice", "l_discount", Q6_FILTERS) for r in range(2)]
+    assert sum(p[0] for p in parts) == want and sum(p[2] for p in parts) == info["n_rows"]
+
+
+def test_fused_aggregate_semantics(con, tmp_path):
+    """NULL in a filter column drops the row, NULL in a factor contributes nothing, negative products and sums beyond
+    64 bits are exact (128-bit accumulation), non-integer columns are refused."""
+    n = 5000
+    rng = np.random.default_rng(4)
+    a = pa.array(rng.integers(-2**62, 2**62, n), pa.int64(), mask=rng.random(n) < 0.1)
+    b = pa.array(rng.integers(-2**31, 2**31, n).astype(np.int32), mask=rng.random(n) < 0.1)
+    f = pa.array(rng.integers(0, 100, n).astype(np.int16), mask=rng.random(n) < 0.2)
+    s = pa.array(["x"] * n)
+    path = str(tmp_path / "agg.arrows")
+    with ipc.new_stream(path, pa.schema([("a", a.type), ("b", b.type), ("f", f.type), ("s", s.type)])) as w:
+        w.write_batch(pa.record_batch([a, b, f, s], names=["a", "b", "f", "s"]))
+    al, bl, fl = a.to_pylist(), b.to_pylist(), f.to_pylist()
+    keep = [x is not None and 10 <= x < 60 for x in fl]
+    want = sum(x * y for x, y, k in zip(al, bl, keep) if k and x is not None and y is not None)
+    total, selected, scanned = con.read_arrow(path).sum_product("a", "b", [("f", 10, 60)])
+    assert total == want and abs(want) > 2**64 and selected == sum(keep) and scanned == n
+    assert con.read_arrow(path).sum_product("b", "b")[1] == n        # no filter: every row selected
+    with pytest.raises(da.MiError, match="not a fixed-width integer-like column"):
+        con.read_arrow(path).sum_product("a", "s")
