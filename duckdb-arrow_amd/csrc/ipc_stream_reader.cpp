@@ -284,6 +284,62 @@ void IPCStreamReader::DecompressBody(RecordBatchMeta* meta) {
   meta->compression = -1;
 }
 
+// Number of RecordBatch.buffers entries a field subtree owns (same rules as the walk in SliceBatch)
+static bool CountSubtreeBuffers(const ArrowField& f, const RecordBatchMeta& meta, size_t* variadic, size_t* buffers) {
+  if (f.has_dictionary) {
+    *buffers += 2;
+    return true;
+  }
+  switch (f.type) {
+    case MI_AT_NULL: break;
+    case MI_AT_STRUCT: case MI_AT_FIXED_LIST: *buffers += 1; break;
+    case MI_AT_UTF8: case MI_AT_BINARY: case MI_AT_LARGE_UTF8: case MI_AT_LARGE_BINARY: *buffers += 3; break;
+    case MI_AT_UTF8_VIEW: case MI_AT_BINARY_VIEW: {
+      if (*variadic >= meta.variadic_counts.size()) return false;
+      const int64_t vc = meta.variadic_counts[(*variadic)++];
+      if (vc < 0 || vc > (1 << 20)) return false;
+      *buffers += 2 + static_cast<size_t>(vc);
+      break;
+    }
+    case MI_AT_UNION: *buffers += f.unit == 1 ? 2 : 1; break;
+    default: *buffers += 2; break;
+  }
+  for (auto& c : f.children)
+    if (!CountSubtreeBuffers(c, meta, variadic, buffers)) return false;
+  return true;
+}
+
+std::vector<std::pair<int64_t, int64_t>> IPCStreamReader::ProjectedBodyRanges(const RecordBatchMeta& meta, int64_t body_length,
+                                                                              int64_t gap) const {
+  std::vector<std::pair<int64_t, int64_t>> ranges;
+  if (!HasProjection() || meta.is_dictionary || meta.compression != -1) return ranges;
+  std::vector<char> wanted(base_schema.fields.size(), 0);
+  for (int32_t c : projected_columns) wanted[static_cast<size_t>(c)] = 1;
+  size_t buf = 0, variadic = 0;
+  std::vector<std::pair<int64_t, int64_t>> need;
+  for (size_t i = 0; i < base_schema.fields.size(); i++) {
+    size_t n = 0;
+    if (!CountSubtreeBuffers(base_schema.fields[i], meta, &variadic, &n) || buf + n > meta.buffers.size()) return ranges;
+    if (wanted[i]) {
+      for (size_t k = buf; k < buf + n; k++) {
+        const mi_buffer_span& b = meta.buffers[k];
+        if (b.length <= 0) continue;
+        if (b.offset < 0 || b.offset + b.length > body_length) return {};  // malformed: read everything, validation reports it
+        need.emplace_back(b.offset, b.offset + ((b.length + 7) & ~int64_t(7)));  // + the 8-byte padding kernels may touch
+      }
+    }
+    buf += n;
+  }
+  std::sort(need.begin(), need.end());
+  for (auto& r : need) {
+    const int64_t hi = std::min(r.second, body_length);
+    if (!ranges.empty() && r.first <= ranges.back().second + gap) ranges.back().second = std::max(ranges.back().second, hi);
+    else ranges.emplace_back(r.first, hi);
+  }
+  if (ranges.empty()) ranges.emplace_back(0, 0);  // nothing to read at all (projection of empty buffers)
+  return ranges;
+}
+
 static std::string BufferSizeError(const std::string& column, int buffer, int64_t need, int64_t have) {
   return "Expected " + column + " buffer " + std::to_string(buffer) + " to have size >= " + std::to_string(need) +
          " bytes but found buffer with " + std::to_string(have) + " bytes";
@@ -561,10 +617,10 @@ class IoPool {
 
 const uint8_t* IPCFileStreamReader::ReadData(uint8_t* ptr, idx_t size) {
   // BufferedFileReader::ReadData throws SerializationException when the file ends early
-  constexpr idx_t kSlice = 2u << 20;
-  if (size >= 2 * kSlice && IoPool::Get().Threads() > 1) {
+  constexpr idx_t kSlice = 256u << 10;  // smallest piece worth a thread hand-off
+  if (size >= 4 * kSlice && IoPool::Get().Threads() > 1) {
     if (offset + static_cast<int64_t>(size) > file_size) throw SerializationException();
-    const int n = static_cast<int>(std::min<idx_t>((size + kSlice - 1) / kSlice, 64));
+    const int n = static_cast<int>(std::min<idx_t>((size + kSlice - 1) / kSlice, static_cast<idx_t>(2 * IoPool::Get().Threads())));
     const idx_t per = ((size + n - 1) / n + 4095) & ~static_cast<idx_t>(4095);
     const int64_t base = offset;
     IoPool::Get().Run(n, [&](int i) {
@@ -652,11 +708,28 @@ void IPCFileStreamReader::DecodeBody() {
     }
     uint8_t* p = nullptr;
     bool compressed = false;
-    if (message.type == MessageType::RECORD_BATCH || message.type == MessageType::DICTIONARY_BATCH)
-      compressed = DecodeRecordBatch(message_meta, message_meta_len).compression != -1;
+    std::vector<std::pair<int64_t, int64_t>> ranges;
+    if (message.type == MessageType::RECORD_BATCH || message.type == MessageType::DICTIONARY_BATCH) {
+      const RecordBatchMeta meta = DecodeRecordBatch(message_meta, message_meta_len);
+      compressed = meta.compression != -1;
+      // projection pushdown reaches the file: only the buffers of the projected columns are read (the reference reads
+      // the whole body, ipc_file_stream_reader.cpp:71-89); what is skipped is never looked at
+      if (message.type == MessageType::RECORD_BATCH) ranges = ProjectedBodyRanges(meta, message.body_length, 256 << 10);
+    }
     cur_owner = (body_allocator && !compressed) ? body_allocator(static_cast<size_t>(message.body_length), message.type, &p)
                                                 : DefaultBodyAlloc(static_cast<size_t>(message.body_length), message.type, &p);
-    ReadData(p, static_cast<idx_t>(message.body_length));
+    if (ranges.empty()) {
+      ReadData(p, static_cast<idx_t>(message.body_length));
+    } else {
+      if (offset + message.body_length > file_size) throw SerializationException();
+      const int64_t body0 = offset;
+      for (auto& r : ranges) {
+        if (r.second <= r.first) continue;
+        offset = body0 + r.first;
+        ReadData(p + r.first, static_cast<idx_t>(r.second - r.first));
+      }
+      offset = body0 + message.body_length;
+    }
     cur_ptr = p;
     cur_size = message.body_length;
   } else {

@@ -89,6 +89,9 @@ class IPCStreamReader {
   //! Sets the projection pushdown for this reader
   void SetColumnProjection(const std::vector<std::string>& column_names);
   bool HasProjection() const { return !projected_fields.empty(); }
+  //! Byte ranges of a record-batch body that hold the buffers of the projected columns (merged when closer than
+  //! `gap`); empty = everything (no projection, compressed body, or malformed metadata: the full validation decides).
+  std::vector<std::pair<int64_t, int64_t>> ProjectedBodyRanges(const RecordBatchMeta& meta, int64_t body_length, int64_t gap) const;
   const std::vector<int64_t>& ProjectedFlatFields() const { return projected_fields; }
 
   MessageType ReadNextMessage(std::vector<MessageType> expected_types, bool end_of_stream_ok = true);

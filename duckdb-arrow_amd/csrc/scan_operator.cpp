@@ -536,10 +536,9 @@ void ArrowScan::EnqueueBatch(Slot& s) {
   for (auto& fx : aux_fixups) tasks[fx.first].buf2 = s.d_aux + fx.second * 8;
   // H2D of the body (+ tables) on the copy stream
   if (b.body_size > 0) {
-    if (!opts.zero_copy_direct) {
-      MI_HIP_CHECK(hipMemcpyAsync(s.d_in, b.body, static_cast<size_t>(b.body_size), hipMemcpyHostToDevice, ctx->h2d_stream));
-    } else {
-      // only what the kernels read: merge the buffer ranges (gaps below 64 KiB are cheaper to copy than to split)
+    {
+      // only what the kernels read (projected columns; with zero_copy_direct not even all of those): merge the buffer
+      // ranges, gaps below 64 KiB are cheaper to copy than to split.  A full scan is one copy of the whole body.
       std::sort(s.upload.begin(), s.upload.end());
       int64_t lo = -1, hi = -1;
       auto flush = [&]() {
