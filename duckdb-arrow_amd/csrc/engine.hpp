@@ -44,6 +44,7 @@ struct ClassSlice {
   int32_t n_tasks = 0;
   int32_t tile_begin_at = 0;  // index into Plan::tile_begin / d_tile_begin (n_tasks + 1 entries)
   uint32_t total_tiles = 0;
+  uint32_t misc_groups = 0;   // class misc only: bit 0 = flat kinds present, bit 1 = nested kinds (list / string view / struct)
 };
 
 // A plan = any number of (record batch, column) tasks, grouped by kernel class; Launch() enqueues one kernel per

@@ -451,7 +451,7 @@ __device__ __forceinline__ void tile_bool(const mi_col_task& t, int64_t row0, in
 __device__ __forceinline__ void tile_date64(const mi_col_task& t, int64_t row0, int n) {
   gptr<const int64_t> src = GC<int64_t>(t.buf1) + t.row_offset + row0;
   gptr<int32_t> out = GM<int32_t>(t.out_data) + row0;
-#pragma unroll 4
+#pragma unroll 2  // 64-bit division by a constant is register hungry; 4 copies cost the class one occupancy step
   for (int r = threadIdx.x; r < n; r += kBlockThreads) out[r] = static_cast<int32_t>(src[r] / 86400000ll);
 }
 
@@ -489,8 +489,15 @@ __device__ __forceinline__ void tile_div_i64(const mi_col_task& t, int64_t row0,
   gptr<const int64_t> src = GC<int64_t>(t.buf1) + t.row_offset + row0;
   gptr<int64_t> out = GM<int64_t>(t.out_data) + row0;
   const int64_t d = t.param;
+  // the divisors the type mapping produces are 1000 (ns -> us) and powers of it: constant divisions are a multiply-high,
+  // the generic 64-bit division (~100 instructions, dozens of registers) stays out of the unrolled loops
+  if (d == 1000) {
 #pragma unroll 4
-  for (int r = threadIdx.x; r < n; r += kBlockThreads) out[r] = src[r] / d;  // all rows, like upstream
+    for (int r = threadIdx.x; r < n; r += kBlockThreads) out[r] = src[r] / 1000;  // all rows, like upstream
+    return;
+  }
+#pragma unroll 1
+  for (int r = threadIdx.x; r < n; r += kBlockThreads) out[r] = src[r] / d;
 }
 
 __device__ __forceinline__ void tile_duration(const mi_col_task& t, int64_t row0, int n, uint32_t* status, const uint64_t* s_valid) {
@@ -498,11 +505,11 @@ __device__ __forceinline__ void tile_duration(const mi_col_task& t, int64_t row0
   gptr<u32x4> out = GM<u32x4>(t.out_data) + row0;
   const bool has_nulls = tile_needs_mask(t);
   uint32_t err = 0;
-#pragma unroll 4
+#pragma unroll 1
   for (int r = threadIdx.x; r < n; r += kBlockThreads) {
     int64_t micros = 0;
     if (t.param < 0) {
-      micros = src[r] / (-t.param);
+      micros = t.param == -1000 ? src[r] / 1000 : src[r] / (-t.param);
     } else if (row_valid(s_valid, has_nulls, r)) {
       if (__builtin_mul_overflow(src[r], t.param, &micros)) {
         micros = 0;
@@ -699,6 +706,11 @@ __device__ __forceinline__ void tile_dict(const mi_col_task& t, int64_t row0, in
   raise(status, err);
 }
 
+// GROUP 0: the common flat kinds (bool, dictionary indices, date64, timestamp unit casts) -- small per-row work whose
+// throughput is set by how many tiles a CU keeps in flight, so they get their own register budget; GROUP 1: list
+// entries, string views, struct validity; GROUP 2: the rare flat kinds (intervals, durations, decimal32/64, half
+// floats, null).  A plan launches only the groups its tasks use.
+template <int GROUP>
 __global__ __launch_bounds__(kBlockThreads) void transcode_misc(const mi_col_task* __restrict__ tasks,
                                                                 const uint32_t* __restrict__ tile_begin,
                                                                 const uint32_t* __restrict__ tile_task, int n_tasks,
@@ -706,32 +718,45 @@ __global__ __launch_bounds__(kBlockThreads) void transcode_misc(const mi_col_tas
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     MI_TILE_PROLOGUE();
     __shared__ uint64_t s_valid[kTileRows / 64];
+    const int group = (t.kind == MI_K_STRUCT || t.kind == MI_K_LIST32 || t.kind == MI_K_LIST64 || t.kind == MI_K_STRVIEW) ? 1
+                      : (t.kind == MI_K_BOOL || t.kind == MI_K_DICT || t.kind == MI_K_DATE64 || t.kind == MI_K_MUL_I32 ||
+                         t.kind == MI_K_MUL_I64 || t.kind == MI_K_DIV_I64) ? 0 : 2;
+    if (group != GROUP) continue;  // uniform: another group's launch owns this tile
     if (tile_needs_mask(t)) __syncthreads();
     if (t.kind != MI_K_NULL) tile_validity(t, row0, n, s_valid);
-    switch (t.kind) {
-      case MI_K_NULL: tile_null(t, row0, n); break;
-      case MI_K_STRUCT: break;  // validity only
-      case MI_K_LIST32: tile_list<int32_t>(t, row0, n, status); break;
-      case MI_K_LIST64: tile_list<int64_t>(t, row0, n, status); break;
-      case MI_K_STRVIEW: tile_strview(t, row0, n, status, s_valid); break;
-      case MI_K_INTERVAL_MONTHS: tile_interval_months(t, row0, n); break;
-      case MI_K_INTERVAL_MDN: tile_interval_mdn(t, row0, n); break;
-      case MI_K_HALF_FLOAT: tile_half_float(t, row0, n); break;
-      case MI_K_NARROW: {
-        const int sw = static_cast<int>(t.param & 0xFF), dw = static_cast<int>((t.param >> 8) & 0xFF);
-        if (sw == 4) tile_narrow<int32_t, int16_t>(t, row0, n, status, s_valid);
-        else if (dw == 2) tile_narrow<int64_t, int16_t>(t, row0, n, status, s_valid);
-        else tile_narrow<int64_t, int32_t>(t, row0, n, status, s_valid);
-        break;
+    if (GROUP == 1) {
+      switch (t.kind) {
+        case MI_K_LIST32: tile_list<int32_t>(t, row0, n, status); break;
+        case MI_K_LIST64: tile_list<int64_t>(t, row0, n, status); break;
+        case MI_K_STRVIEW: tile_strview(t, row0, n, status, s_valid); break;
+        default: break;  // MI_K_STRUCT: validity only
       }
-      case MI_K_BOOL: tile_bool(t, row0, n); break;
-      case MI_K_DATE64: tile_date64(t, row0, n); break;
-      case MI_K_MUL_I32: tile_mul_i32(t, row0, n, s_valid); break;
-      case MI_K_MUL_I64: tile_mul_i64(t, row0, n, status, s_valid); break;
-      case MI_K_DIV_I64: tile_div_i64(t, row0, n); break;
-      case MI_K_DURATION: tile_duration(t, row0, n, status, s_valid); break;
-      case MI_K_DICT: tile_dict(t, row0, n, status, s_valid); break;
-      default: break;
+    } else if (GROUP == 0) {
+      switch (t.kind) {
+        case MI_K_BOOL: tile_bool(t, row0, n); break;
+        case MI_K_DATE64: tile_date64(t, row0, n); break;
+        case MI_K_MUL_I32: tile_mul_i32(t, row0, n, s_valid); break;
+        case MI_K_MUL_I64: tile_mul_i64(t, row0, n, status, s_valid); break;
+        case MI_K_DIV_I64: tile_div_i64(t, row0, n); break;
+        case MI_K_DICT: tile_dict(t, row0, n, status, s_valid); break;
+        default: break;
+      }
+    } else {
+      switch (t.kind) {
+        case MI_K_NULL: tile_null(t, row0, n); break;
+        case MI_K_INTERVAL_MONTHS: tile_interval_months(t, row0, n); break;
+        case MI_K_INTERVAL_MDN: tile_interval_mdn(t, row0, n); break;
+        case MI_K_HALF_FLOAT: tile_half_float(t, row0, n); break;
+        case MI_K_NARROW: {
+          const int sw = static_cast<int>(t.param & 0xFF), dw = static_cast<int>((t.param >> 8) & 0xFF);
+          if (sw == 4) tile_narrow<int32_t, int16_t>(t, row0, n, status, s_valid);
+          else if (dw == 2) tile_narrow<int64_t, int16_t>(t, row0, n, status, s_valid);
+          else tile_narrow<int64_t, int32_t>(t, row0, n, status, s_valid);
+          break;
+        }
+        case MI_K_DURATION: tile_duration(t, row0, n, status, s_valid); break;
+        default: break;
+      }
     }
   }
 }
@@ -1354,7 +1379,7 @@ bool SetTune(const char* knob, int value) {
 }
 
 hipError_t LaunchTranscode(int cls, const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
-                           int32_t n_tasks, uint32_t total_tiles, uint32_t* d_status, int num_cus, hipStream_t stream) {
+                           int32_t n_tasks, uint32_t total_tiles, uint32_t* d_status, uint32_t misc_groups, int num_cus, hipStream_t stream) {
   if (total_tiles == 0) return hipSuccess;
   const Tune& tune = TuneRef();
   const uint32_t blocks = tune.blocks_per_cu > 0 ? grid_for(total_tiles, num_cus * tune.blocks_per_cu) : total_tiles;
@@ -1379,7 +1404,9 @@ hipError_t LaunchTranscode(int cls, const mi_col_task* d_tasks, const uint32_t* 
       else MI_LAUNCH(transcode_string<0>);
       break;
     case kClassMisc:
-      MI_LAUNCH(transcode_misc);
+      if (misc_groups & 1u) MI_LAUNCH(transcode_misc<0>);
+      if (misc_groups & 2u) MI_LAUNCH(transcode_misc<1>);
+      if (misc_groups & 4u) MI_LAUNCH(transcode_misc<2>);
       break;
     default:
       return hipErrorInvalidValue;

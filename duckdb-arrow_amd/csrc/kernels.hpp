@@ -33,7 +33,7 @@ int ClassOfKind(int32_t kind);  // -1 for an unknown kind
 // tile_begin[n_tasks] = total_tiles.  `status` accumulates MI_ST_* bits.
 // `tile_task[tile]` = task index of every tile of the slice (optional, NULL = binary search over tile_begin).
 hipError_t LaunchTranscode(int cls, const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
-                           int32_t n_tasks, uint32_t total_tiles, uint32_t* d_status, int num_cus, hipStream_t stream);
+                           int32_t n_tasks, uint32_t total_tiles, uint32_t* d_status, uint32_t misc_groups, int num_cus, hipStream_t stream);
 // measurement knobs: "copy" | "dec128" | "string" = kernel variant, "grid" = workgroups per CU (0 = one per tile),
 // "tile_table" = 0/1
 bool SetTune(const char* knob, int value);
