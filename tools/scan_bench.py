@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--sf", type=float, default=1.0)
     ap.add_argument("--dir", default="/dev/shm")
     ap.add_argument("--repeat", type=int, default=3)
+    ap.add_argument("--files", type=int, default=8, help="config 3: also scan the table split into this many files")
     args = ap.parse_args()
     import duckdb_arrow_amd as da
     buf, info = da.synth_lineitem_stream(scale_factor=args.sf, seed=42)
@@ -52,6 +53,39 @@ def main():
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
         out["q6_fused_on_gpu"] = {"seconds": best, "rows_per_s": scanned / best, "revenue_scale4": total, "selected": selected}
+        # BASELINE configs[2] shape on one GPU: the table as a list of files, l_shipdate filter pushed into the scan,
+        # row groups sharded rank / world (each rank of an N-GPU job runs exactly this with its own rank)
+        if args.files > 1:
+            per = (info["n_batches"] + args.files - 1) // args.files * 122880
+            paths = []
+            for i in range(args.files):
+                first = i * per
+                if first >= info["n_rows"]:
+                    break
+                part, _ = da.synth_lineitem_stream(scale_factor=args.sf, seed=42, n_rows=min(per, info["n_rows"] - first), first_row=first)
+                pth = os.path.join(args.dir, "mi_lineitem_sf%g_part%d.arrows" % (args.sf, i))
+                part.tofile(pth)
+                paths.append(pth)
+            try:
+                res = {}
+                for world in (1, 2):
+                    sel, rows, secs = 0, 0, []
+                    for rank in range(world):
+                        best = None
+                        for _ in range(args.repeat):
+                            t0 = time.perf_counter()
+                            d = con.read_arrow(paths, rank=rank, world=world).filter_range("l_shipdate", 8766, 9131).count(detail=True)
+                            dt = time.perf_counter() - t0
+                            best = dt if best is None else min(best, dt)
+                        secs.append(best)
+                        sel += d["selected"]
+                        rows += d["rows"]
+                    res["world_%d" % world] = {"seconds_per_rank": secs, "rows": rows, "selected": sel}
+                assert res["world_1"]["selected"] == res["world_2"]["selected"] and res["world_1"]["rows"] == info["n_rows"]
+                out["multi_file_filter_pushdown"] = dict(files=len(paths), **res)
+            finally:
+                for pth in paths:
+                    os.unlink(pth)
     finally:
         os.unlink(path)
     print(json.dumps(out))
