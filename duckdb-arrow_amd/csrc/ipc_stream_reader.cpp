@@ -194,6 +194,94 @@ bool IPCStreamReader::GetNextBatch(DecodedBatch* out, bool accept_dictionaries, 
   return true;
 }
 
+// Large bodies are read with several concurrent pread()s: one thread copies out of the page cache at ~10 GB/s, far below
+// what the H2D link takes, so the body is cut into slices read in parallel (MI_IO_THREADS, default 8).
+namespace {
+class IoPool {
+ public:
+  static IoPool& Get() {
+    static IoPool pool;
+    return pool;
+  }
+  int Threads() const { return n_threads; }
+  // runs fn(i) for i in [0, n) on the pool + the calling thread; rethrows the first failure
+  void Run(int n, const std::function<void(int)>& fn) {
+    if (n <= 1 || n_threads <= 1) {
+      for (int i = 0; i < n; i++) fn(i);
+      return;
+    }
+    std::unique_lock<std::mutex> lk(mu);
+    job = &fn;
+    job_n = n;
+    next = 0;
+    pending = n;
+    error = nullptr;
+    generation++;
+    cv.notify_all();
+    lk.unlock();
+    Work();
+    lk.lock();
+    done_cv.wait(lk, [&] { return pending == 0; });
+    job = nullptr;
+    if (error) std::rethrow_exception(error);
+  }
+
+ private:
+  IoPool() {
+    const char* v = std::getenv("MI_IO_THREADS");
+    n_threads = v ? std::max(1, std::atoi(v)) : 8;
+    for (int i = 1; i < n_threads; i++) workers.emplace_back([this] { Loop(); });
+  }
+  ~IoPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv.notify_all();
+    for (auto& t : workers) t.join();
+  }
+  void Work() {
+    while (true) {
+      int i;
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!job || next >= job_n) return;
+        i = next++;
+      }
+      try {
+        (*job)(i);
+      } catch (...) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!error) error = std::current_exception();
+      }
+      std::lock_guard<std::mutex> lk(mu);
+      if (--pending == 0) done_cv.notify_all();
+    }
+  }
+  void Loop() {
+    uint64_t seen = 0;
+    while (true) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || generation != seen; });
+        if (stop) return;
+        seen = generation;
+      }
+      Work();
+    }
+  }
+  std::mutex mu;
+  std::condition_variable cv, done_cv;
+  std::vector<std::thread> workers;
+  const std::function<void(int)>* job = nullptr;
+  int job_n = 0, next = 0, pending = 0, n_threads = 1;
+  uint64_t generation = 0;
+  bool stop = false;
+  std::exception_ptr error;
+};
+}  // namespace
+
+
 // ------------------------------------------------------------------------------------------------ compression
 // Body compression (Message.fbs BodyCompression, method BUFFER): every buffer is `int64 uncompressed_length` (-1 = the
 // bytes that follow are stored raw) + one frame.  The reference decompresses ZSTD on the CPU with DuckDB's bundled zstd
@@ -230,11 +318,19 @@ void IPCStreamReader::DecompressBody(RecordBatchMeta* meta) {
   if (meta->compression != 1) throw IOException("Unknown BodyCompression codec " + std::to_string(meta->compression));
   const ZstdApi& z = Zstd();
   if (!z.ok) throw NotImplementedException("ZSTD compressed IPC body but libzstd.so.1 is not available on this host");
-  // pass 1: uncompressed sizes -> layout of the new body (every buffer 64-byte aligned)
-  std::vector<int64_t> ulen(meta->buffers.size(), 0);
+  // pass 1: uncompressed sizes -> layout of the new body (every buffer 64-byte aligned); buffers of columns outside
+  // the projection are neither read (DecodeBody) nor decompressed
+  const std::vector<char> needed = NeededBuffers(*meta);
+  const size_t nbuf = meta->buffers.size();
+  std::vector<int64_t> ulen(nbuf, 0), opos(nbuf, 0);
   int64_t total = 0;
-  for (size_t i = 0; i < meta->buffers.size(); i++) {
-    const mi_buffer_span& b = meta->buffers[i];
+  for (size_t i = 0; i < nbuf; i++) {
+    mi_buffer_span& b = meta->buffers[i];
+    opos[i] = total;
+    if (!needed.empty() && !needed[i]) {
+      b.length = 0;
+      continue;
+    }
     if (b.length == 0) continue;
     if (b.offset < 0 || b.length < 8 || b.offset + b.length > cur_size)
       throw InternalException("Compressed buffer " + std::to_string(i) + " lies outside the message body");
@@ -248,21 +344,24 @@ void IPCStreamReader::DecompressBody(RecordBatchMeta* meta) {
   uint8_t* out = nullptr;
   std::shared_ptr<void> owner = body_allocator ? body_allocator(static_cast<size_t>(total + 64), message.type, &out)
                                                : DefaultBodyAlloc(static_cast<size_t>(total + 64), message.type, &out);
-  int64_t pos = 0;
-  for (size_t i = 0; i < meta->buffers.size(); i++) {
+  // pass 2: one frame per buffer, independent of each other -> the I/O pool's threads share them
+  const uint8_t* in = cur_ptr;
+  IoPool::Get().Run(static_cast<int>(nbuf), [&](int bi) {
+    const size_t i = static_cast<size_t>(bi);
     mi_buffer_span& b = meta->buffers[i];
     if (b.length == 0) {
-      b.offset = pos;
-      continue;
+      b.offset = opos[i];
+      return;
     }
-    const uint8_t* src = cur_ptr + b.offset;
+    const uint8_t* src = in + b.offset;
     int64_t declared;
     std::memcpy(&declared, src, 8);
     const int64_t n = ulen[i];
+    uint8_t* dst = out + opos[i];
     if (declared == -1) {
-      std::memcpy(out + pos, src + 8, static_cast<size_t>(n));
+      std::memcpy(dst, src + 8, static_cast<size_t>(n));
     } else {
-      const size_t code = z.decompress(out + pos, static_cast<size_t>(n), src + 8, static_cast<size_t>(b.length - 8));
+      const size_t code = z.decompress(dst, static_cast<size_t>(n), src + 8, static_cast<size_t>(b.length - 8));
       if (z.is_error(code)) {
         throw IOException("ZSTD_decompress([buffer with " + std::to_string(b.length - 8) + " bytes] -> [buffer with " +
                           std::to_string(n) + " bytes]) failed with error '" + z.error_name(code) + "'");
@@ -272,11 +371,10 @@ void IPCStreamReader::DecompressBody(RecordBatchMeta* meta) {
       }
     }
     const int64_t padded = (n + 63) & ~static_cast<int64_t>(63);
-    std::memset(out + pos + n, 0, static_cast<size_t>(padded - n));
-    b.offset = pos;
+    std::memset(dst + n, 0, static_cast<size_t>(padded - n));
+    b.offset = opos[i];
     b.length = n;
-    pos += padded;
-  }
+  });
   compressed_owner = cur_owner;  // released with the next message
   cur_owner = owner;
   cur_ptr = out;
@@ -309,26 +407,37 @@ static bool CountSubtreeBuffers(const ArrowField& f, const RecordBatchMeta& meta
   return true;
 }
 
+// Per RecordBatch.buffers entry: does a projected column own it?  Empty = all of them (no projection, dictionary batch,
+// or metadata the walk cannot follow -- the full validation reports that).
+std::vector<char> IPCStreamReader::NeededBuffers(const RecordBatchMeta& meta) const {
+  std::vector<char> need;
+  if (!HasProjection() || meta.is_dictionary) return need;
+  std::vector<char> wanted(base_schema.fields.size(), 0);
+  for (int32_t c : projected_columns) wanted[static_cast<size_t>(c)] = 1;
+  need.assign(meta.buffers.size(), 0);
+  size_t buf = 0, variadic = 0;
+  for (size_t i = 0; i < base_schema.fields.size(); i++) {
+    size_t n = 0;
+    if (!CountSubtreeBuffers(base_schema.fields[i], meta, &variadic, &n) || buf + n > meta.buffers.size()) return {};
+    if (wanted[i])
+      for (size_t k = buf; k < buf + n; k++) need[k] = 1;
+    buf += n;
+  }
+  return need;
+}
+
 std::vector<std::pair<int64_t, int64_t>> IPCStreamReader::ProjectedBodyRanges(const RecordBatchMeta& meta, int64_t body_length,
                                                                               int64_t gap) const {
   std::vector<std::pair<int64_t, int64_t>> ranges;
-  if (!HasProjection() || meta.is_dictionary || meta.compression != -1) return ranges;
-  std::vector<char> wanted(base_schema.fields.size(), 0);
-  for (int32_t c : projected_columns) wanted[static_cast<size_t>(c)] = 1;
-  size_t buf = 0, variadic = 0;
+  const std::vector<char> needed = NeededBuffers(meta);
+  if (needed.empty()) return ranges;
   std::vector<std::pair<int64_t, int64_t>> need;
-  for (size_t i = 0; i < base_schema.fields.size(); i++) {
-    size_t n = 0;
-    if (!CountSubtreeBuffers(base_schema.fields[i], meta, &variadic, &n) || buf + n > meta.buffers.size()) return ranges;
-    if (wanted[i]) {
-      for (size_t k = buf; k < buf + n; k++) {
-        const mi_buffer_span& b = meta.buffers[k];
-        if (b.length <= 0) continue;
-        if (b.offset < 0 || b.offset + b.length > body_length) return {};  // malformed: read everything, validation reports it
-        need.emplace_back(b.offset, b.offset + ((b.length + 7) & ~int64_t(7)));  // + the 8-byte padding kernels may touch
-      }
-    }
-    buf += n;
+  for (size_t k = 0; k < meta.buffers.size(); k++) {
+    if (!needed[k]) continue;
+    const mi_buffer_span& b = meta.buffers[k];
+    if (b.length <= 0) continue;
+    if (b.offset < 0 || b.offset + b.length > body_length) return {};  // malformed: read everything, validation reports it
+    need.emplace_back(b.offset, b.offset + ((b.length + 7) & ~int64_t(7)));  // + the 8-byte padding kernels may touch
   }
   std::sort(need.begin(), need.end());
   for (auto& r : need) {
@@ -527,93 +636,6 @@ double IPCFileStreamReader::GetProgress() {
   if (file_size == 0) return 100;
   return (static_cast<double>(offset) / static_cast<double>(file_size)) * 100;
 }
-
-// Large bodies are read with several concurrent pread()s: one thread copies out of the page cache at ~10 GB/s, far below
-// what the H2D link takes, so the body is cut into slices read in parallel (MI_IO_THREADS, default 8).
-namespace {
-class IoPool {
- public:
-  static IoPool& Get() {
-    static IoPool pool;
-    return pool;
-  }
-  int Threads() const { return n_threads; }
-  // runs fn(i) for i in [0, n) on the pool + the calling thread; rethrows the first failure
-  void Run(int n, const std::function<void(int)>& fn) {
-    if (n <= 1 || n_threads <= 1) {
-      for (int i = 0; i < n; i++) fn(i);
-      return;
-    }
-    std::unique_lock<std::mutex> lk(mu);
-    job = &fn;
-    job_n = n;
-    next = 0;
-    pending = n;
-    error = nullptr;
-    generation++;
-    cv.notify_all();
-    lk.unlock();
-    Work();
-    lk.lock();
-    done_cv.wait(lk, [&] { return pending == 0; });
-    job = nullptr;
-    if (error) std::rethrow_exception(error);
-  }
-
- private:
-  IoPool() {
-    const char* v = std::getenv("MI_IO_THREADS");
-    n_threads = v ? std::max(1, std::atoi(v)) : 8;
-    for (int i = 1; i < n_threads; i++) workers.emplace_back([this] { Loop(); });
-  }
-  ~IoPool() {
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      stop = true;
-    }
-    cv.notify_all();
-    for (auto& t : workers) t.join();
-  }
-  void Work() {
-    while (true) {
-      int i;
-      {
-        std::lock_guard<std::mutex> lk(mu);
-        if (!job || next >= job_n) return;
-        i = next++;
-      }
-      try {
-        (*job)(i);
-      } catch (...) {
-        std::lock_guard<std::mutex> lk(mu);
-        if (!error) error = std::current_exception();
-      }
-      std::lock_guard<std::mutex> lk(mu);
-      if (--pending == 0) done_cv.notify_all();
-    }
-  }
-  void Loop() {
-    uint64_t seen = 0;
-    while (true) {
-      {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return stop || generation != seen; });
-        if (stop) return;
-        seen = generation;
-      }
-      Work();
-    }
-  }
-  std::mutex mu;
-  std::condition_variable cv, done_cv;
-  std::vector<std::thread> workers;
-  const std::function<void(int)>* job = nullptr;
-  int job_n = 0, next = 0, pending = 0, n_threads = 1;
-  uint64_t generation = 0;
-  bool stop = false;
-  std::exception_ptr error;
-};
-}  // namespace
 
 const uint8_t* IPCFileStreamReader::ReadData(uint8_t* ptr, idx_t size) {
   // BufferedFileReader::ReadData throws SerializationException when the file ends early

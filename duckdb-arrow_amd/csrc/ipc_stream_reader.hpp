@@ -91,6 +91,7 @@ class IPCStreamReader {
   bool HasProjection() const { return !projected_fields.empty(); }
   //! Byte ranges of a record-batch body that hold the buffers of the projected columns (merged when closer than
   //! `gap`); empty = everything (no projection, compressed body, or malformed metadata: the full validation decides).
+  std::vector<char> NeededBuffers(const RecordBatchMeta& meta) const;
   std::vector<std::pair<int64_t, int64_t>> ProjectedBodyRanges(const RecordBatchMeta& meta, int64_t body_length, int64_t gap) const;
   const std::vector<int64_t>& ProjectedFlatFields() const { return projected_fields; }
 

@@ -17,6 +17,8 @@ def main():
     ap.add_argument("--dir", default="/dev/shm")
     ap.add_argument("--repeat", type=int, default=3)
     ap.add_argument("--files", type=int, default=8, help="config 3: also scan the table split into this many files")
+    ap.add_argument("--zstd", action="store_true", help="also: the reference benchmark's zstd-compressed Arrow IPC *file* "
+                                                         "(benchmark/lineitem.py:128-145), written here by pyarrow")
     args = ap.parse_args()
     import duckdb_arrow_amd as da
     buf, info = da.synth_lineitem_stream(scale_factor=args.sf, seed=42)
@@ -86,6 +88,31 @@ def main():
             finally:
                 for pth in paths:
                     os.unlink(pth)
+        if args.zstd:
+            import pyarrow as pa
+            import pyarrow.ipc as ipc
+            table = ipc.open_stream(path).read_all()
+            zpath = os.path.join(args.dir, "mi_lineitem_sf%g_zstd.arrow" % args.sf)
+            with ipc.new_file(zpath, table.schema, options=ipc.IpcWriteOptions(compression="zstd")) as w:
+                w.write_table(table, max_chunksize=122880)
+            del table
+            try:
+                z = {"file_bytes": os.path.getsize(zpath)}
+                for name, fn in (("count_all_columns", lambda: con.read_arrow(zpath).count()),
+                                 ("q6_fused_on_gpu", lambda: con.read_arrow(zpath).sum_product(
+                                     "l_extendedprice", "l_discount", [("l_shipdate", 8766, 9131), ("l_discount", 5, 8), ("l_quantity", -2**63, 2400)])[2]),
+                                 ("pyarrow_read_all_cpu", lambda: ipc.open_file(zpath).read_all().num_rows)):
+                    best = None
+                    for _ in range(args.repeat):
+                        t0 = time.perf_counter()
+                        n = fn()
+                        dt = time.perf_counter() - t0
+                        best = dt if best is None else min(best, dt)
+                    assert n == info["n_rows"]
+                    z[name] = {"seconds": best, "rows_per_s": info["n_rows"] / best}
+                out["zstd_ipc_file"] = z
+            finally:
+                os.unlink(zpath)
     finally:
         os.unlink(path)
     print(json.dumps(out))
