@@ -609,6 +609,16 @@ def _chunks_from_table(table, keep, chunk_rows=VECTOR_SIZE):
     return chunks
 
 
+def encode_schema(names, types):
+    """The Arrow IPC Schema message the writer emits for these DuckDB columns (host only)."""
+    fields = _c_fields(names, types)
+    size = C.c_int64(0)
+    _ffi.check(_ffi.lib().mi_encode_schema(fields, len(names), None, 0, C.byref(size)))
+    buf = np.zeros(size.value, np.uint8)
+    _ffi.check(_ffi.lib().mi_encode_schema(fields, len(names), buf.ctypes.data, buf.size, C.byref(size)))
+    return buf.tobytes()
+
+
 def _c_fields(names, types):
     arr = (_ffi.Field * len(names))()
     for i, (n, t) in enumerate(zip(names, types)):

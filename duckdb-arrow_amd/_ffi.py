@@ -161,6 +161,7 @@ SIGNATURES = {
     "mi_write_options_set": (C.c_int, [C.POINTER(WriteOptions), C.c_char_p, C.c_char_p]),
     "mi_write_options_add_kv": (C.c_int, [C.POINTER(WriteOptions), C.c_char_p, C.c_char_p, C.c_int32]),
     "mi_write_options_finalize": (C.c_int, [C.POINTER(WriteOptions)]),
+    "mi_encode_schema": (C.c_int, [C.POINTER(Field), C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "mi_writer_open": (C.c_int, [P, C.c_char_p, C.POINTER(Field), C.c_int32, C.POINTER(WriteOptions), PP]),
     "mi_writer_sink": (C.c_int, [P, C.POINTER(DataChunk)]),
     "mi_writer_finalize": (C.c_int, [P]),

@@ -575,6 +575,17 @@ int mi_write_options_finalize(mi_write_options* o) {
   });
 }
 
+int mi_encode_schema(const mi_field* fields, int32_t n_fields, uint8_t* out, int64_t cap, int64_t* size) {
+  return WrapC([&] {
+    if (!size) throw InvalidInputException("mi_encode_schema: NULL argument");
+    ArrowSchemaModel schema;
+    schema.fields = FieldsFromC(fields, n_fields);
+    const std::vector<uint8_t> msg = EncodeSchemaMessage(schema);
+    *size = static_cast<int64_t>(msg.size());
+    if (out && cap >= *size) std::memcpy(out, msg.data(), msg.size());
+  });
+}
+
 int mi_writer_open(mi_ctx* ctx, const char* path, const mi_field* fields, int32_t n_fields, const mi_write_options* opts,
                    mi_writer** out) {
   return WrapC([&] {

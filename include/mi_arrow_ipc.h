@@ -411,6 +411,11 @@ int mi_write_options_set(mi_write_options* o, const char* name, const char* valu
 int mi_write_options_add_kv(mi_write_options* o, const char* key, const char* value, int32_t value_len);
 int mi_write_options_finalize(mi_write_options* o);
 
+/* The Schema message (encapsulated: continuation token + length + flatbuffer, padded to 8) the writer emits for
+ * these columns -- ColumnDataCollectionSerializer::SerializeSchema (column_data_collection_serializer.cpp:59-65) over
+ * ArrowConverter::ToArrowSchema.  Host only (no GPU needed).  *size = bytes needed; copied when cap suffices. */
+int mi_encode_schema(const mi_field* fields, int32_t n_fields, uint8_t* out, int64_t cap, int64_t* size);
+
 /* ArrowWriteInitializeGlobal (write_arrow_stream.cpp:127-139): creates the file, truncating an existing one
  * (FILE_FLAGS_FILE_CREATE_NEW = create-or-truncate in DuckDB, arrow_stream_writer.cpp:49-53) and writes the Schema message.
  * `fields`: name + duck_type per column: "BIGINT", "DECIMAL(15,2)", "VARCHAR", "DATE", "BOOLEAN", ... and the nested
