@@ -132,6 +132,9 @@ static void ValidateTask(const mi_col_task& t, size_t i) {
       if (t.out_aux == nullptr) fail("out_aux (string data) is NULL");
       if (reinterpret_cast<uintptr_t>(t.buf1) % 16 != 0) fail("string_t vector must be 16-byte aligned");
       break;
+    case MI_K_ENC_LIST32:
+      if (reinterpret_cast<uintptr_t>(t.buf1) % 16 != 0) fail("list_entry_t vector must be 16-byte aligned");
+      break;
     default: break;
   }
   if (t.kind >= MI_K_ENC_COPY && t.kind != MI_K_ENC_COPY && t.out_validity == nullptr)
@@ -167,7 +170,7 @@ static int64_t TaskBytesRead(const mi_col_task& t) {
     switch (t.kind) {
       case MI_K_ENC_COPY: case MI_K_ENC_DEC128: b += n * t.param; break;
       case MI_K_ENC_BOOL: b += n; break;
-      case MI_K_ENC_STR32: b += n * 16; break;  // + payload, known only after the scan (reported via buf2_len if given)
+      case MI_K_ENC_STR32: case MI_K_ENC_LIST32: b += n * 16; break;  // + payload, known only after the scan (reported via buf2_len if given)
       default: break;
     }
     if (t.kind == MI_K_ENC_STR32) b += t.buf2_len;
@@ -186,6 +189,7 @@ static int64_t TaskBytesWritten(const mi_col_task& t) {
     case MI_K_ENC_DEC128: b += n * 16; break;
     case MI_K_ENC_BOOL: b += (n + 7) / 8; break;
     case MI_K_ENC_STR32: b += (n + 1) * 4 + t.buf2_len; break;
+    case MI_K_ENC_LIST32: b += (n + 1) * 4; break;
     default: break;
   }
   return b;

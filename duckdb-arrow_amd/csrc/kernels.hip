@@ -929,7 +929,8 @@ __global__ __launch_bounds__(kBlockThreads) void encode_string_tile_sums(const m
   __shared__ int64_t lds4[kBlockThreads / 64];
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     MI_TILE_PROLOGUE();
-    gptr<const uint32_t> lens = GC<uint32_t>(t.buf1) + 4 * row0;  // string_t.length every 16 B
+    // string_t.length (dword 0) or, for MI_K_ENC_LIST32, list_entry_t.length (low dword of the second u64) every 16 B
+    gptr<const uint32_t> lens = GC<uint32_t>(t.buf1) + 4 * row0 + (t.kind == MI_K_ENC_LIST32 ? 2 : 0);
     gptr<const uint64_t> valid = GC<uint64_t>(t.validity);
     const bool has = t.validity != nullptr;
     int64_t local = 0;
@@ -989,12 +990,16 @@ __device__ __forceinline__ void encode_string_tile_generic(const mi_col_task& t,
     uint32_t len = 0;
     if (r < n) {
       s = str[r];
-      len = enc_row_valid(valid, has, row0 + r) ? s.x : 0u;
+      len = enc_row_valid(valid, has, row0 + r) ? (t.kind == MI_K_ENC_LIST32 ? s.z : s.x) : 0u;
     }
     int64_t total;
     const int64_t ex = block_exclusive_scan(static_cast<int64_t>(len), &total, lds4);
     const int64_t pos = base + ex;
     if (r < n) off[row0 + r + 1] = static_cast<int32_t>(pos + len);
+    if (t.kind == MI_K_ENC_LIST32) {  // offsets only
+      base += total;
+      continue;
+    }
     // LDS image: byte i of the sub-block's payload lives at stage[shift + i], shift = base mod 16, so that 16-byte
     // aligned global addresses are 16-byte aligned LDS addresses
     const int shift = static_cast<int>(base & 15);
@@ -1251,9 +1256,10 @@ __global__ __launch_bounds__(kBlockThreads, OCC) void encode_string_v5(const mi_
         nxt = __builtin_nontemporal_load(str + (rn < n ? rn : n - 1));
       }
       const bool ok = r < n && ((s_valid[r >> 6] >> (r & 63)) & 1);
-      const uint32_t len = ok ? s.x : 0u;
+      const bool is_list = t.kind == MI_K_ENC_LIST32;  // offsets only: the "payload" is the child node, encoded on its own
+      const uint32_t len = ok ? (is_list ? s.z : s.x) : 0u;
       uint32_t W[14];
-      if (len > 12) {
+      if (len > 12 && !is_list) {
         const uint64_t p = static_cast<uint64_t>(s.z) | (static_cast<uint64_t>(s.w) << 32);
         heap_load13(heap + (p - t.ptr_base), len, W);
       }
@@ -1279,7 +1285,7 @@ __global__ __launch_bounds__(kBlockThreads, OCC) void encode_string_v5(const mi_
       const uint32_t total = tot.x + tot.y + tot.z + tot.w;
       const uint32_t ex = before + incl - len;
       if (r < n) offp[r] = static_cast<int32_t>(base + ex + len);
-      for (uint32_t w0 = 0; w0 < total;) {  // uniform: stage windows
+      for (uint32_t w0 = 0; w0 < total && !is_list;) {  // uniform: stage windows
         const uint32_t shiftw = static_cast<uint32_t>((base + w0) & 15);
         const uint32_t room = static_cast<uint32_t>(kEncStage5) - shiftw;
         const uint32_t w1 = total - w0 < room ? total : w0 + room;
@@ -1336,7 +1342,7 @@ int ClassOfKind(int32_t kind) {
     case MI_K_DICT: case MI_K_INTERVAL_MONTHS: case MI_K_INTERVAL_MDN: case MI_K_NARROW: case MI_K_HALF_FLOAT:
     case MI_K_NULL: case MI_K_STRVIEW: case MI_K_LIST32: case MI_K_LIST64: case MI_K_STRUCT: return kClassMisc;
     case MI_K_ENC_COPY: case MI_K_ENC_DEC128: case MI_K_ENC_BOOL: case MI_K_ENC_VALIDITY: return kClassEncFixed;
-    case MI_K_ENC_STR32: return kClassEncString;
+    case MI_K_ENC_STR32: case MI_K_ENC_LIST32: return kClassEncString;
     default: return -1;
   }
 }

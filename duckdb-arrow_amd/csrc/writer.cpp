@@ -99,7 +99,7 @@ int32_t ChunkCollection::AddField(const ArrowField& f, int32_t depth) {
     switch (f.type) {
       case MI_AT_STRUCT: break;
       case MI_AT_FIXED_LIST: c.param = f.byte_width; break;
-      case MI_AT_LIST: case MI_AT_MAP: c.enc_kind = MI_K_ENC_COPY; c.param = 4; c.width = 4; break;
+      case MI_AT_LIST: case MI_AT_MAP: c.enc_kind = MI_K_ENC_LIST32; c.param = 0; c.width = 16; break;
       default: EncodePlanFor(f, &c.enc_kind, &c.param, &c.width); break;
     }
   }
@@ -120,10 +120,9 @@ ChunkCollection::~ChunkCollection() {
 
 void ChunkCollection::Reserve(Column& c, int64_t rows, int64_t extra_heap) {
   ctx->Bind();
-  const int64_t lead = c.IsList() ? 1 : 0;  // a list stages count + 1 offsets
   if (c.width > 0)
-    GrowPinned(&c.data, &c.data_cap, static_cast<size_t>(rows + lead) * static_cast<size_t>(c.width) + 64,
-               static_cast<size_t>(c.count + lead) * static_cast<size_t>(c.width));
+    GrowPinned(&c.data, &c.data_cap, static_cast<size_t>(rows) * static_cast<size_t>(c.width) + 64,
+               static_cast<size_t>(c.count) * static_cast<size_t>(c.width));
   const size_t old_vcap = c.validity_cap;
   GrowPinned(&c.validity, &c.validity_cap, static_cast<size_t>((rows + 63) / 64) * 8 + 16, static_cast<size_t>((c.count + 63) / 64) * 8);
   if (c.validity_cap != old_vcap) {
@@ -174,34 +173,30 @@ void ChunkCollection::AppendNode(int32_t ni, const mi_vector& v, int64_t start, 
     return;
   }
   if (c.IsList()) {
-    // Arrow offsets are staged here; the child rows of every valid list are gathered in order (ArrowListData::Append)
+    // the list_entry_t rows are staged as they are (the GPU turns the lengths of the valid rows into Arrow offsets);
+    // the child rows of every valid list are gathered here, in list order (ArrowListData::Append)
     const uint64_t* ent = static_cast<const uint64_t*>(v.data) + 2 * start;
-    int32_t* offs = reinterpret_cast<int32_t*>(c.data);
-    if (c.count == 0) offs[0] = 0;
-    int64_t last = offs[c.count];
+    std::memcpy(c.data + static_cast<size_t>(c.count) * 16, ent, static_cast<size_t>(n) * 16);
     int64_t run_start = 0, run_len = 0;
     const int32_t child = c.children[0];
-    const int64_t row_base = c.count;
     c.count += n;
-    size_in_bytes += n * 4;
+    size_in_bytes += n * 16;
     for (int64_t i = 0; i < n; i++) {
-      if (BitAt(v.validity, vbit + i)) {
-        const int64_t o = static_cast<int64_t>(ent[2 * i]), l = static_cast<int64_t>(ent[2 * i + 1]);
-        if (l > 0) {
-          if (run_len > 0 && o == run_start + run_len) {
-            run_len += l;
-          } else {
-            if (run_len > 0) AppendNode(child, v.children[0], run_start, run_len);
-            run_start = o;
-            run_len = l;
-          }
-          last += l;
-          if (last > 0x7FFFFFFFll)
-            throw InvalidInputException("Arrow Appender: The maximum combined list offset for regular list buffers is 2147483647 but the offset of " +
-                                        std::to_string(last) + " exceeds this.\n* SET arrow_large_buffer_size=true to use large list buffers");
-        }
+      if (!BitAt(v.validity, vbit + i)) continue;
+      const int64_t o = static_cast<int64_t>(ent[2 * i]), l = static_cast<int64_t>(ent[2 * i + 1]);
+      if (l <= 0) continue;
+      if (run_len > 0 && o == run_start + run_len) {
+        run_len += l;
+      } else {
+        if (run_len > 0) AppendNode(child, v.children[0], run_start, run_len);
+        run_start = o;
+        run_len = l;
       }
-      reinterpret_cast<int32_t*>(columns[static_cast<size_t>(ni)].data)[row_base + i + 1] = static_cast<int32_t>(last);
+      columns[static_cast<size_t>(ni)].payload_bytes += l;   // child rows so far = the last Arrow offset
+      if (columns[static_cast<size_t>(ni)].payload_bytes > 0x7FFFFFFFll)
+        throw InvalidInputException("Arrow Appender: The maximum combined list offset for regular list buffers is 2147483647 but the offset of " +
+                                    std::to_string(columns[static_cast<size_t>(ni)].payload_bytes) +
+                                    " exceeds this.\n* SET arrow_large_buffer_size=true to use large list buffers");
     }
     if (run_len > 0) AppendNode(child, v.children[0], run_start, run_len);
     return;
@@ -304,7 +299,7 @@ idx_t ColumnDataCollectionSerializer::Serialize(ChunkCollection& buffer) {
         default: break;
       }
     }
-    const int64_t staged_rows = n + (c.IsList() ? 1 : 0);
+    const int64_t staged_rows = n;
     in_off[ci].data = in_bytes;
     in_bytes += RoundUp(static_cast<size_t>(staged_rows) * static_cast<size_t>(c.width) + 16, 256);
     in_off[ci].validity = in_bytes;
@@ -326,7 +321,7 @@ idx_t ColumnDataCollectionSerializer::Serialize(ChunkCollection& buffer) {
     const int64_t n = c.count;
     if (n == 0) continue;  // zero-length buffers, no work
     const size_t sp = in_off[ci].first_span;
-    const int64_t staged_rows = n + (c.IsList() ? 1 : 0);
+    const int64_t staged_rows = n;
     if (c.width > 0)
       MI_HIP_CHECK(hipMemcpyAsync(d_in + in_off[ci].data, c.data, static_cast<size_t>(staged_rows) * static_cast<size_t>(c.width), hipMemcpyHostToDevice, s));
     if (c.has_nulls)
@@ -339,22 +334,19 @@ idx_t ColumnDataCollectionSerializer::Serialize(ChunkCollection& buffer) {
     t.validity = c.has_nulls ? d_in + in_off[ci].validity : nullptr;
     t.out_validity = d_body + spans[sp].offset;
     validity_task[ci] = static_cast<int32_t>(tasks.size());
-    if (c.IsGroup() || c.IsList()) {
-      // struct / fixed_size_list / list / map: the node's own bitmap + NULL count
+    if (c.IsGroup()) {
+      // struct / fixed_size_list: the node's own bitmap + NULL count
       t.kind = MI_K_ENC_VALIDITY;
       t.buf1 = d_in + in_off[ci].validity;
       t.out_data = d_body + spans[sp].offset;
       tasks.push_back(t);
-      if (c.IsList()) {  // the staged int32 offsets
-        mi_col_task o;
-        std::memset(&o, 0, sizeof(o));
-        o.kind = MI_K_ENC_COPY;
-        o.param = 4;
-        o.nrows = n + 1;
-        o.buf1 = d_in + in_off[ci].data;
-        o.out_data = d_body + spans[sp + 1].offset;
-        tasks.push_back(o);
-      }
+      continue;
+    }
+    if (c.IsList()) {  // list / map: bitmap + int32 offsets from the staged list_entry_t rows
+      t.kind = MI_K_ENC_LIST32;
+      t.buf1 = d_in + in_off[ci].data;
+      t.out_data = d_body + spans[sp + 1].offset;
+      tasks.push_back(t);
       continue;
     }
     t.kind = c.enc_kind;

@@ -28,7 +28,7 @@ namespace miarrow {
 //! write_arrow_stream.cpp:43-52): per FIELD NODE (depth first; a flat column is one node) a pinned staging array in
 //! DuckDB layout.  Nested vectors are flattened while they are appended, the way ArrowAppender walks them: struct and
 //! fixed-size-list children take every parent row, a list's child rows are gathered in list order (NULL lists add none)
-//! and the list node itself stages its int32 Arrow offsets.
+//! and the list node itself stages its list_entry_t rows (the GPU turns their lengths into the int32 Arrow offsets).
 class ChunkCollection {
  public:
   ChunkCollection(Context* ctx, const std::vector<ArrowField>& fields);
@@ -39,17 +39,17 @@ class ChunkCollection {
   int64_t SizeInBytes() const { return size_in_bytes; }
 
   struct Column {
-    int32_t enc_kind = 0;    // MI_K_ENC_* of a leaf; MI_K_ENC_COPY for the offsets of a list; 0 for struct / fixed-size list
+    int32_t enc_kind = 0;    // MI_K_ENC_* of a leaf; MI_K_ENC_LIST32 for a list / map; 0 for struct / fixed-size list
     int32_t arrow_type = 0;  // MI_AT_*
     int64_t param = 0;       // vector element width (or decimal physical width); fixed_size_list: list size
-    int32_t width = 0;       // bytes per staged row (list: 4 = one int32 offset per row, +1 leading)
+    int32_t width = 0;       // bytes per staged row (list: 16 = one list_entry_t)
     int32_t depth = 0;
     int64_t count = 0;       // rows buffered in this node
     uint8_t* data = nullptr;      size_t data_cap = 0;       // pinned
     uint64_t* validity = nullptr; size_t validity_cap = 0;   // pinned words
     uint8_t* heap = nullptr;      size_t heap_cap = 0;       // pinned payload of long strings (pointer = heap offset)
     int64_t heap_used = 0;
-    int64_t payload_bytes = 0;    // sum of valid string lengths = size of the Arrow data buffer
+    int64_t payload_bytes = 0;    // sum of valid string lengths = size of the Arrow data buffer (list: child rows gathered)
     bool has_nulls = false;
     std::vector<int32_t> children;
     bool IsList() const { return arrow_type == MI_AT_LIST || arrow_type == MI_AT_MAP; }

@@ -105,8 +105,10 @@ enum mi_kind {
   MI_K_ENC_DEC128 = 33,   /* K7b int16/32/64 -> decimal128 sign extension; param = in width */
   MI_K_ENC_BOOL = 34,     /* K7c byte -> bit, bits start as 1 */
   MI_K_ENC_STR32 = 35,    /* K7d string_t -> int32 offsets + data */
-  MI_K_ENC_VALIDITY = 36  /* K7a alone: validity words -> always-present bitmap + NULL count (the node of a struct /
-                           * list / map / fixed_size_list; their offsets travel as MI_K_ENC_COPY with out_validity NULL) */
+  MI_K_ENC_VALIDITY = 36, /* K7a alone: validity words -> always-present bitmap + NULL count (struct / fixed_size_list node) */
+  MI_K_ENC_LIST32 = 37    /* list_entry_t{u64 offset, u64 length} rows -> bitmap + int32 Arrow offsets (running sum of the
+                           * lengths of the valid rows, NULL rows repeat the offset: ArrowListData::AppendOffsets); the
+                           * child rows are a node of their own, gathered in list order */
 };
 
 typedef struct mi_field {
