@@ -274,6 +274,7 @@ void Plan::Set(const mi_col_task* in_tasks, int32_t n_tasks, hipStream_t upload_
         tiles += nt;
         if (tiles > 0xFFFFFFF0ull) throw InvalidInputException("plan has too many tiles");
         tile_task.insert(tile_task.end(), static_cast<size_t>(nt), local_task);
+        if (c == device::kClassEncString) sl.misc_groups |= t.kind == MI_K_ENC_LIST32 ? 2u : 1u;
         if (c == device::kClassMisc)
           sl.misc_groups |= (t.kind == MI_K_LIST32 || t.kind == MI_K_LIST64 || t.kind == MI_K_STRVIEW || t.kind == MI_K_STRUCT) ? 2u
                             : (t.kind == MI_K_BOOL || t.kind == MI_K_DICT || t.kind == MI_K_DATE64 || t.kind == MI_K_MUL_I32 ||
@@ -364,7 +365,7 @@ void Plan::LaunchSlice(const ClassSlice& cs, hipStream_t s) {
     case device::kClassEncString:
       MI_HIP_CHECK(device::LaunchEncodeStringTileSums(t, tb, tt, cs.n_tasks, cs.total_tiles, d_tile_sums, grid, s));
       MI_HIP_CHECK(device::LaunchEncodeStringScan(t, tb, cs.n_tasks, d_tile_sums, d_status, s));
-      MI_HIP_CHECK(device::LaunchEncodeString(t, tb, tt, cs.n_tasks, cs.total_tiles, d_tile_sums, d_null_counts, grid, s));
+      MI_HIP_CHECK(device::LaunchEncodeString(t, tb, tt, cs.n_tasks, cs.total_tiles, d_tile_sums, d_null_counts, grid, cs.misc_groups, s));
       break;
     default:
       MI_HIP_CHECK(device::LaunchTranscode(cs.cls, t, tb, tt, cs.n_tasks, cs.total_tiles, d_status, cs.misc_groups,

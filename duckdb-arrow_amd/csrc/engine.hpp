@@ -44,7 +44,8 @@ struct ClassSlice {
   int32_t n_tasks = 0;
   int32_t tile_begin_at = 0;  // index into Plan::tile_begin / d_tile_begin (n_tasks + 1 entries)
   uint32_t total_tiles = 0;
-  uint32_t misc_groups = 0;   // class misc only: bit 0 = flat kinds present, bit 1 = nested kinds (list / string view / struct)
+  uint32_t misc_groups = 0;   // which kernels of the class have work.  misc: bit 0 common flat kinds, bit 1 nested kinds
+                              // (list / string view / struct), bit 2 rare flat kinds; enc_string: bit 0 strings, bit 1 lists
 };
 
 // A plan = any number of (record batch, column) tasks, grouped by kernel class; Launch() enqueues one kernel per

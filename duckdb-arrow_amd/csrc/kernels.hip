@@ -1052,6 +1052,8 @@ __device__ __forceinline__ void encode_string_tile_generic(const mi_col_task& t,
   }
 }
 
+// LISTS_ONLY = false: every tile (variant 0 of the A/B knob); true: only the MI_K_ENC_LIST32 tiles, beside encode_string_v5
+template <bool LISTS_ONLY>
 __global__ __launch_bounds__(kBlockThreads) void encode_string(const mi_col_task* __restrict__ tasks,
                                                                const uint32_t* __restrict__ tile_begin,
                                                                const uint32_t* __restrict__ tile_task, int n_tasks,
@@ -1061,6 +1063,7 @@ __global__ __launch_bounds__(kBlockThreads) void encode_string(const mi_col_task
   __shared__ __attribute__((aligned(16))) uint8_t stage[kEncStage + 16];
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     MI_TILE_PROLOGUE();
+    if (LISTS_ONLY && t.kind != MI_K_ENC_LIST32) continue;  // uniform
     enc_tile_validity(t, row0, n, null_counts);
     encode_string_tile_generic(t, row0, n, tile_sums[tile], lds4, stage);
     __syncthreads();
@@ -1225,7 +1228,7 @@ template <int OCC>
 __global__ __launch_bounds__(kBlockThreads, OCC) void encode_string_v5(const mi_col_task* __restrict__ tasks,
                                                                   const uint32_t* __restrict__ tile_begin,
                                                                   const uint32_t* __restrict__ tile_task, int n_tasks,
-                                                                  uint32_t total_tiles, const int64_t* __restrict__ tile_sums,
+                                                                  uint32_t total_tiles, int64_t* __restrict__ tile_sums,
                                                                   int64_t* __restrict__ null_counts) {
   constexpr int kWaves = kBlockThreads / 64;
   static_assert(kWaves == 4, "wave totals travel as one 16-byte LDS row");
@@ -1236,12 +1239,14 @@ __global__ __launch_bounds__(kBlockThreads, OCC) void encode_string_v5(const mi_
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     MI_TILE_PROLOGUE();
+    if (t.kind == MI_K_ENC_LIST32) continue;  // uniform: list offsets are the other launch's tiles (encode_string<1>)
     enc_tile_validity(t, row0, n, null_counts, s_valid);
     gptr<const u32x4> str = GC<u32x4>(t.buf1) + row0;
     gptr<const uint8_t> heap = GC<uint8_t>(t.buf2);
     gptr<int32_t> offp = GM<int32_t>(t.out_data) + row0 + 1;
     gptr<uint8_t> data = GM<uint8_t>(t.out_aux);
-    int64_t base = tile_sums[tile];
+    const int64_t tile_base = tile_sums[tile];
+    int64_t base = tile_base;
     if (row0 == 0 && threadIdx.x == 0) offp[-1] = 0;
     const int nsub = (n + kBlockThreads - 1) / kBlockThreads;
     u32x4 nxt = __builtin_nontemporal_load(str + (static_cast<int>(threadIdx.x) < n ? static_cast<int>(threadIdx.x) : n - 1));
@@ -1256,10 +1261,9 @@ __global__ __launch_bounds__(kBlockThreads, OCC) void encode_string_v5(const mi_
         nxt = __builtin_nontemporal_load(str + (rn < n ? rn : n - 1));
       }
       const bool ok = r < n && ((s_valid[r >> 6] >> (r & 63)) & 1);
-      const bool is_list = t.kind == MI_K_ENC_LIST32;  // offsets only: the "payload" is the child node, encoded on its own
-      const uint32_t len = ok ? (is_list ? s.z : s.x) : 0u;
+      const uint32_t len = ok ? s.x : 0u;
       uint32_t W[14];
-      if (len > 12 && !is_list) {
+      if (len > 12) {
         const uint64_t p = static_cast<uint64_t>(s.z) | (static_cast<uint64_t>(s.w) << 32);
         heap_load13(heap + (p - t.ptr_base), len, W);
       }
@@ -1270,22 +1274,17 @@ __global__ __launch_bounds__(kBlockThreads, OCC) void encode_string_v5(const mi_
       __syncthreads();
       const u32x4 tot = *reinterpret_cast<const u32x4*>(&s_tot[k & 1][0]);
       if ((tot.x | tot.y | tot.z | tot.w) & 0x80000000u) {
-        // uniform: a string of >= 8 MiB in this sub-block -- 32-bit sums may wrap; the 64-bit formulation does the rows
-        __syncthreads();
-        int64_t total64;
-        block_exclusive_scan(static_cast<int64_t>(len), &total64, lds4);
-        const int64_t sub0 = static_cast<int64_t>(k) * kBlockThreads;
-        encode_string_tile_generic(t, row0 + sub0, n - static_cast<int>(sub0) < kBlockThreads ? n - static_cast<int>(sub0) : kBlockThreads,
-                                   base, lds4, stage);
-        __syncthreads();
-        base += total64;
-        continue;
+        // uniform: a string of >= 8 MiB in this sub-block -- 32-bit sums may wrap.  The tile is handed to the 64-bit
+        // formulation (encode_string_redo, launched right after this kernel) by setting the sign bit of its base; the
+        // rare path stays out of this kernel's register budget (inlined here it cost 28 VGPRs = two occupancy steps)
+        if (threadIdx.x == 0) tile_sums[tile] = tile_base | static_cast<int64_t>(0x8000000000000000ull);
+        break;
       }
       const uint32_t before = (wave > 0 ? tot.x : 0u) + (wave > 1 ? tot.y : 0u) + (wave > 2 ? tot.z : 0u);
       const uint32_t total = tot.x + tot.y + tot.z + tot.w;
       const uint32_t ex = before + incl - len;
       if (r < n) offp[r] = static_cast<int32_t>(base + ex + len);
-      for (uint32_t w0 = 0; w0 < total && !is_list;) {  // uniform: stage windows
+      for (uint32_t w0 = 0; w0 < total;) {  // uniform: stage windows
         const uint32_t shiftw = static_cast<uint32_t>((base + w0) & 15);
         const uint32_t room = static_cast<uint32_t>(kEncStage5) - shiftw;
         const uint32_t w1 = total - w0 < room ? total : w0 + room;
@@ -1316,6 +1315,34 @@ __global__ __launch_bounds__(kBlockThreads, OCC) void encode_string_v5(const mi_
       base += total;
     }
     __syncthreads();  // s_valid / stage are rewritten by the next tile
+  }
+}
+
+// Tiles encode_string_v5 gave up on (sign bit of tile_sums set): 64-bit positions, sub-block by sub-block.  A small
+// persistent grid sweeps the flags 256 at a time; validity bitmap and NULL count were already written by v5.
+__global__ __launch_bounds__(kBlockThreads) void encode_string_redo(const mi_col_task* __restrict__ tasks,
+                                                                    const uint32_t* __restrict__ tile_begin,
+                                                                    const uint32_t* __restrict__ tile_task, int n_tasks,
+                                                                    uint32_t total_tiles, const int64_t* __restrict__ tile_sums,
+                                                                    int64_t* __restrict__ null_counts) {
+  __shared__ int64_t lds4[kBlockThreads / 64];
+  __shared__ __attribute__((aligned(16))) uint8_t stage[kEncStage + 16];
+  __shared__ uint32_t s_todo[kBlockThreads];
+  __shared__ uint32_t s_ntodo;
+  for (uint32_t first = blockIdx.x * kBlockThreads; first < total_tiles; first += gridDim.x * kBlockThreads) {
+    if (threadIdx.x == 0) s_ntodo = 0;
+    __syncthreads();
+    const uint32_t mine = first + threadIdx.x;
+    if (mine < total_tiles && tile_sums[mine] < 0) s_todo[atomicAdd(&s_ntodo, 1u)] = mine;
+    __syncthreads();
+    const uint32_t ntodo = s_ntodo;
+    for (uint32_t j = 0; j < ntodo; j++) {
+      const uint32_t tile = s_todo[j];
+      MI_TILE_PROLOGUE();
+      encode_string_tile_generic(t, row0, n, tile_sums[tile] & 0x7FFFFFFFFFFFFFFFll, lds4, stage);
+      __syncthreads();
+    }
+    __syncthreads();
   }
 }
 
@@ -1490,22 +1517,28 @@ hipError_t LaunchEncodeFixed(const mi_col_task* d_tasks, const uint32_t* d_tile_
 
 hipError_t LaunchEncodeString(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
                               int32_t n_tasks, uint32_t total_tiles, const int64_t* d_tile_sums, int64_t* d_null_counts,
-                              int grid_blocks, hipStream_t stream) {
+                              int grid_blocks, uint32_t groups, hipStream_t stream) {
   if (total_tiles == 0) return hipSuccess;
   const uint32_t* tt = TuneRef().use_tile_table ? d_tile_task : nullptr;
   const int ev = TuneRef().enc_string_variant;
-  if (ev == 1)
-    hipLaunchKernelGGL(encode_string_v5<4>, dim3(enc_grid(total_tiles, grid_blocks)), dim3(kBlockThreads), 0, stream, d_tasks,
-                       d_tile_begin, tt, n_tasks, total_tiles, d_tile_sums, d_null_counts);
-  else if (ev == 2)
-    hipLaunchKernelGGL(encode_string_v5<5>, dim3(enc_grid(total_tiles, grid_blocks)), dim3(kBlockThreads), 0, stream, d_tasks,
-                       d_tile_begin, tt, n_tasks, total_tiles, d_tile_sums, d_null_counts);
-  else if (ev == 3)
-    hipLaunchKernelGGL(encode_string_v5<6>, dim3(enc_grid(total_tiles, grid_blocks)), dim3(kBlockThreads), 0, stream, d_tasks,
-                       d_tile_begin, tt, n_tasks, total_tiles, d_tile_sums, d_null_counts);
-  else
-    hipLaunchKernelGGL(encode_string, dim3(enc_grid(total_tiles, grid_blocks)), dim3(kBlockThreads), 0, stream, d_tasks,
-                       d_tile_begin, tt, n_tasks, total_tiles, d_tile_sums, d_null_counts);
+  const dim3 grid(enc_grid(total_tiles, grid_blocks)), block(kBlockThreads);
+#define MI_ENC_LAUNCH(KERNEL) \
+  hipLaunchKernelGGL(KERNEL, grid, block, 0, stream, d_tasks, d_tile_begin, tt, n_tasks, total_tiles, d_tile_sums, d_null_counts)
+  if (ev == 0) {
+    MI_ENC_LAUNCH(encode_string<false>);
+  } else {
+    if (groups & 1u) {  // strings
+      int64_t* sums = const_cast<int64_t*>(d_tile_sums);
+      if (ev == 2) hipLaunchKernelGGL(encode_string_v5<5>, grid, block, 0, stream, d_tasks, d_tile_begin, tt, n_tasks, total_tiles, sums, d_null_counts);
+      else if (ev == 3) hipLaunchKernelGGL(encode_string_v5<4>, grid, block, 0, stream, d_tasks, d_tile_begin, tt, n_tasks, total_tiles, sums, d_null_counts);
+      else hipLaunchKernelGGL(encode_string_v5<6>, grid, block, 0, stream, d_tasks, d_tile_begin, tt, n_tasks, total_tiles, sums, d_null_counts);
+      const uint32_t sweep = (total_tiles + kBlockThreads - 1) / kBlockThreads;
+      hipLaunchKernelGGL(encode_string_redo, dim3(sweep < 512u ? sweep : 512u), block, 0, stream, d_tasks, d_tile_begin, tt, n_tasks,
+                         total_tiles, d_tile_sums, d_null_counts);
+    }
+    if (groups & 2u) MI_ENC_LAUNCH(encode_string<true>);  // list / map offsets
+  }
+#undef MI_ENC_LAUNCH
   return hipGetLastError();
 }
 

@@ -69,7 +69,7 @@ hipError_t LaunchEncodeFixed(const mi_col_task* d_tasks, const uint32_t* d_tile_
                              int32_t n_tasks, uint32_t total_tiles, int64_t* d_null_counts, int grid_blocks,
                              hipStream_t stream);
 hipError_t LaunchEncodeString(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
-                              int32_t n_tasks, uint32_t total_tiles, const int64_t* d_tile_sums, int64_t* d_null_counts, int grid_blocks,
+                              int32_t n_tasks, uint32_t total_tiles, const int64_t* d_tile_sums, int64_t* d_null_counts, int grid_blocks, uint32_t groups,
                               hipStream_t stream);
 
 }  // namespace device
