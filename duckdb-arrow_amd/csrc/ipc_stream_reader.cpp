@@ -210,6 +210,7 @@ class IoPool {
       for (int i = 0; i < n; i++) fn(i);
       return;
     }
+    std::lock_guard<std::mutex> one_job_at_a_time(run_mu);  // readers of different scans may call from different threads
     std::unique_lock<std::mutex> lk(mu);
     job = &fn;
     job_n = n;
@@ -270,7 +271,7 @@ class IoPool {
       Work();
     }
   }
-  std::mutex mu;
+  std::mutex mu, run_mu;
   std::condition_variable cv, done_cv;
   std::vector<std::thread> workers;
   const std::function<void(int)>* job = nullptr;

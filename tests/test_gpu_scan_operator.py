@@ -415,3 +415,34 @@ def test_fused_aggregate_semantics(con, tmp_path):
     assert con.read_arrow(path).sum_product("b", "b")[1] == n        # no filter: every row selected
     with pytest.raises(da.MiError, match="not a fixed-width integer-like column"):
         con.read_arrow(path).sum_product("a", "s")
+
+
+def test_two_worker_threads_with_their_own_contexts(golden_dir, tmp_path):
+    """The boundary's threading contract: one context per (device, worker), entry points re-entrant across
+    contexts -- DuckDB scans different files from different threads.  Two threads scan concurrently (ctypes drops the
+    GIL inside the calls), sharing only the process-wide I/O pool."""
+    import threading
+    buf, info = da.synth_lineitem_stream(scale_factor=0.2, seed=12)
+    paths = []
+    for i in range(2):
+        p = str(tmp_path / ("t%d.arrows" % i))
+        buf.tofile(p)
+        paths.append(p)
+    results, errors = {}, []
+
+    def worker(i):
+        try:
+            c = da.Connection(0)
+            for rep in range(3):
+                rows = c.read_arrow(paths[i]).count()
+                total, sel, scanned = c.read_arrow(paths[i]).sum_product("l_extendedprice", "l_discount", Q6_FILTERS)
+                results[(i, rep)] = (rows, total, sel, scanned)
+            c.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+    assert len(set(results.values())) == 1 and next(iter(results.values()))[0] == info["n_rows"]
