@@ -310,15 +310,66 @@ const ZstdApi& Zstd() {
   }();
   return api;
 }
+// LZ4_FRAME (codec 0; what Feather V2 files use by default): the reference registers no LZ4 function, so it rejects these
+// bodies; here the system's liblz4.so.1 frame API is bound at run time when it exists.
+struct Lz4Api {
+  size_t (*create)(void**, unsigned) = nullptr;
+  size_t (*free_ctx)(void*) = nullptr;
+  size_t (*decompress)(void*, void*, size_t*, const void*, size_t*, const void*) = nullptr;
+  unsigned (*is_error)(size_t) = nullptr;
+  const char* (*error_name)(size_t) = nullptr;
+  bool ok = false;
+};
+const Lz4Api& Lz4() {
+  static Lz4Api api = [] {
+    Lz4Api a;
+    void* h = dlopen("liblz4.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("liblz4.so", RTLD_NOW | RTLD_LOCAL);
+    if (h) {
+      a.create = reinterpret_cast<size_t (*)(void**, unsigned)>(dlsym(h, "LZ4F_createDecompressionContext"));
+      a.free_ctx = reinterpret_cast<size_t (*)(void*)>(dlsym(h, "LZ4F_freeDecompressionContext"));
+      a.decompress = reinterpret_cast<size_t (*)(void*, void*, size_t*, const void*, size_t*, const void*)>(dlsym(h, "LZ4F_decompress"));
+      a.is_error = reinterpret_cast<unsigned (*)(size_t)>(dlsym(h, "LZ4F_isError"));
+      a.error_name = reinterpret_cast<const char* (*)(size_t)>(dlsym(h, "LZ4F_getErrorName"));
+      a.ok = a.create && a.free_ctx && a.decompress && a.is_error && a.error_name;
+    }
+    return a;
+  }();
+  return api;
+}
+
+// one LZ4 frame -> exactly n bytes
+void Lz4DecompressFrame(const Lz4Api& z, uint8_t* dst, int64_t n, const uint8_t* src, int64_t src_len) {
+  void* dctx = nullptr;
+  size_t rc = z.create(&dctx, 100 /* LZ4F_VERSION */);
+  if (z.is_error(rc)) throw IOException(std::string("LZ4F_createDecompressionContext failed: ") + z.error_name(rc));
+  std::shared_ptr<void> guard(dctx, [&z](void* p) { z.free_ctx(p); });
+  size_t produced = 0, consumed = 0;
+  while (true) {
+    size_t dst_size = static_cast<size_t>(n) - produced, src_size = static_cast<size_t>(src_len) - consumed;
+    rc = z.decompress(dctx, dst + produced, &dst_size, src + consumed, &src_size, nullptr);
+    if (z.is_error(rc)) {
+      throw IOException("LZ4F_decompress([buffer with " + std::to_string(src_len) + " bytes] -> [buffer with " + std::to_string(n) +
+                        " bytes]) failed with error '" + z.error_name(rc) + "'");
+    }
+    produced += dst_size;
+    consumed += src_size;
+    if (rc == 0) break;                             // frame complete
+    if (dst_size == 0 && src_size == 0) break;      // no progress: truncated frame or output full
+  }
+  if (static_cast<int64_t>(produced) != n || rc != 0)
+    throw IOException("Expected decompressed size of " + std::to_string(n) + " bytes but got " + std::to_string(produced) + " bytes");
+}
 }  // namespace
 
 void IPCStreamReader::DecompressBody(RecordBatchMeta* meta) {
-  if (meta->compression == 0) {
-    throw NotImplementedException("LZ4_FRAME compressed IPC bodies are not supported (the reference registers a ZSTD decompressor only)");
-  }
-  if (meta->compression != 1) throw IOException("Unknown BodyCompression codec " + std::to_string(meta->compression));
+  if (meta->compression != 0 && meta->compression != 1) throw IOException("Unknown BodyCompression codec " + std::to_string(meta->compression));
+  const bool lz4 = meta->compression == 0;
   const ZstdApi& z = Zstd();
-  if (!z.ok) throw NotImplementedException("ZSTD compressed IPC body but libzstd.so.1 is not available on this host");
+  const Lz4Api& l4 = Lz4();
+  if (lz4 && !l4.ok)
+    throw NotImplementedException("LZ4_FRAME compressed IPC body but liblz4.so.1 is not available on this host (the reference registers a ZSTD decompressor only)");
+  if (!lz4 && !z.ok) throw NotImplementedException("ZSTD compressed IPC body but libzstd.so.1 is not available on this host");
   // pass 1: uncompressed sizes -> layout of the new body (every buffer 64-byte aligned); buffers of columns outside
   // the projection are neither read (DecodeBody) nor decompressed
   const std::vector<char> needed = NeededBuffers(*meta);
@@ -361,6 +412,8 @@ void IPCStreamReader::DecompressBody(RecordBatchMeta* meta) {
     uint8_t* dst = out + opos[i];
     if (declared == -1) {
       std::memcpy(dst, src + 8, static_cast<size_t>(n));
+    } else if (lz4) {
+      Lz4DecompressFrame(l4, dst, n, src + 8, b.length - 8);
     } else {
       const size_t code = z.decompress(dst, static_cast<size_t>(n), src + 8, static_cast<size_t>(b.length - 8));
       if (z.is_error(code)) {
