@@ -89,6 +89,14 @@ class IPCStreamReader {
   //! Sets the projection pushdown for this reader
   void SetColumnProjection(const std::vector<std::string>& column_names);
   bool HasProjection() const { return !projected_fields.empty(); }
+  //! Drops the reader's own reference to the body of the message it returned last (the DecodedBatch keeps its own);
+  //! a caller that recycles body buffers needs this when it stops pulling from a reader
+  void ReleaseCurrentBody() {
+    cur_owner.reset();
+    compressed_owner.reset();
+    cur_ptr = nullptr;
+    cur_size = 0;
+  }
   //! Byte ranges of a record-batch body that hold the buffers of the projected columns (merged when closer than
   //! `gap`); empty = everything (no projection, compressed body, or malformed metadata: the full validation decides).
   std::vector<char> NeededBuffers(const RecordBatchMeta& meta) const;

@@ -61,6 +61,7 @@ ArrowScan::ArrowScan(Context* ctx_p, std::vector<ArrowIPCBuffer> buffers_p, cons
 }
 
 ArrowScan::~ArrowScan() {
+  StopProducer();
   try {
     ctx->Bind();
   } catch (...) {
@@ -69,7 +70,7 @@ ArrowScan::~ArrowScan() {
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipStreamSynchronize(ctx->d2h_stream);
   for (auto& s : slots) {
-    if (s.h_in) (void)hipHostFree(s.h_in);
+    s.batch = DecodedBatch();  // returns the staging lease
     if (s.d_in) (void)hipFree(s.d_in);
     if (s.d_out) (void)hipFree(s.d_out);
     if (s.h_out) (void)hipHostFree(s.h_out);
@@ -81,6 +82,9 @@ ArrowScan::~ArrowScan() {
     if (s.d2h_done) (void)hipEventDestroy(s.d2h_done);
   }
   dicts.clear();
+  fetched.clear();
+  for (auto& st : staging)
+    if (st.p) (void)hipHostFree(st.p);
 }
 
 ArrowScan::DictState::~DictState() {
@@ -641,79 +645,183 @@ void ArrowScan::BuildVector(Slot& s, int32_t node, size_t window, uint8_t* base,
   }
 }
 
-bool ArrowScan::SubmitNextBatch() {
+// per-file column mapping by name (DuckDB's multi-file column mapping) + reader projection
+void ArrowScan::PrepareSource(size_t si) {
+  OpenSource(si);
+  Source& src = sources[si];
+  if (!src.out_to_file_column.empty()) return;
+  const ArrowSchemaModel& schema = src.reader->GetBaseSchema();
+  std::vector<std::string> names;
+  for (auto& f : schema.fields) names.push_back(f.name);
+  DeduplicateColumns(names);
+  std::vector<std::string> wanted;
+  src.out_to_file_column.assign(out_columns.size(), -1);
+  for (size_t c = 0; c < out_columns.size(); c++) {
+    if (out_columns[c].is_filename || out_columns[c].is_hive) continue;
+    auto it = std::find(names.begin(), names.end(), out_columns[c].name);
+    if (it == names.end()) {
+      if (!opts.union_by_name) {
+        throw InvalidInputException("Failed to read file \"" + src.path + "\": schema mismatch: column \"" + out_columns[c].name +
+                                    "\" is missing. If you are trying to read files with different schemas, try setting union_by_name=True");
+      }
+      continue;
+    }
+    const ArrowField& ff = schema.fields[static_cast<size_t>(it - names.begin())];
+    if (ff.Format() != out_columns[c].field.Format()) {
+      throw NotImplementedException("Column \"" + out_columns[c].name + "\" has type " + ff.DuckType() + " in file \"" + src.path +
+                                    "\" but " + out_columns[c].field.DuckType() +
+                                    " in the first file; cross-file casts are done by DuckDB's MultiFileReader above this path");
+    }
+    src.out_to_file_column[c] = static_cast<int32_t>(wanted.size());
+    wanted.push_back(*it);
+  }
+  if (!wanted.empty()) src.reader->SetColumnProjection(wanted);
+  else src.out_to_file_column.assign(out_columns.size(), -1);
+}
+
+// A pinned staging buffer for one record-batch body; the returned handle gives it back when the batch is released.
+std::shared_ptr<void> ArrowScan::LeaseStaging(size_t bytes, uint8_t** ptr) {
+  Staging* st = nullptr;
+  {
+    std::unique_lock<std::mutex> lk(q_mu);
+    q_cv.wait(lk, [&] {
+      if (producer_stop) return true;
+      for (auto& x : staging)
+        if (!x.leased) return true;
+      return false;
+    });
+    if (producer_stop) throw IOException("scan closed while reading");
+    // prefer a free buffer that is already large enough
+    for (auto& x : staging)
+      if (!x.leased && x.cap >= bytes + 64) { st = &x; break; }
+    if (!st)
+      for (auto& x : staging)
+        if (!x.leased) { st = &x; break; }
+    st->leased = true;
+  }
+  if (bytes + 64 > st->cap) {
+    ctx->Bind();
+    if (st->p) MI_HIP_CHECK(hipHostFree(st->p));
+    st->p = nullptr;
+    st->cap = RoundUp(std::max(bytes + 64, st->cap + st->cap / 2), 1 << 16);
+    MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&st->p), st->cap, hipHostMallocDefault));
+  }
+  *ptr = st->p;
+  return std::shared_ptr<void>(st->p, [this, st](void*) {
+    {
+      std::lock_guard<std::mutex> lk(q_mu);
+      st->leased = false;
+    }
+    q_cv.notify_all();
+  });
+}
+
+void ArrowScan::ProducerLoop() {
+  auto push = [&](Fetched&& f) {
+    std::unique_lock<std::mutex> lk(q_mu);
+    q_cv.wait(lk, [&] { return producer_stop || fetched.size() < static_cast<size_t>(kReadAhead); });
+    if (producer_stop) return false;
+    fetched.push_back(std::move(f));
+    lk.unlock();
+    q_cv.notify_all();
+    return true;
+  };
+  try {
+    ctx->Bind();
+    size_t si = 0;
+    int64_t ordinal = 0;
+    while (si < sources.size()) {
+      {
+        std::lock_guard<std::mutex> lk(q_mu);
+        if (producer_stop) return;
+      }
+      PrepareSource(si);
+      Source& src = sources[si];
+      src.reader->SetBodyAllocator([this](size_t bytes, MessageType type, uint8_t** ptr) -> std::shared_ptr<void> {
+        if (type == MessageType::DICTIONARY_BATCH) {  // lives as long as the dictionary version that points into it
+          ctx->Bind();
+          void* p = nullptr;
+          MI_HIP_CHECK(hipHostMalloc(&p, bytes + 64, hipHostMallocDefault));
+          *ptr = static_cast<uint8_t*>(p);
+          return std::shared_ptr<void>(p, [](void* q) { (void)hipHostFree(q); });
+        }
+        return LeaseStaging(bytes, ptr);
+      });
+      Fetched f;
+      const bool mine = opts.world <= 1 || (ordinal % opts.world) == opts.rank;
+      const bool got = src.reader->GetNextBatch(&f.batch, opts.accept_dictionaries != 0, /*skip_body*/ !mine);
+      src.reader->ReleaseCurrentBody();  // the lease belongs to the batch alone
+      if (!got) {
+        si++;
+        continue;
+      }
+      f.source = static_cast<int32_t>(si);
+      if (!f.batch.is_dictionary) {
+        f.ordinal = ordinal++;
+        if (!mine) continue;
+      }
+      if (!push(std::move(f))) return;
+    }
+    Fetched end;
+    end.end = true;
+    push(std::move(end));
+  } catch (...) {
+    Fetched err;
+    err.error = std::current_exception();
+    push(std::move(err));
+  }
+}
+
+void ArrowScan::StartProducer() {
+  if (producer_started) return;
+  producer_started = true;
+  producer = std::thread([this] { ProducerLoop(); });
+}
+
+void ArrowScan::StopProducer() {
+  if (!producer_started) return;
+  {
+    std::lock_guard<std::mutex> lk(q_mu);
+    producer_stop = true;
+  }
+  q_cv.notify_all();
+  if (producer.joinable()) producer.join();
+}
+
+bool ArrowScan::SubmitNextBatch(bool may_block) {
+  StartProducer();
   while (!exhausted) {
-    if (cur_source >= sources.size()) {
+    Slot* slot = FreeSlot();
+    if (!slot) return false;
+    Fetched f;
+    {
+      std::unique_lock<std::mutex> lk(q_mu);
+      if (fetched.empty()) {
+        if (!may_block) return false;
+        q_cv.wait(lk, [&] { return !fetched.empty(); });
+      }
+      f = std::move(fetched.front());
+      fetched.pop_front();
+    }
+    q_cv.notify_all();
+    if (f.error) {
+      exhausted = true;
+      std::rethrow_exception(f.error);
+    }
+    if (f.end) {
       exhausted = true;
       return false;
     }
-    Slot* slot = FreeSlot();
-    if (!slot) return false;
-    OpenSource(cur_source);
+    cur_source = static_cast<size_t>(f.source);
     Source& src = sources[cur_source];
-    if (src.out_to_file_column.empty()) {
-      // per-file column mapping by name (DuckDB's multi-file column mapping) + reader projection
-      const ArrowSchemaModel& schema = src.reader->GetBaseSchema();
-      std::vector<std::string> names;
-      for (auto& f : schema.fields) names.push_back(f.name);
-      DeduplicateColumns(names);
-      std::vector<std::string> wanted;
-      src.out_to_file_column.assign(out_columns.size(), -1);
-      for (size_t c = 0; c < out_columns.size(); c++) {
-        if (out_columns[c].is_filename || out_columns[c].is_hive) continue;
-        auto it = std::find(names.begin(), names.end(), out_columns[c].name);
-        if (it == names.end()) {
-          if (!opts.union_by_name) {
-            throw InvalidInputException("Failed to read file \"" + src.path + "\": schema mismatch: column \"" + out_columns[c].name +
-                                        "\" is missing. If you are trying to read files with different schemas, try setting union_by_name=True");
-          }
-          continue;
-        }
-        const ArrowField& ff = schema.fields[static_cast<size_t>(it - names.begin())];
-        if (ff.Format() != out_columns[c].field.Format()) {
-          throw NotImplementedException("Column \"" + out_columns[c].name + "\" has type " + ff.DuckType() + " in file \"" + src.path +
-                                        "\" but " + out_columns[c].field.DuckType() +
-                                        " in the first file; cross-file casts are done by DuckDB's MultiFileReader above this path");
-        }
-        src.out_to_file_column[c] = static_cast<int32_t>(wanted.size());
-        wanted.push_back(*it);
-      }
-      if (!wanted.empty()) src.reader->SetColumnProjection(wanted);
-      else src.out_to_file_column.assign(out_columns.size(), -1);
+    if (f.batch.is_dictionary) {
+      DecodeDictionary(src, f.batch);
+      continue;
     }
-    // read the next message of this source; bodies land directly in the slot's pinned buffer
     Slot& s = *slot;
-    src.reader->SetBodyAllocator([this, &s](size_t bytes, MessageType type, uint8_t** ptr) -> std::shared_ptr<void> {
-      ctx->Bind();
-      if (type == MessageType::DICTIONARY_BATCH) {
-        void* p = nullptr;
-        MI_HIP_CHECK(hipHostMalloc(&p, bytes + 64, hipHostMallocDefault));
-        *ptr = static_cast<uint8_t*>(p);
-        return std::shared_ptr<void>(p, [](void* q) { (void)hipHostFree(q); });
-      }
-      if (bytes + 64 > s.h_in_cap) {
-        if (s.h_in) MI_HIP_CHECK(hipHostFree(s.h_in));
-        s.h_in = nullptr;
-        s.h_in_cap = RoundUp(std::max(bytes + 64, s.h_in_cap + s.h_in_cap / 2), 1 << 16);
-        MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.h_in), s.h_in_cap, hipHostMallocDefault));
-      }
-      *ptr = s.h_in;
-      return std::shared_ptr<void>();
-    });
-    const bool mine = opts.world <= 1 || (next_batch_ordinal % opts.world) == opts.rank;
-    bool got = src.reader->GetNextBatch(&s.batch, opts.accept_dictionaries != 0, /*skip_body*/ !mine);
-    if (!got) {
-      cur_source++;
-      continue;
-    }
-    if (s.batch.is_dictionary) {
-      DecodeDictionary(src, s.batch);
-      continue;
-    }
-    const int64_t ordinal = next_batch_ordinal++;
-    if (!mine) continue;
-    s.source = static_cast<int32_t>(cur_source);
-    s.batch_index = ordinal;
+    s.batch = std::move(f.batch);
+    s.source = f.source;
+    s.batch_index = f.ordinal;
     s.busy = true;
     EnqueueBatch(s);
     inflight.push_back(static_cast<int>(&s - slots));
@@ -736,7 +844,7 @@ void ArrowScan::Next(mi_data_chunk* out) {
       cur_row = 0;
     }
     // keep the pipeline full
-    while (inflight.size() < static_cast<size_t>(kSlots) && SubmitNextBatch()) {
+    while (inflight.size() < static_cast<size_t>(kSlots) && SubmitNextBatch(/*may_block*/ inflight.empty())) {
     }
     if (cur_slot < 0) {
       if (inflight.empty()) {

@@ -15,7 +15,11 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <condition_variable>
+#include <deque>
 #include <map>
+#include <mutex>
+#include <thread>
 #include <memory>
 #include <string>
 #include <vector>
@@ -74,7 +78,6 @@ class ArrowScan {
   };
   struct Slot {
     // one record batch in flight
-    uint8_t* h_in = nullptr;   size_t h_in_cap = 0;    // pinned body
     uint8_t* d_in = nullptr;   size_t d_in_cap = 0;    // body in HBM
     uint8_t* d_out = nullptr;  size_t d_out_cap = 0;   // decoded vectors in HBM
     uint8_t* h_out = nullptr;  size_t h_out_cap = 0;   // decoded vectors, pinned
@@ -109,7 +112,37 @@ class ArrowScan {
 
   void OpenSource(size_t i);
   void BuildOutputSchema();
-  bool SubmitNextBatch();   // reads + enqueues one more record batch; false when all sources are exhausted
+  //! takes the next fetched record batch and enqueues its GPU work; false when nothing could be submitted (no free
+  //! slot, nothing fetched yet while `may_block` is false, or every source is exhausted)
+  bool SubmitNextBatch(bool may_block);
+  // ---- read-ahead: a producer thread walks the sources (open, column mapping, projection, sharding, pread into pinned
+  // staging buffers) a few record batches ahead of the consumer, so file I/O overlaps whatever the consumer does between
+  // two Next() calls; the reference reads synchronously inside the scan call (ipc_file_stream_reader.cpp:71-94)
+  struct Fetched {
+    DecodedBatch batch;
+    int32_t source = 0;
+    int64_t ordinal = 0;
+    bool end = false;                 // every source is exhausted
+    std::exception_ptr error;         // raised where the consumer reaches it, after the batches read before it
+  };
+  struct Staging {                    // pinned body buffers, leased to one record batch at a time
+    uint8_t* p = nullptr;
+    size_t cap = 0;
+    bool leased = false;
+  };
+  void StartProducer();
+  void StopProducer();
+  void ProducerLoop();
+  void PrepareSource(size_t si);      // per-file column mapping + reader projection (was inline in SubmitNextBatch)
+  std::shared_ptr<void> LeaseStaging(size_t bytes, uint8_t** ptr);
+  static constexpr int kReadAhead = 3;              // fetched batches waiting for a slot
+  static constexpr int kStaging = 3 + kReadAhead + 1;  // in flight on the GPU + waiting + the one being read
+  std::thread producer;
+  std::mutex q_mu;
+  std::condition_variable q_cv;
+  std::deque<Fetched> fetched;
+  Staging staging[kStaging];
+  bool producer_started = false, producer_stop = false;
   void EnqueueBatch(Slot& s);
  public:
   //! sum(a * b) over rows passing the range filters, all on the GPU; drains the scan (mi_scan_sum_product)

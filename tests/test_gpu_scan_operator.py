@@ -446,3 +446,36 @@ def test_two_worker_threads_with_their_own_contexts(golden_dir, tmp_path):
     [t.join() for t in threads]
     assert not errors, errors
     assert len(set(results.values())) == 1 and next(iter(results.values()))[0] == info["n_rows"]
+
+
+def test_many_files_and_early_close_with_read_ahead(con, tmp_path):
+    """The read-ahead thread leases a fixed set of pinned staging buffers: more files than buffers (every finished reader
+    must give its last body back), consumers that stop early (close with batches still queued), and an error in a later
+    file surfacing only after the rows before it."""
+    t = pa.table({"a": list(range(5000)), "s": ["value %d" % i for i in range(5000)]})
+    paths = []
+    for i in range(12):
+        p = str(tmp_path / ("f%02d.arrows" % i))
+        with ipc.new_stream(p, t.schema) as w:
+            w.write_table(t, max_chunksize=1000)
+        paths.append(p)
+    assert con.read_arrow(paths).count() == 12 * 5000
+    a, s = con.read_arrow(paths).fetch_columns()
+    assert a == list(range(5000)) * 12 and s[-1] == "value 4999"
+    # early close: pull two chunks, drop the relation (the producer is blocked on a full queue or a lease)
+    rel = con.read_arrow(paths)
+    it = rel.chunks()
+    next(it)
+    next(it)
+    rel.close()
+    # a broken file in the middle: rows of the files before it arrive, then the error
+    bad = str(tmp_path / "f05.arrows")
+    with open(bad, "r+b") as f:
+        f.seek(0)
+        f.write(b"\x01\x02\x03\x04")
+    rel = con.read_arrow(paths)
+    seen = 0
+    with pytest.raises(da.MiError):
+        for ch in rel.chunks():
+            seen += ch.size
+    assert seen >= 4 * 5000 and seen <= 5 * 5000
