@@ -763,6 +763,10 @@ class Connection:
 
         w = open_writer()
         try:
+            if isinstance(table, Relation) and not rotate:   # native pump: scan -> sink without a Python loop
+                table._init()
+                _ffi.check(L.mi_writer_sink_scan(w, table._h, None))
+                source = ()
             for ch in source:
                 _ffi.check(L.mi_writer_sink(w, C.byref(ch)))
                 if rotate and L.mi_writer_rotate_next_file(w, -1 if file_size_bytes is None else file_size_bytes):

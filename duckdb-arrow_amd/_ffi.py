@@ -164,6 +164,7 @@ SIGNATURES = {
     "mi_encode_schema": (C.c_int, [C.POINTER(Field), C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "mi_writer_open": (C.c_int, [P, C.c_char_p, C.POINTER(Field), C.c_int32, C.POINTER(WriteOptions), PP]),
     "mi_writer_sink": (C.c_int, [P, C.POINTER(DataChunk)]),
+    "mi_writer_sink_scan": (C.c_int, [P, P, C.POINTER(C.c_int64)]),
     "mi_writer_finalize": (C.c_int, [P]),
     "mi_writer_close": (None, [P]),
     "mi_writer_row_groups": (C.c_int64, [P]),

@@ -762,51 +762,84 @@ __global__ __launch_bounds__(kBlockThreads) void transcode_misc(const mi_col_tas
 }
 
 // ---------------------------------------------------------------------------------------------------- K6
-// Range filter lo <= v < hi AND valid -> ascending window-relative indices.  One workgroup per 2048-row window:
-// lane i owns rows [8i, 8i+8) (32 or 64 contiguous bytes), a wave-level + 4-wave LDS scan of the per-lane counts
-// gives each lane its output position, so the selection vector comes out sorted without a second pass.
+// Range filter lo <= v < hi AND valid -> ascending window-relative indices, one selection vector per 2048-row window.
+// A workgroup takes kFilterWindows consecutive windows: lane i owns rows [8i, 8i+8) of each (16 to 64 contiguous bytes,
+// loaded as one vector), all windows' loads are issued before anything depends on them (a single 8 KB window per
+// workgroup left the kernel bound by the latency of that one round trip: 2.1 TB/s), then per window a DPP wave scan +
+// one LDS exchange of the 4 wave totals gives every lane its output position: the selection vector comes out sorted
+// without a second pass.
+constexpr int kFilterWindows = 4;
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v);
+
 template <typename T>
-__global__ __launch_bounds__(kBlockThreads) void filter_range(const T* __restrict__ values,
-                                                              const uint64_t* __restrict__ validity, int64_t nrows,
-                                                              int64_t lo, int64_t hi, mi_sel_t* __restrict__ sel_out,
-                                                              uint32_t* __restrict__ count_out) {
-  __shared__ uint32_t wave_total[kBlockThreads / 64];
-  const int64_t row0 = static_cast<int64_t>(blockIdx.x) * kTileRows;
-  const int64_t left = nrows - row0;
-  const int n = left < kTileRows ? static_cast<int>(left) : kTileRows;
+__global__ __launch_bounds__(kBlockThreads) void filter_range(const T* __restrict__ values_p,
+                                                              const uint64_t* __restrict__ validity_p, int64_t nrows,
+                                                              int64_t lo, int64_t hi, mi_sel_t* __restrict__ sel_out_p,
+                                                              uint32_t* __restrict__ count_out_p) {
+  typedef T vec8 __attribute__((ext_vector_type(8)));
+  typedef vec8 vec8_a4 __attribute__((aligned(4)));
+  __shared__ uint32_t wave_total[kFilterWindows][kBlockThreads / 64];
+  gptr<const T> values = GC<T>(values_p);
+  gptr<const uint64_t> validity = GC<uint64_t>(validity_p);
+  gptr<mi_sel_t> sel_out = GM<mi_sel_t>(sel_out_p);
+  gptr<uint32_t> count_out = GM<uint32_t>(count_out_p);
+  const int64_t first_window = static_cast<int64_t>(blockIdx.x) * kFilterWindows;
   const int r = 8 * threadIdx.x;
-  uint32_t mask = 0;
-  if (r < n) {
-    const uint32_t vbits = validity ? static_cast<uint32_t>((validity[(row0 + r) >> 6] >> ((row0 + r) & 63)) & 0xFF) : 0xFFu;
-    const T* __restrict__ p = values + row0 + r;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t mask[kFilterWindows];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      if (r + k < n) {
-        const int64_t v = static_cast<int64_t>(p[k]);
-        if (v >= lo && v < hi && ((vbits >> k) & 1)) mask |= 1u << k;
+  for (int w = 0; w < kFilterWindows; w++) {
+    const int64_t row0 = (first_window + w) * kTileRows;
+    const int64_t left = nrows - row0;
+    const int n = left < kTileRows ? static_cast<int>(left < 0 ? 0 : left) : kTileRows;
+    uint32_t m = 0;
+    if (r + 8 <= n) {
+      const uint32_t vbits = validity ? static_cast<uint32_t>((validity[(row0 + r) >> 6] >> ((row0 + r) & 63)) & 0xFF) : 0xFFu;
+      const vec8 v = __builtin_nontemporal_load((gptr<const vec8_a4>)(values + row0 + r));
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int64_t x = static_cast<int64_t>(v[k]);
+        if (x >= lo && x < hi) m |= 1u << k;
       }
+      m &= vbits;
+    } else if (r < n) {  // the table's last, partial vector
+      const uint32_t vbits = validity ? static_cast<uint32_t>((validity[(row0 + r) >> 6] >> ((row0 + r) & 63)) & 0xFF) : 0xFFu;
+      for (int k = 0; r + k < n; k++) {
+        const int64_t x = static_cast<int64_t>(values[row0 + r + k]);
+        if (x >= lo && x < hi) m |= 1u << k;
+      }
+      m &= vbits;
     }
+    mask[w] = m;
   }
-  const uint32_t cnt = __builtin_popcount(mask);
-  uint32_t incl = cnt;  // inclusive scan inside the wave
-  const int lane = threadIdx.x & 63;
+  uint32_t incl[kFilterWindows];
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t up = __shfl_up(incl, d, 64);
-    if (lane >= d) incl += up;
+  for (int w = 0; w < kFilterWindows; w++) {
+    incl[w] = wave_inclusive_scan_u32(__builtin_popcount(mask[w]));
+    if (lane == 63) wave_total[w][wave] = incl[w];
   }
-  const int wave = threadIdx.x >> 6;
-  if (lane == 63) wave_total[wave] = incl;
   __syncthreads();
-  uint32_t base = 0;
-  for (int w = 0; w < wave; w++) base += wave_total[w];
-  uint32_t pos = base + incl - cnt;
-  mi_sel_t* __restrict__ out = sel_out + row0;
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
-    if ((mask >> k) & 1) out[pos++] = static_cast<mi_sel_t>(r + k);
+  for (int w = 0; w < kFilterWindows; w++) {
+    const int64_t window = first_window + w;
+    if (window * kTileRows >= nrows) break;  // uniform
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < kBlockThreads / 64; i++) {
+      const uint32_t x = wave_total[w][i];
+      if (i < wave) base += x;
+      total += x;
+    }
+    uint32_t pos = base + incl[w] - __builtin_popcount(mask[w]);
+    gptr<mi_sel_t> out = sel_out + window * kTileRows;
+    uint32_t m = mask[w];
+    while (m) {  // ascending set bits
+      const int k = __builtin_ctz(m);
+      m &= m - 1;
+      out[pos++] = static_cast<mi_sel_t>(r + k);
+    }
+    if (threadIdx.x == 0) count_out[window] = total;
   }
-  if (threadIdx.x == kBlockThreads - 1) count_out[blockIdx.x] = base + incl;
 }
 
 // ==================================================================================================== K7 (encode)
@@ -1459,7 +1492,8 @@ hipError_t LaunchAggSumProduct(const AggSumProductArgs& args, unsigned long long
 hipError_t LaunchFilterRange(const void* values, int32_t width, const void* validity, int64_t nrows, int64_t lo,
                              int64_t hi, mi_sel_t* sel_out, uint32_t* count_out, hipStream_t stream) {
   if (nrows <= 0) return hipSuccess;
-  const uint32_t grid = static_cast<uint32_t>((nrows + kTileRows - 1) / kTileRows);
+  const int64_t windows = (nrows + kTileRows - 1) / kTileRows;
+  const uint32_t grid = static_cast<uint32_t>((windows + kFilterWindows - 1) / kFilterWindows);
   const uint64_t* v = static_cast<const uint64_t*>(validity);
   switch (width) {
     case 4:

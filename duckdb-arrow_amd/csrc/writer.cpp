@@ -613,6 +613,21 @@ int mi_writer_sink(mi_writer* w, const mi_data_chunk* chunk) {
   });
 }
 
+int mi_writer_sink_scan(mi_writer* w, mi_scan* scan, int64_t* rows) {
+  int64_t n = 0;
+  mi_data_chunk ch;
+  while (true) {
+    int rc = mi_scan_next(scan, &ch);
+    if (rc != MI_OK) return rc;
+    if (ch.size == 0) break;
+    rc = mi_writer_sink(w, &ch);
+    if (rc != MI_OK) return rc;
+    n += ch.size;
+  }
+  if (rows) *rows = n;
+  return MI_OK;
+}
+
 int mi_writer_finalize(mi_writer* w) {
   return WrapC([&] {
     if (!w || !w->writer) throw InvalidInputException("mi_writer_finalize: bad argument");

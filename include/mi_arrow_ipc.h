@@ -430,6 +430,9 @@ int mi_writer_open(mi_ctx* ctx, const char* path, const mi_field* fields, int32_
 int mi_writer_sink(mi_writer* w, const mi_data_chunk* chunk);
 /* ArrowWriteCombine + ArrowWriteFinalize (write_arrow_stream.cpp:161-174): flush the tail, write EOS
  * {FF FF FF FF 00 00 00 00} (arrow_stream_writer.cpp:78-82), close. */
+/* COPY (FROM read_arrow(...)) TO 'file' (FORMAT ARROWS): pulls every remaining chunk of `scan` (host consumer mode)
+ * straight into the sink, natively -- the pump DuckDB's executor is between a scan and a copy sink.  *rows = copied. */
+int mi_writer_sink_scan(mi_writer* w, mi_scan* scan, int64_t* rows);
 int mi_writer_finalize(mi_writer* w);
 void mi_writer_close(mi_writer* w);
 int64_t mi_writer_row_groups(const mi_writer* w);  /* ArrowStreamWriter::NumberOfRowGroups */

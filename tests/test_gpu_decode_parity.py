@@ -327,3 +327,29 @@ def test_zero_copy_plan_leaves_direct_columns_in_the_body(ctx):
                 assert np.array_equal(d_in[a: a + wc["data"].size], wc["data"]), gc["name"]
             else:
                 assert_nodes_equal(gc, wc, gc["name"])
+
+
+@pytest.mark.parametrize("width,dtype", [(2, np.int16), (4, np.int32), (8, np.int64)])
+@pytest.mark.parametrize("n", [1, 7, 8, 2047, 2048, 2049, 4 * 2048 - 3, 4 * 2048, 4 * 2048 + 9, 11 * 2048 + 1234])
+def test_filter_range_sizes_widths_and_nulls(ctx, torch, width, dtype, n):
+    """K6 at sizes around the 2048-row window and the 4-window workgroup boundaries, every value width, with NULLs: per
+    window the count and the ascending window-relative indices equal a numpy filter (NULL rows never pass)."""
+    rng = np.random.default_rng(n * 10 + width)
+    vals = rng.integers(-1000, 1000, n).astype(dtype)
+    ok = rng.random(n) < 0.8
+    words = np.packbits(np.concatenate([ok, np.zeros((-n) % 64, bool)]), bitorder="little").view(np.uint64).copy()
+    d_vals = torch.from_numpy(vals.view(np.uint8).copy()).cuda()
+    d_valid = torch.from_numpy(words.view(np.uint8).copy()).cuda()
+    nw = (n + 2047) // 2048
+    sel = torch.full((nw * 2048 + 16,), -1, dtype=torch.int32, device="cuda")
+    cnt = torch.full((nw + 8,), -1, dtype=torch.int32, device="cuda")
+    da.filter_range(ctx, d_vals.data_ptr(), width, d_valid.data_ptr(), n, -100, 250, sel.data_ptr(), cnt.data_ptr(),
+                    torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    sel, cnt = sel.cpu().numpy(), cnt.cpu().numpy()
+    for w in range(nw):
+        lo, hi = w * 2048, min(n, (w + 1) * 2048)
+        want = np.nonzero((vals[lo:hi] >= -100) & (vals[lo:hi] < 250) & ok[lo:hi])[0]
+        assert cnt[w] == len(want)
+        assert np.array_equal(sel[w * 2048: w * 2048 + len(want)], want)
+    assert (cnt[nw:] == -1).all()      # nothing written past the last window

@@ -55,6 +55,17 @@ def main():
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
         out["q6_fused_on_gpu"] = {"seconds": best, "rows_per_s": scanned / best, "revenue_scale4": total, "selected": selected}
+        # BASELINE configs[3] end to end: COPY (FROM read_arrow(file)) TO 'out.arrows' (row_group_size 122880): scan
+        # (pread, H2D, decode, D2H) -> sink (host staging, H2D, K7 encode, D2H) -> write(); host staging is one thread
+        opath = os.path.join(args.dir, "mi_copy_out_sf%g.arrows" % args.sf)
+        try:
+            t0 = time.perf_counter()
+            con.copy_to(con.read_arrow(path), opath, row_group_size=122880)
+            dt = time.perf_counter() - t0
+            out["copy_scan_to_file"] = {"seconds": dt, "rows_per_s": info["n_rows"] / dt, "out_bytes": os.path.getsize(opath)}
+        finally:
+            if os.path.exists(opath):
+                os.unlink(opath)
         # BASELINE configs[2] shape on one GPU: the table as a list of files, l_shipdate filter pushed into the scan,
         # row groups sharded rank / world (each rank of an N-GPU job runs exactly this with its own rank)
         if args.files > 1:
