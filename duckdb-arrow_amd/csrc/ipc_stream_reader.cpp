@@ -691,6 +691,9 @@ double IPCFileStreamReader::GetProgress() {
   return (static_cast<double>(offset) / static_cast<double>(file_size)) * 100;
 }
 
+void ParallelFor(int n, const std::function<void(int)>& fn) { IoPool::Get().Run(n, fn); }
+int IoThreads() { return IoPool::Get().Threads(); }
+
 const uint8_t* IPCFileStreamReader::ReadData(uint8_t* ptr, idx_t size) {
   // BufferedFileReader::ReadData throws SerializationException when the file ends early
   constexpr idx_t kSlice = 256u << 10;  // smallest piece worth a thread hand-off

@@ -19,6 +19,12 @@
 
 namespace miarrow {
 
+//! Runs fn(i), i in [0, n), on the process-wide I/O pool (MI_IO_THREADS, default 8) + the calling thread; rethrows the
+//! first failure.  One job at a time: callers on different threads queue up.
+void ParallelFor(int n, const std::function<void(int)>& fn);
+int IoThreads();
+
+
 
 
 struct ArrowIpcMessagePrefix {  // base_stream_reader.hpp:39-42

@@ -1,11 +1,14 @@
 // writer.cpp -- see writer.hpp.
 #include "writer.hpp"
+#include "ipc_stream_reader.hpp"
 
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cctype>
 #include <cerrno>
 #include <cstdlib>
@@ -17,6 +20,21 @@ namespace miarrow {
 int WrapC(const std::function<void()>& f);  // c_api.cpp
 
 namespace {
+// MI_WRITER_TIMING=1: cumulative seconds per stage of the COPY sink, printed when a writer is finalized
+struct SinkTimers {
+  double append = 0, serialize = 0, write = 0;
+  bool on = std::getenv("MI_WRITER_TIMING") != nullptr;
+};
+SinkTimers& Timers() {
+  static SinkTimers t;
+  return t;
+}
+struct ScopedTimer {
+  double* acc;
+  std::chrono::steady_clock::time_point t0;
+  explicit ScopedTimer(double* a) : acc(Timers().on ? a : nullptr) { if (acc) t0 = std::chrono::steady_clock::now(); }
+  ~ScopedTimer() { if (acc) *acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
 constexpr size_t kBufferAlign = 64;  // Arrow's recommended buffer alignment; any multiple of 8 is valid IPC
 size_t RoundUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -134,6 +152,7 @@ void ChunkCollection::Reserve(Column& c, int64_t rows, int64_t extra_heap) {
 }
 
 void ChunkCollection::Append(const mi_data_chunk& chunk) {
+  ScopedTimer timer(&Timers().append);
   if (chunk.n_columns != static_cast<int32_t>(roots.size()))
     throw InvalidInputException("DataChunk has " + std::to_string(chunk.n_columns) + " columns, the writer expects " + std::to_string(roots.size()));
   const int64_t n = chunk.size;
@@ -153,11 +172,45 @@ void ChunkCollection::AppendNode(int32_t ni, const mi_vector& v, int64_t start, 
     if ((c.IsList() || c.IsGroup()) && (v.n_children < (c.arrow_type == MI_AT_STRUCT ? static_cast<int32_t>(c.children.size()) : 1) || !v.children))
       throw InvalidInputException("nested vector without child vectors");
   }
-  int64_t extra_heap = 0;
+  // strings: one pass over the rows decides how the long-string payloads of this slice are staged
+  int64_t extra_heap = 0, payload = 0;
+  bool grow_run = false;
+  uint64_t slice_hi = 0;
   if (columns[static_cast<size_t>(ni)].enc_kind == MI_K_ENC_STR32) {
+    Column& sc = columns[static_cast<size_t>(ni)];
     const mi_string_t* s = static_cast<const mi_string_t*>(v.data) + start;
-    for (int64_t i = 0; i < n; i++)
-      if (BitAt(v.validity, vbit + i) && s[i].value.inlined.length > 12) extra_heap += s[i].value.inlined.length;
+    bool contiguous = sc.run_open;
+    uint64_t expect = sc.run_end;           // where the next long string may start at the earliest
+    int64_t since = sc.rows_since_long;
+    int64_t long_bytes = 0;
+    uint64_t first_long = 0;
+    for (int64_t i = 0; i < n; i++) {
+      if (!BitAt(v.validity, vbit + i)) { since++; continue; }
+      const uint32_t len = s[i].value.inlined.length;
+      payload += len;
+      if (len <= 12) { since++; continue; }
+      const uint64_t p = s[i].value.pointer.ptr;
+      long_bytes += len;
+      if (first_long == 0) first_long = p;
+      if (contiguous && expect != 0 && (p < expect || p - expect > static_cast<uint64_t>(12 * since))) contiguous = false;
+      expect = p + len;
+      since = 0;
+    }
+    if (long_bytes > 0) {
+      if (contiguous) {  // [run_end (or the first long string), expect) continues the run
+        grow_run = true;
+        slice_hi = expect;
+        const uint64_t from = sc.run_end ? sc.run_end : first_long;
+        extra_heap = static_cast<int64_t>(slice_hi - from);
+        if (sc.run_end == 0) {
+          sc.ptr_base = first_long - static_cast<uint64_t>(sc.heap_used);  // heap_used is 0 here: a run starts a row group
+          sc.run_end = first_long;
+        }
+      } else {
+        extra_heap = long_bytes;
+      }
+    }
+    sc.rows_since_long = since;
   }
   Reserve(columns[static_cast<size_t>(ni)], columns[static_cast<size_t>(ni)].count + n, extra_heap);
   Column& c = columns[static_cast<size_t>(ni)];  // (children are appended after this block: `columns` never grows here)
@@ -205,18 +258,23 @@ void ChunkCollection::AppendNode(int32_t ni, const mi_vector& v, int64_t start, 
               static_cast<const uint8_t*>(v.data) + static_cast<size_t>(start) * static_cast<size_t>(c.width),
               static_cast<size_t>(n) * static_cast<size_t>(c.width));
   if (c.enc_kind == MI_K_ENC_STR32) {
-    mi_string_t* dst = reinterpret_cast<mi_string_t*>(c.data) + c.count;
-    for (int64_t i = 0; i < n; i++) {
-      if (!BitAt(v.validity, vbit + i)) {
-        std::memset(&dst[i], 0, sizeof(mi_string_t));
-        continue;
-      }
-      const uint32_t len = dst[i].value.inlined.length;
-      c.payload_bytes += len;
-      if (len > 12) {
-        // long string: move the payload into the staging heap, the pointer becomes the heap offset (ptr_base = 0)
+    c.payload_bytes += payload;
+    if (grow_run) {
+      // the string_t rows stay as they are; the new source bytes extend the staged run
+      std::memcpy(c.heap + (c.run_end - c.ptr_base), reinterpret_cast<const void*>(static_cast<uintptr_t>(c.run_end)),
+                  static_cast<size_t>(slice_hi - c.run_end));
+      c.run_end = slice_hi;
+      c.heap_used = static_cast<int64_t>(c.run_end - c.ptr_base);
+    } else if (extra_heap > 0) {
+      // not laid out back to back: gather string by string; the pointer becomes ptr_base + heap offset
+      c.run_open = false;
+      mi_string_t* dst = reinterpret_cast<mi_string_t*>(c.data) + c.count;
+      for (int64_t i = 0; i < n; i++) {
+        if (!BitAt(v.validity, vbit + i)) continue;
+        const uint32_t len = dst[i].value.inlined.length;
+        if (len <= 12) continue;
         std::memcpy(c.heap + c.heap_used, reinterpret_cast<const void*>(static_cast<uintptr_t>(dst[i].value.pointer.ptr)), len);
-        dst[i].value.pointer.ptr = static_cast<uint64_t>(c.heap_used);
+        dst[i].value.pointer.ptr = c.ptr_base + static_cast<uint64_t>(c.heap_used);
         c.heap_used += len;
       }
     }
@@ -230,6 +288,10 @@ void ChunkCollection::Reset() {
   for (auto& c : columns) {
     c.count = 0;
     c.heap_used = 0;
+    c.ptr_base = 0;
+    c.run_end = 0;
+    c.run_open = true;
+    c.rows_since_long = 0;
     c.payload_bytes = 0;
     c.has_nulls = false;
     if (c.validity) std::memset(c.validity, 0xFF, c.validity_cap);
@@ -242,7 +304,9 @@ void ChunkCollection::Reset() {
 ColumnDataCollectionSerializer::ColumnDataCollectionSerializer(Context* ctx_p) : ctx(ctx_p) {}
 
 ColumnDataCollectionSerializer::~ColumnDataCollectionSerializer() {
-  if (h_body) (void)hipHostFree(h_body);
+  h_bodies[cur_body] = h_body;
+  for (auto* b : h_bodies)
+    if (b) (void)hipHostFree(b);
   if (d_body) (void)hipFree(d_body);
   if (d_in) (void)hipFree(d_in);
 }
@@ -255,6 +319,7 @@ void ColumnDataCollectionSerializer::SerializeSchema() {
 }
 
 idx_t ColumnDataCollectionSerializer::Serialize(ChunkCollection& buffer) {
+  ScopedTimer timer(&Timers().serialize);
   header.clear();
   body_size = 0;
   const int64_t n_top = buffer.Count();
@@ -356,7 +421,7 @@ idx_t ColumnDataCollectionSerializer::Serialize(ChunkCollection& buffer) {
     if (c.enc_kind == MI_K_ENC_STR32) {
       t.buf2 = d_in + in_off[ci].heap;
       t.buf2_len = c.payload_bytes;
-      t.ptr_base = 0;
+      t.ptr_base = c.ptr_base;
       t.out_aux = d_body + spans[sp + 2].offset;
     }
     tasks.push_back(t);
@@ -382,6 +447,12 @@ ArrowStreamWriter::ArrowStreamWriter(Context* ctx_p, const std::string& file_pat
 }
 
 ArrowStreamWriter::~ArrowStreamWriter() {
+  {
+    std::lock_guard<std::mutex> lk(io_mu);
+    io_stop = true;
+  }
+  io_cv.notify_all();
+  if (io_thread.joinable()) io_thread.join();  // queued batches are still written
   if (fd >= 0) ::close(fd);
 }
 
@@ -399,6 +470,7 @@ void ArrowStreamWriter::InitOutputFile(const std::string& file_path) {
 }
 
 void ArrowStreamWriter::WriteData(const uint8_t* p, size_t n) {
+  ScopedTimer timer(&Timers().write);
   size_t done = 0;
   while (done < n) {
     ssize_t w = ::write(fd, p + done, n - done);
@@ -408,33 +480,90 @@ void ArrowStreamWriter::WriteData(const uint8_t* p, size_t n) {
     }
     done += static_cast<size_t>(w);
   }
-  total_written += n;
 }
 
 void ArrowStreamWriter::WriteSchema() {
   serializer.SerializeSchema();
   WriteData(serializer.GetHeader().data(), serializer.GetHeader().size());
+  total_written += serializer.GetHeader().size();
+}
+
+void ArrowStreamWriter::IoLoop() {
+  while (true) {
+    WriteJob job;
+    {
+      std::unique_lock<std::mutex> lk(io_mu);
+      io_cv.wait(lk, [&] { return io_stop || !io_jobs.empty(); });
+      if (io_jobs.empty()) return;  // stop requested and nothing left
+      job = std::move(io_jobs.front());
+      io_jobs.pop_front();
+    }
+    try {
+      if (!io_error) {
+        WriteData(job.header.data(), job.header.size());
+        WriteData(job.body, job.body_size);
+      }
+    } catch (...) {
+      std::lock_guard<std::mutex> lk(io_mu);
+      if (!io_error) io_error = std::current_exception();
+    }
+    {
+      std::lock_guard<std::mutex> lk(io_mu);
+      if (job.buffer >= 0) buffer_busy[job.buffer] = false;
+    }
+    io_cv.notify_all();
+  }
+}
+
+void ArrowStreamWriter::WaitBufferFree(int buffer) {
+  std::unique_lock<std::mutex> lk(io_mu);
+  io_cv.wait(lk, [&] { return !buffer_busy[buffer]; });
+  if (io_error) std::rethrow_exception(io_error);
+}
+
+void ArrowStreamWriter::DrainIo() {
+  std::unique_lock<std::mutex> lk(io_mu);
+  io_cv.wait(lk, [&] { return io_jobs.empty() && !buffer_busy[0] && !buffer_busy[1]; });
+  if (io_error) std::rethrow_exception(io_error);
 }
 
 void ArrowStreamWriter::Flush(ChunkCollection& buffer) {
+  // Serialize() writes into the serializer's current body buffer: it must not be in the I/O thread's hands any more
+  WaitBufferFree(serializer.CurrentBody());
   if (serializer.Serialize(buffer) == 0) {
     buffer.Reset();
     ++row_group_count;  // the reference counts the flush even when the collection was empty (arrow_stream_writer.cpp:66-71)
     return;
   }
   buffer.Reset();
-  WriteData(serializer.GetHeader().data(), serializer.GetHeader().size());
-  WriteData(serializer.GetBody(), static_cast<size_t>(serializer.GetBodySize()));
+  WriteJob job;
+  job.header = serializer.GetHeader();
+  job.body = serializer.GetBody();
+  job.body_size = static_cast<size_t>(serializer.GetBodySize());
+  total_written += job.header.size() + job.body_size;
+  {
+    std::lock_guard<std::mutex> lk(io_mu);
+    job.buffer = serializer.SwapBody();
+    buffer_busy[job.buffer] = true;
+    io_jobs.push_back(std::move(job));
+    if (!io_thread.joinable()) io_thread = std::thread([this] { IoLoop(); });
+  }
+  io_cv.notify_all();
   ++row_group_count;
 }
 
 void ArrowStreamWriter::Finalize() {
   if (finalized) return;
+  DrainIo();
   const uint8_t end_of_stream[] = {0xFF, 0xFF, 0xFF, 0xFF, 0x00, 0x00, 0x00, 0x00};
   WriteData(end_of_stream, sizeof(end_of_stream));
+  total_written += sizeof(end_of_stream);
   ::close(fd);
   fd = -1;
   finalized = true;
+  if (Timers().on)
+    std::fprintf(stderr, "[mi_writer] append %.3f s, serialize (H2D + K7 + D2H) %.3f s, write (I/O thread) %.3f s\n", Timers().append,
+                 Timers().serialize, Timers().write);
 }
 
 }  // namespace miarrow

@@ -14,8 +14,12 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <condition_variable>
 #include <cstdint>
+#include <deque>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -51,6 +55,13 @@ class ChunkCollection {
     int64_t heap_used = 0;
     int64_t payload_bytes = 0;    // sum of valid string lengths = size of the Arrow data buffer (list: child rows gathered)
     bool has_nulls = false;
+    // long-string payloads: while the incoming strings lie back to back in row order (Arrow data buffers, DuckDB string
+    // heaps filled in order) the source bytes are staged as ONE growing run and the string_t rows keep their pointers
+    // (heap offset = pointer - ptr_base); anything else is gathered string by string behind the run
+    uint64_t ptr_base = 0;        // pointer value of heap[0]
+    uint64_t run_end = 0;         // source address one past the staged run (0: no run)
+    bool run_open = true;         // the run can still grow (nothing has been gathered behind it yet)
+    int64_t rows_since_long = 0;  // rows appended since the last long string (each may own <= 12 inline bytes in between)
     std::vector<int32_t> children;
     bool IsList() const { return arrow_type == MI_AT_LIST || arrow_type == MI_AT_MAP; }
     bool IsGroup() const { return arrow_type == MI_AT_STRUCT || arrow_type == MI_AT_FIXED_LIST; }
@@ -77,6 +88,18 @@ class ColumnDataCollectionSerializer {
   idx_t Serialize(ChunkCollection& buffer);
   const std::vector<uint8_t>& GetHeader() const { return header; }
   const uint8_t* GetBody() const { return h_body; }
+  int CurrentBody() const { return cur_body; }
+  //! The next Serialize() writes its body into the other pinned buffer (the stream writer hands the current one to its
+  //! I/O thread); returns the index of the buffer that was current
+  int SwapBody() {
+    const int was = cur_body;
+    h_bodies[cur_body] = h_body;
+    h_body_caps[cur_body] = h_body_cap;
+    cur_body ^= 1;
+    h_body = h_bodies[cur_body];
+    h_body_cap = h_body_caps[cur_body];
+    return was;
+  }
   int64_t GetBodySize() const { return body_size; }
   int64_t LastBytesRead() const { return plan ? plan->bytes_read : 0; }
 
@@ -84,7 +107,10 @@ class ColumnDataCollectionSerializer {
   Context* ctx;
   const ArrowSchemaModel* schema = nullptr;
   std::vector<uint8_t> header;
-  uint8_t* h_body = nullptr;  size_t h_body_cap = 0;   // pinned
+  uint8_t* h_body = nullptr;  size_t h_body_cap = 0;   // pinned; the current one of two
+  uint8_t* h_bodies[2] = {nullptr, nullptr};
+  size_t h_body_caps[2] = {0, 0};
+  int cur_body = 0;
   uint8_t* d_body = nullptr;  size_t d_body_cap = 0;
   uint8_t* d_in = nullptr;    size_t d_in_cap = 0;
   int64_t body_size = 0;
@@ -108,13 +134,32 @@ class ArrowStreamWriter {
   void InitOutputFile(const std::string& file_path);
   void WriteData(const uint8_t* p, size_t n);
 
+  // record-batch messages are written by an I/O thread while the sink stages the next row group; two body buffers
+  // alternate (the reference writes synchronously inside Flush, arrow_stream_writer.cpp:66-77)
+  struct WriteJob {
+    std::vector<uint8_t> header;
+    const uint8_t* body = nullptr;
+    size_t body_size = 0;
+    int buffer = -1;
+  };
+  void IoLoop();
+  void WaitBufferFree(int buffer);
+  void DrainIo();
+  std::thread io_thread;
+  std::mutex io_mu;
+  std::condition_variable io_cv;
+  std::deque<WriteJob> io_jobs;
+  bool buffer_busy[2] = {false, false};
+  bool io_stop = false;
+  std::exception_ptr io_error;
+
   Context* ctx;
   ArrowSchemaModel schema;
   ColumnDataCollectionSerializer serializer;
   std::string file_name;
   int fd = -1;
   idx_t row_group_count = 0;
-  idx_t total_written = 0;
+  idx_t total_written = 0;      // bytes handed to the file (queued writes included: rotation decisions see them at once)
   bool finalized = false;
 };
 
