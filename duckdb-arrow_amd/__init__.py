@@ -722,7 +722,7 @@ class Connection:
         finally:
             L.mi_writer_close(w)
 
-    def copy_to(self, table, path, preserve_insertion_order=True, file_size_bytes=None, **options):
+    def copy_to(self, table, path, preserve_insertion_order=True, file_size_bytes=None, arrow_large_buffer_size=False, **options):
         """COPY table TO 'path' (FORMAT ARROWS, row_group_size ..., chunk_size ..., row_group_size_bytes ...,
         row_groups_per_file ..., kv_metadata {...}).  With row_groups_per_file / file_size_bytes `path` becomes a
         directory of data_<i>.arrows files, like DuckDB's file rotation.  Returns the list of files written."""
@@ -730,6 +730,7 @@ class Connection:
         o = _ffi.WriteOptions()
         _ffi.check(L.mi_write_options_init(C.byref(o)))
         o.preserve_insertion_order = int(preserve_insertion_order)
+        o.arrow_large_buffer_size = int(arrow_large_buffer_size)   # SET arrow_large_buffer_size=true
         for k, v in options.items():
             if k.lower() == "kv_metadata":
                 if not isinstance(v, dict):

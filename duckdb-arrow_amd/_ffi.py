@@ -106,7 +106,8 @@ class WriteOptions(C.Structure):
                 ("row_groups_per_file", C.c_int64), ("row_group_size_set", C.c_int32),
                 ("row_group_size_bytes_set", C.c_int32), ("preserve_insertion_order", C.c_int32),
                 ("n_kv_metadata", C.c_int32), ("kv_keys", (C.c_char * 64) * MAX_KV),
-                ("kv_values", (C.c_char * 256) * MAX_KV), ("kv_value_lens", C.c_int32 * MAX_KV)]
+                ("kv_values", (C.c_char * 256) * MAX_KV), ("kv_value_lens", C.c_int32 * MAX_KV),
+                ("arrow_large_buffer_size", C.c_int32), ("_reserved", C.c_int32)]
 
 
 class SynthOptions(C.Structure):

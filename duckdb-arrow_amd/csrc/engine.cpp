@@ -188,8 +188,8 @@ static int64_t TaskBytesWritten(const mi_col_task& t) {
     case MI_K_ENC_COPY: b += n * t.param; break;
     case MI_K_ENC_DEC128: b += n * 16; break;
     case MI_K_ENC_BOOL: b += (n + 7) / 8; break;
-    case MI_K_ENC_STR32: b += (n + 1) * 4 + t.buf2_len; break;
-    case MI_K_ENC_LIST32: b += (n + 1) * 4; break;
+    case MI_K_ENC_STR32: b += (n + 1) * ((t.flags & 1) ? 8 : 4) + t.buf2_len; break;
+    case MI_K_ENC_LIST32: b += (n + 1) * ((t.flags & 1) ? 8 : 4); break;
     default: break;
   }
   return b;

@@ -993,7 +993,7 @@ __global__ __launch_bounds__(kBlockThreads) void encode_string_scan(const mi_col
       if (i < last) tile_sums[i] = carry + ex;
       carry += total;
     }
-    if (threadIdx.x == 0 && carry > 0x7FFFFFFFll) atomicOr(status, MI_ST_OFFSET_OVERFLOW);
+    if (threadIdx.x == 0 && carry > 0x7FFFFFFFll && !(tasks[ti].flags & 1)) atomicOr(status, MI_ST_OFFSET_OVERFLOW);
   }
 }
 
@@ -1014,8 +1014,13 @@ __device__ __forceinline__ void encode_string_tile_generic(const mi_col_task& t,
   const bool has = t.validity != nullptr;
   gptr<const uint8_t> heap = GC<uint8_t>(t.buf2);
   gptr<int32_t> off = GM<int32_t>(t.out_data);
+  gptr<int64_t> off64 = GM<int64_t>(t.out_data);
+  const bool large = (t.flags & 1) != 0;  // LargeUtf8 / LargeList: int64 offsets (arrow_large_buffer_size)
   gptr<uint8_t> data = GM<uint8_t>(t.out_aux);
-  if (row0 == 0 && threadIdx.x == 0) off[0] = 0;
+  if (row0 == 0 && threadIdx.x == 0) {
+    if (large) off64[0] = 0;
+    else off[0] = 0;
+  }
   for (int k = 0; k < kTileRows / kBlockThreads; k++) {
     const int r = threadIdx.x + k * kBlockThreads;
     if (k * kBlockThreads >= n) break;  // uniform
@@ -1028,7 +1033,10 @@ __device__ __forceinline__ void encode_string_tile_generic(const mi_col_task& t,
     int64_t total;
     const int64_t ex = block_exclusive_scan(static_cast<int64_t>(len), &total, lds4);
     const int64_t pos = base + ex;
-    if (r < n) off[row0 + r + 1] = static_cast<int32_t>(pos + len);
+    if (r < n) {
+      if (large) off64[row0 + r + 1] = pos + len;
+      else off[row0 + r + 1] = static_cast<int32_t>(pos + len);
+    }
     if (t.kind == MI_K_ENC_LIST32) {  // offsets only
       base += total;
       continue;
@@ -1277,10 +1285,15 @@ __global__ __launch_bounds__(kBlockThreads, OCC) void encode_string_v5(const mi_
     gptr<const u32x4> str = GC<u32x4>(t.buf1) + row0;
     gptr<const uint8_t> heap = GC<uint8_t>(t.buf2);
     gptr<int32_t> offp = GM<int32_t>(t.out_data) + row0 + 1;
+    gptr<int64_t> offp64 = GM<int64_t>(t.out_data) + row0 + 1;
+    const bool large = (t.flags & 1) != 0;  // LargeUtf8: int64 offsets (arrow_large_buffer_size)
     gptr<uint8_t> data = GM<uint8_t>(t.out_aux);
     const int64_t tile_base = tile_sums[tile];
     int64_t base = tile_base;
-    if (row0 == 0 && threadIdx.x == 0) offp[-1] = 0;
+    if (row0 == 0 && threadIdx.x == 0) {
+      if (large) offp64[-1] = 0;
+      else offp[-1] = 0;
+    }
     const int nsub = (n + kBlockThreads - 1) / kBlockThreads;
     u32x4 nxt = __builtin_nontemporal_load(str + (static_cast<int>(threadIdx.x) < n ? static_cast<int>(threadIdx.x) : n - 1));
     __syncthreads();  // s_valid
@@ -1316,7 +1329,10 @@ __global__ __launch_bounds__(kBlockThreads, OCC) void encode_string_v5(const mi_
       const uint32_t before = (wave > 0 ? tot.x : 0u) + (wave > 1 ? tot.y : 0u) + (wave > 2 ? tot.z : 0u);
       const uint32_t total = tot.x + tot.y + tot.z + tot.w;
       const uint32_t ex = before + incl - len;
-      if (r < n) offp[r] = static_cast<int32_t>(base + ex + len);
+      if (r < n) {
+        if (large) offp64[r] = base + ex + len;
+        else offp[r] = static_cast<int32_t>(base + ex + len);
+      }
       for (uint32_t w0 = 0; w0 < total;) {  // uniform: stage windows
         const uint32_t shiftw = static_cast<uint32_t>((base + w0) & 15);
         const uint32_t room = static_cast<uint32_t>(kEncStage5) - shiftw;

@@ -74,7 +74,8 @@ void EncodePlanFor(const ArrowField& f, int32_t* enc_kind, int64_t* param, int32
       else if (f.precision <= 18) { *enc_kind = MI_K_ENC_DEC128; *param = 8; *width = 8; }
       else { *enc_kind = MI_K_ENC_COPY; *param = 16; *width = 16; }
       return;
-    case MI_AT_UTF8: case MI_AT_BINARY: *enc_kind = MI_K_ENC_STR32; *param = 0; *width = 16; return;
+    case MI_AT_UTF8: case MI_AT_BINARY: case MI_AT_LARGE_UTF8: case MI_AT_LARGE_BINARY:
+      *enc_kind = MI_K_ENC_STR32; *param = 0; *width = 16; return;
     default: throw NotImplementedException("Arrow type " + f.Format() + " is not encoded by the MI355X writer path");
   }
 }
@@ -117,9 +118,10 @@ int32_t ChunkCollection::AddField(const ArrowField& f, int32_t depth) {
     switch (f.type) {
       case MI_AT_STRUCT: break;
       case MI_AT_FIXED_LIST: c.param = f.byte_width; break;
-      case MI_AT_LIST: case MI_AT_MAP: c.enc_kind = MI_K_ENC_LIST32; c.param = 0; c.width = 16; break;
+      case MI_AT_LIST: case MI_AT_LARGE_LIST: case MI_AT_MAP: c.enc_kind = MI_K_ENC_LIST32; c.param = 0; c.width = 16; break;
       default: EncodePlanFor(f, &c.enc_kind, &c.param, &c.width); break;
     }
+    c.large_offsets = f.type == MI_AT_LARGE_UTF8 || f.type == MI_AT_LARGE_BINARY || f.type == MI_AT_LARGE_LIST;
   }
   for (auto& ch : f.children) {
     const int32_t k = AddField(ch, depth + 1);
@@ -246,7 +248,7 @@ void ChunkCollection::AppendNode(int32_t ni, const mi_vector& v, int64_t start, 
         run_len = l;
       }
       columns[static_cast<size_t>(ni)].payload_bytes += l;   // child rows so far = the last Arrow offset
-      if (columns[static_cast<size_t>(ni)].payload_bytes > 0x7FFFFFFFll)
+      if (columns[static_cast<size_t>(ni)].payload_bytes > 0x7FFFFFFFll && !columns[static_cast<size_t>(ni)].large_offsets)
         throw InvalidInputException("Arrow Appender: The maximum combined list offset for regular list buffers is 2147483647 but the offset of " +
                                     std::to_string(columns[static_cast<size_t>(ni)].payload_bytes) +
                                     " exceeds this.\n* SET arrow_large_buffer_size=true to use large list buffers");
@@ -345,20 +347,21 @@ idx_t ColumnDataCollectionSerializer::Serialize(ChunkCollection& buffer) {
     if (n > 0x7FFFFFFFll) throw InvalidInputException("record batch too large");
     in_off[ci].first_span = spans.size();
     add_span((n + 7) / 8);  // validity: always emitted (ArrowAppender::FinalizeChild)
+    const int64_t off_width = c.large_offsets ? 8 : 4;
     if (c.IsList()) {
-      add_span((n + 1) * 4);
+      add_span((n + 1) * off_width);
     } else if (!c.IsGroup()) {
       switch (c.enc_kind) {
         case MI_K_ENC_COPY: add_span(n * c.param); break;
         case MI_K_ENC_DEC128: add_span(n * 16); break;
         case MI_K_ENC_BOOL: add_span((n + 7) / 8); break;
         case MI_K_ENC_STR32:
-          if (c.payload_bytes > 0x7FFFFFFFll) {
+          if (c.payload_bytes > 0x7FFFFFFFll && !c.large_offsets) {
             throw InvalidInputException(
                 "Arrow Appender: The maximum total string size for regular string buffers is 2147483647 but the offset of " +
                 std::to_string(c.payload_bytes) + " exceeds this.\n* SET arrow_large_buffer_size=true to use large string buffers");
           }
-          add_span((n + 1) * 4);
+          add_span((n + 1) * off_width);
           add_span(c.payload_bytes);
           break;
         default: break;
@@ -407,7 +410,8 @@ idx_t ColumnDataCollectionSerializer::Serialize(ChunkCollection& buffer) {
       tasks.push_back(t);
       continue;
     }
-    if (c.IsList()) {  // list / map: bitmap + int32 offsets from the staged list_entry_t rows
+    t.flags = c.large_offsets ? 1 : 0;
+    if (c.IsList()) {  // list / map: bitmap + int32 (or int64) offsets from the staged list_entry_t rows
       t.kind = MI_K_ENC_LIST32;
       t.buf1 = d_in + in_off[ci].data;
       t.out_data = d_body + spans[sp + 1].offset;
@@ -628,10 +632,22 @@ uint64_t ParseU64(const std::string& name, const std::string& v) {
   return x;
 }
 
-std::vector<ArrowField> FieldsFromC(const mi_field* fields, int32_t n_fields) {
+// arrow_large_buffer_size: VARCHAR / BLOB / LIST export with 64-bit offsets (ArrowConverter::ToArrowSchema with
+// ArrowOffsetSize::LARGE); MAP keeps int32 offsets (the Arrow format has no large map)
+void MakeLarge(ArrowField& f) {
+  if (f.type == MI_AT_UTF8) f.type = MI_AT_LARGE_UTF8;
+  else if (f.type == MI_AT_BINARY) f.type = MI_AT_LARGE_BINARY;
+  else if (f.type == MI_AT_LIST) f.type = MI_AT_LARGE_LIST;
+  for (auto& c : f.children) MakeLarge(c);
+}
+
+std::vector<ArrowField> FieldsFromC(const mi_field* fields, int32_t n_fields, bool large = false) {
   if (!fields || n_fields <= 0) throw InvalidInputException("writer needs at least one column");
   std::vector<ArrowField> out;
-  for (int32_t i = 0; i < n_fields; i++) out.push_back(FieldFromDuckType(fields[i].name, fields[i].duck_type));
+  for (int32_t i = 0; i < n_fields; i++) {
+    out.push_back(FieldFromDuckType(fields[i].name, fields[i].duck_type));
+    if (large) MakeLarge(out.back());
+  }
   return out;
 }
 }  // namespace
@@ -720,7 +736,7 @@ int mi_writer_open(mi_ctx* ctx, const char* path, const mi_field* fields, int32_
       mi_write_options_finalize(&w->opts);
     }
     if (w->opts.row_group_size_bytes <= 0) w->opts.row_group_size_bytes = w->opts.row_group_size * 1024;
-    w->fields = FieldsFromC(fields, n_fields);
+    w->fields = FieldsFromC(fields, n_fields, w->opts.arrow_large_buffer_size != 0);
     std::vector<std::pair<std::string, std::string>> kv;
     for (int32_t i = 0; i < w->opts.n_kv_metadata; i++)
       kv.emplace_back(w->opts.kv_keys[i], std::string(w->opts.kv_values[i], static_cast<size_t>(w->opts.kv_value_lens[i])));

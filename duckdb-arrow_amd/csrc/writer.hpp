@@ -35,6 +35,7 @@ namespace miarrow {
 //! and the list node itself stages its list_entry_t rows (the GPU turns their lengths into the int32 Arrow offsets).
 class ChunkCollection {
  public:
+  //! fields as exported (LargeUtf8 / LargeBinary / LargeList nodes get int64 offsets)
   ChunkCollection(Context* ctx, const std::vector<ArrowField>& fields);
   ~ChunkCollection();
   void Append(const mi_data_chunk& chunk);
@@ -55,6 +56,7 @@ class ChunkCollection {
     int64_t heap_used = 0;
     int64_t payload_bytes = 0;    // sum of valid string lengths = size of the Arrow data buffer (list: child rows gathered)
     bool has_nulls = false;
+    bool large_offsets = false;   // int64 Arrow offsets (arrow_large_buffer_size)
     // long-string payloads: while the incoming strings lie back to back in row order (Arrow data buffers, DuckDB string
     // heaps filled in order) the source bytes are staged as ONE growing run and the string_t rows keep their pointers
     // (heap offset = pointer - ptr_base); anything else is gathered string by string behind the run
@@ -63,7 +65,7 @@ class ChunkCollection {
     bool run_open = true;         // the run can still grow (nothing has been gathered behind it yet)
     int64_t rows_since_long = 0;  // rows appended since the last long string (each may own <= 12 inline bytes in between)
     std::vector<int32_t> children;
-    bool IsList() const { return arrow_type == MI_AT_LIST || arrow_type == MI_AT_MAP; }
+    bool IsList() const { return arrow_type == MI_AT_LIST || arrow_type == MI_AT_LARGE_LIST || arrow_type == MI_AT_MAP; }
     bool IsGroup() const { return arrow_type == MI_AT_STRUCT || arrow_type == MI_AT_FIXED_LIST; }
   };
   std::vector<Column> columns;     // every field node, depth first

@@ -104,7 +104,7 @@ enum mi_kind {
   MI_K_ENC_COPY = 32,     /* K7b fixed-width copy; param = width */
   MI_K_ENC_DEC128 = 33,   /* K7b int16/32/64 -> decimal128 sign extension; param = in width */
   MI_K_ENC_BOOL = 34,     /* K7c byte -> bit, bits start as 1 */
-  MI_K_ENC_STR32 = 35,    /* K7d string_t -> int32 offsets + data */
+  MI_K_ENC_STR32 = 35,    /* K7d string_t -> int32 offsets + data (flags bit 0: int64 offsets, LargeUtf8 / LargeList) */
   MI_K_ENC_VALIDITY = 36, /* K7a alone: validity words -> always-present bitmap + NULL count (struct / fixed_size_list node) */
   MI_K_ENC_LIST32 = 37    /* list_entry_t{u64 offset, u64 length} rows -> bitmap + int32 Arrow offsets (running sum of the
                            * lengths of the valid rows, NULL rows repeat the offset: ArrowListData::AppendOffsets); the
@@ -400,6 +400,10 @@ typedef struct mi_write_options {
   char kv_keys[MI_MAX_KV_METADATA][64];
   char kv_values[MI_MAX_KV_METADATA][256]; /* BLOB values are written raw, others as their string form */
   int32_t kv_value_lens[MI_MAX_KV_METADATA];
+  int32_t arrow_large_buffer_size; /* DuckDB's setting of the same name (ClientProperties.arrow_offset_size, passed to the
+                                    * serializer at arrow_stream_writer.cpp:11-13): VARCHAR / BLOB / LIST export as
+                                    * LargeUtf8 / LargeBinary / LargeList with int64 offsets; default 0 */
+  int32_t _reserved;
 } mi_write_options;
 
 /* ArrowWriteBind (write_arrow_stream.cpp:54-125): _init fills the defaults; _set parses one COPY option (name is

@@ -414,3 +414,23 @@ def test_nested_scan_then_copy_equals_source(con, golden_dir, tmp_path):
     assert b.num_rows == a.num_rows
     for name in rel.columns:
         assert a.column(name).to_pylist() == b.column(name).to_pylist(), name
+
+
+def test_arrow_large_buffer_size_exports_int64_offsets(con, tmp_path):
+    """SET arrow_large_buffer_size=true (ClientProperties.arrow_offset_size, arrow_stream_writer.cpp:11-13): VARCHAR /
+    BLOB / LIST columns are exported as LargeUtf8 / LargeBinary / LargeList with int64 offsets, MAP keeps int32."""
+    cols = nested_rows(3000, seed=8)
+    blobs = [None if i % 9 == 0 else bytes([i % 251]) * (i % 40) for i in range(3000)]
+    path = str(tmp_path / "large.arrows")
+    con.copy_to(da.Table(NESTED_NAMES + ["b"], NESTED_TYPES + ["BLOB"], cols + [blobs]), path, row_group_size=2048,
+                arrow_large_buffer_size=True)
+    t = ipc.open_stream(path).read_all()
+    assert t.schema.field("s").type == pa.large_string() and t.schema.field("b").type == pa.large_binary()
+    assert t.schema.field("l").type == pa.large_list(pa.field("l", pa.int32()))
+    assert t.schema.field("ll").type == pa.large_list(pa.field("l", pa.large_list(pa.field("l", pa.large_string()))))
+    assert t.schema.field("mp").type == pa.map_(pa.large_string(), pa.int32())
+    for name, want in zip(NESTED_NAMES + ["b"], cols + [blobs]):
+        assert t.column(name).to_pylist() == want, name
+    # and the scan reads its own large output back (int64 offsets -> K4b / LIST64)
+    back = con.read_arrow(path).project(["s", "l", "b"]).fetch_columns()
+    assert back[0] == cols[6] and back[1] == cols[0] and back[2] == blobs
