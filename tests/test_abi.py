@@ -83,3 +83,38 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or f == "Makefile":
                 text = open(os.path.join(root, f), errors="replace").read()
                 assert "pyoracle" not in text and "liboracle" not in text and "oracle.h" not in text, os.path.join(root, f)
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "q6")
+    libdir = os.path.join(root, "duckdb-arrow_amd")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "examples", "q6.c"), "-L" + libdir, "-lmi_arrow_ipc", "-Wl,-rpath," + libdir, "-o", exe],
+                   check=True, capture_output=True)
+    return exe
+
+
+def test_plain_c_client_builds_and_fails_loudly_without_a_gpu(tmp_path):
+    """examples/q6.c is C99 against include/mi_arrow_ipc.h alone (no C++, HIP or torch on the client side).  Without a
+    device the first call reports MI_ENODEV -- the product path has no CPU fallback."""
+    import subprocess
+    import torch
+    exe = _build_c_example(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("covered by the GPU variant")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([exe, os.path.join(root, "tests", "golden", "lineitem_sf0_01_q6.arrows")], capture_output=True, text=True)
+    assert r.returncode == 1 and "mi_ctx_create failed (19)" in r.stderr and "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+def test_plain_c_client_computes_q6(tmp_path):
+    """The same binary on a GPU box: TPC-H Q6 on lineitem SF0.01 = 1193053.2253 (test/nodejs/arrow_test.js:423-424)."""
+    import subprocess
+    exe = _build_c_example(tmp_path)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([exe, os.path.join(root, "tests", "golden", "lineitem_sf0_01_q6.arrows")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "revenue = 1193053.2253  (1191 of 60175 rows pass)" in r.stdout
