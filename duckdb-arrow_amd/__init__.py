@@ -632,10 +632,19 @@ class Connection:
     """The extension's function surface for this path, bound to one GPU."""
 
     def __init__(self, device=0):
+        import weakref
         self.ctx = Context(device)
+        self._relations = weakref.WeakSet()   # scans hold streams / buffers of the context: they go first
 
     def close(self):
+        for rel in list(self._relations):
+            rel.close()
         self.ctx.close()
+
+    def _relation(self, handle, keep=None):
+        rel = Relation(self, handle, keep)
+        self._relations.add(rel)
+        return rel
 
     # -- scan ------------------------------------------------------------------------------------------
     @staticmethod
@@ -668,7 +677,7 @@ class Connection:
         arr = (C.c_char_p * len(expanded))(*[os.fsencode(p) for p in expanded])
         h = C.c_void_p()
         _ffi.check(_ffi.lib().mi_scan_open_files(self.ctx._h, arr, len(expanded), C.byref(opts), C.byref(h)))
-        return Relation(self, h)
+        return self._relation(h)
 
     def scan_arrow_ipc(self, buffers, **options):
         """FROM scan_arrow_ipc([{ptr, size}, ...]); buffers may be bytes-like objects or (ptr, size) tuples."""
@@ -683,7 +692,7 @@ class Connection:
         opts = self._options(**options)
         h = C.c_void_p()
         _ffi.check(_ffi.lib().mi_scan_open_buffers(self.ctx._h, arr, len(buffers), C.byref(opts), C.byref(h)))
-        return Relation(self, h, keep=(keep, buffers))
+        return self._relation(h, keep=(keep, buffers))
 
     def from_arrow(self, message_reader, **options):
         """con.from_arrow(pyarrow.ipc.MessageReader): serialises each message back to its IPC bytes and scans the

@@ -23,7 +23,7 @@ ST_BAD_OFFSETS, ST_STRING_TOO_LARGE, ST_MUL_OVERFLOW, ST_INDEX_RANGE, ST_DECIMAL
 
 
 class Field(C.Structure):
-    _fields_ = [("name", C.c_char * 128), ("timezone", C.c_char * 64), ("duck_type", C.c_char * 64),
+    _fields_ = [("name", C.c_char * 128), ("timezone", C.c_char * 64), ("duck_type", C.c_char * 1024),
                 ("format", C.c_char * 32), ("arrow_type", C.c_int32), ("bit_width", C.c_int32),
                 ("is_signed", C.c_int32), ("precision", C.c_int32), ("scale", C.c_int32), ("unit", C.c_int32),
                 ("byte_width", C.c_int32), ("nullable", C.c_int32), ("has_dictionary", C.c_int32),

@@ -202,7 +202,11 @@ void FillCField(const ArrowField& f, int32_t flat_index, mi_field* out) {
   std::memset(out, 0, sizeof(*out));
   std::snprintf(out->name, sizeof(out->name), "%s", f.name.c_str());
   std::snprintf(out->timezone, sizeof(out->timezone), "%s", f.timezone.c_str());
-  std::snprintf(out->duck_type, sizeof(out->duck_type), "%s", f.DuckType().c_str());
+  const std::string duck = f.DuckType();
+  if (duck.size() >= sizeof(out->duck_type))
+    throw NotImplementedException("Column '" + f.name + "': the DuckDB type description is longer than " +
+                                  std::to_string(sizeof(out->duck_type) - 1) + " characters");
+  std::snprintf(out->duck_type, sizeof(out->duck_type), "%s", duck.c_str());
   std::snprintf(out->format, sizeof(out->format), "%s", f.Format().c_str());
   out->arrow_type = f.type;
   out->bit_width = f.bit_width;

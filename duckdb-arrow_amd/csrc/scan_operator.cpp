@@ -417,7 +417,7 @@ int32_t ArrowScan::AddNode(Slot& s, const DecodedBatch& b, int32_t ni, std::vect
       }
       if (nd.spans.size() <= 2) { aux->push_back(0); aux->push_back(0); }
       t.buf2_len = static_cast<int64_t>(nd.spans.size() > 2 ? nd.spans.size() - 2 : 0);
-      aux_fixups->emplace_back(tasks->size(), at);
+      if (n > 0) aux_fixups->emplace_back(tasks->size(), at);  // an empty node gets no task (below): nothing to patch
       break;
     }
     case MI_K_DICT: {
@@ -434,7 +434,7 @@ int32_t ArrowScan::AddNode(Slot& s, const DecodedBatch& b, int32_t ni, std::vect
         const size_t at = aux->size();
         for (int64_t r : win) aux->push_back(static_cast<uint64_t>(r));
         t.buf2_len = static_cast<int64_t>(win.size());
-        aux_fixups->emplace_back(tasks->size(), at);
+        if (n > 0) aux_fixups->emplace_back(tasks->size(), at);
       }
       // the child's windows start at offsets[win[k]] (read from the host copy of the body)
       const uint8_t* offs = b.body + span(1).offset;

@@ -114,7 +114,8 @@ enum mi_kind {
 typedef struct mi_field {
   char name[128];
   char timezone[64];
-  char duck_type[64];     /* DuckDB logical type as `typeof` prints it: BIGINT, DECIMAL(15,2), TIMESTAMP WITH TIME ZONE */
+  char duck_type[1024];   /* DuckDB logical type as `typeof` prints it: BIGINT, DECIMAL(15,2), TIMESTAMP WITH TIME ZONE,
+                           * STRUCT(a INTEGER, b VARCHAR[])[] ... (nested types need the room; longer ones are refused) */
   char format[32];        /* Arrow C data interface format string: "l", "u", "d:15,2", "tdD", "tsu:UTC" */
   int32_t arrow_type;     /* enum mi_arrow_type */
   int32_t bit_width, is_signed, precision, scale, unit, byte_width, nullable;

@@ -479,3 +479,25 @@ def test_many_files_and_early_close_with_read_ahead(con, tmp_path):
         for ch in rel.chunks():
             seen += ch.size
     assert seen >= 4 * 5000 and seen <= 5 * 5000
+
+
+def test_empty_record_batches_with_nested_columns(con, tmp_path):
+    """Regression (found by the random-table test): a record batch of 0 rows whose columns are lists of lists / string
+    views gets no transcode task, so nothing may refer to one (window / buffer tables were patched into a missing task)."""
+    sch = pa.schema([("ll", pa.large_list(pa.large_list(pa.int16()))), ("k", pa.int64()), ("sv", pa.string_view()),
+                     ("l", pa.list_(pa.string()))])
+    def batch(rows):
+        return pa.record_batch([pa.array([r[0] for r in rows], sch[0].type), pa.array([r[1] for r in rows], sch[1].type),
+                                pa.array([r[2] for r in rows], sch[2].type), pa.array([r[3] for r in rows], sch[3].type)], schema=sch)
+    rows = [([[1, 2], [], None, [3]], 7, "a string longer than twelve bytes", ["x", None]), (None, None, None, None), ([], 1, "", [])]
+    path = str(tmp_path / "e.arrows")
+    with ipc.new_stream(path, sch) as w:
+        w.write_batch(batch([]))
+        w.write_batch(batch(rows))
+        w.write_batch(batch([]))
+        w.write_batch(batch(rows * 1000))
+    got = con.read_arrow(path).fetch_columns()
+    want = ipc.open_stream(path).read_all()
+    assert [len(c) for c in got] == [3003] * 4
+    for name, g in zip(want.column_names, got):
+        assert g == want.column(name).to_pylist(), name
