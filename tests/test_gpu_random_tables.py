@@ -131,3 +131,103 @@ def test_random_tables_scan_and_copy(seed, tmp_path):
             a, b = want_table.column(name).to_pylist(), back.column(name).to_pylist()
             assert fix_floats(a) == fix_floats(b), (seed, name)
     con.close()
+
+
+# ---------------------------------------------------------------------------------------- flat types x container modes
+def _flat_random_column(rng, n):
+    """One random flat column of a temporal / decimal / dictionary / plain type (NULLs at 15 %)."""
+    mask = rng.random(n) < 0.15
+    kind = int(rng.integers(0, 14))
+    i64 = lambda lo, hi: rng.integers(lo, hi, n)
+    if kind == 0:
+        return pa.array(i64(-10**12, 10**12), pa.timestamp(["s", "ms", "us", "ns"][int(rng.integers(0, 4))]), mask=mask)
+    if kind == 1:
+        return pa.array(i64(-10**11, 10**11), pa.timestamp(["s", "ms", "us", "ns"][int(rng.integers(0, 4))], "UTC"), mask=mask)
+    if kind == 2:
+        return pa.array(i64(0, 86400).astype(np.int32), pa.time32("s"), mask=mask)
+    if kind == 3:
+        return pa.array(i64(0, 86400000).astype(np.int32), pa.time32("ms"), mask=mask)
+    if kind == 4:
+        return pa.array(i64(0, 86400 * 10**6), pa.time64("us"), mask=mask)
+    if kind == 5:
+        return pa.array(i64(0, 86400 * 10**9), pa.time64("ns"), mask=mask)
+    if kind == 6:
+        return pa.array(i64(-10**6, 10**6) * 86400000, pa.date64(), mask=mask)
+    if kind == 7:
+        return pa.array(i64(-10**9, 10**9), pa.duration(["s", "ms", "us", "ns"][int(rng.integers(0, 4))]), mask=mask)
+    if kind == 8:
+        p = int(rng.integers(1, 39))
+        s = int(rng.integers(0, p + 1))
+        vals = [None if m else decimal.Decimal(int(rng.integers(-10**min(p, 18) + 1, 10**min(p, 18)))).scaleb(-s) for m in mask]
+        return pa.array(vals, pa.decimal128(p, s))
+    if kind == 9:
+        cats = pa.array([WORDS[i] + str(i) for i in range(len(WORDS))])
+        idx_t = [pa.int8(), pa.int16(), pa.int32(), pa.int64(), pa.uint8(), pa.uint16()][int(rng.integers(0, 6))]
+        return pa.DictionaryArray.from_arrays(pa.array(rng.integers(0, len(cats), n), idx_t, mask=mask), cats)
+    if kind == 10:
+        return pa.array(rng.normal(size=n).astype(np.float16), pa.float16(), mask=mask)
+    if kind == 11:
+        return pa.array([None if m else bytes(rng.integers(0, 256, 5, dtype=np.uint8)) for m in mask], pa.binary(5))
+    if kind == 12:
+        return pa.array([None] * n, pa.null())
+    return pa.array([None if m else WORDS[int(rng.integers(0, len(WORDS)))] * int(rng.integers(0, 4)) for m in mask], pa.large_binary()
+                    if rng.random() < 0.5 else pa.large_string())
+
+
+@pytest.mark.parametrize("mode", ["stream", "file", "zstd", "lz4", "zero_copy", "projection"])
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MI_RANDOM_FLAT_SEEDS", "4"))))
+def test_random_flat_types_in_every_container(seed, mode, tmp_path):
+    """Temporal unit casts, decimals of every precision, dictionaries with every index type, half floats, fixed binary,
+    null columns -- through the stream format, the IPC *file* format, ZSTD and LZ4 bodies, zero_copy_direct and a projected
+    read; expected values are make_golden.py's canonical forms (what DuckDB stores), computed from pyarrow."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_golden import canon_column
+    from helpers import canon_python
+    rng = np.random.default_rng(5000 + seed)
+    ncols = int(rng.integers(2, 8))
+    sizes = [int(x) for x in rng.choice([0, 1, 64, 999, 2048, 4100], size=int(rng.integers(1, 4)))]
+    first = [_flat_random_column(rng, sizes[0]) for _ in range(ncols)]
+    schema = pa.schema([pa.field("c%d" % i, a.type) for i, a in enumerate(first)])
+    batches = [pa.record_batch(first, schema=schema)]
+    for n in sizes[1:]:
+        cols = []
+        for f in schema:
+            while True:   # a column of the same type (the generator picks the type at random)
+                a = _flat_random_column(rng, n)
+                if a.type == f.type:
+                    break
+            cols.append(a)
+        batches.append(pa.record_batch(cols, schema=schema))
+    path = str(tmp_path / ("t." + ("arrow" if mode == "file" else "arrows")))
+    opts = ipc.IpcWriteOptions(compression=mode) if mode in ("zstd", "lz4") else None
+    if mode == "file":
+        with ipc.new_file(path, schema) as w:
+            for b in batches:
+                w.write_batch(b)
+        table = ipc.open_file(path).read_all()
+    else:
+        with ipc.new_stream(path, schema, options=opts) as w:
+            for b in batches:
+                w.write_batch(b)
+        table = ipc.open_stream(path).read_all()
+    con = da.Connection(0)
+    names = table.column_names
+    if mode == "projection":
+        names = [n for i, n in enumerate(names) if (seed + i) % 2 == 0] or names[:1]
+        names = names[::-1]
+    rel = con.read_arrow(path, accept_dictionaries=True, zero_copy_direct=(mode == "zero_copy"))
+    if mode == "projection":
+        rel = rel.project(names)
+    got = rel.fetch_columns()
+    for name, g in zip(names, got):
+        t = table.schema.field(name).type
+        want = canon_column(table.column(name))
+        if pa.types.is_duration(t):
+            g = [None if v is None else v[2] for v in g]
+        elif pa.types.is_float16(t) or pa.types.is_floating(t):
+            g = [None if v is None else ("nan" if v != v else repr(v)) for v in g]
+            want = [None if v is None else (v if isinstance(v, str) else repr(float(v))) for v in want]
+        assert canon_python(g) == want, (seed, mode, name, str(t))
+    con.close()
