@@ -231,3 +231,27 @@ def test_random_flat_types_in_every_container(seed, mode, tmp_path):
             want = [None if v is None else (v if isinstance(v, str) else repr(float(v))) for v in want]
         assert canon_python(g) == want, (seed, mode, name, str(t))
     con.close()
+
+
+# ---------------------------------------------------------------------------------------- kernel level vs the oracle
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MI_RANDOM_ORACLE_SEEDS", "10"))))
+def test_random_tables_bit_exact_vs_oracle(seed):
+    """The same random nested tables at kernel level: every decoded array (data bytes, validity words, list entries,
+    child windows) equals the CPU oracle's bit for bit -- layout parity, not just logical values."""
+    from duckdb_arrow_amd.hbm import HbmStream
+    from oracle import pyoracle as po
+    from test_gpu_decode_parity import assert_streams_equal
+    rng = np.random.default_rng(9000 + seed)
+    schema = pa.schema([pa.field("c%d" % i, random_type(rng, 0)) for i in range(int(rng.integers(1, 6)))])
+    sink = pa.BufferOutputStream()
+    with ipc.new_stream(sink, schema) as w:
+        for n in [int(x) for x in rng.choice([0, 1, 63, 700, 2048, 2500, 5000], size=int(rng.integers(1, 4)))]:
+            w.write_batch(pa.record_batch([pa.array([random_value(rng, f.type, 0.15) for _ in range(n)], f.type) for f in schema],
+                                          schema=schema))
+    buf = np.frombuffer(sink.getvalue(), np.uint8)
+    ctx = da.Context(0)
+    hs = HbmStream(ctx, buf)
+    hs.launch()
+    assert hs.status() == 0
+    _, want = po.decode_stream(buf)
+    assert_streams_equal(hs.fetch(), want)
