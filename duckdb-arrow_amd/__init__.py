@@ -46,10 +46,12 @@ def device_count():
 
 
 def _field_dict(f):
-    return dict(name=f.name.decode(), duck_type=f.duck_type.decode(), format=f.format.decode(), arrow_type=f.arrow_type,
+    # names come from the file: a damaged stream may carry bytes that are not UTF-8
+    return dict(name=f.name.decode("utf-8", "replace"), duck_type=f.duck_type.decode("utf-8", "replace"),
+                format=f.format.decode("utf-8", "replace"), arrow_type=f.arrow_type,
                 kind=f.kind, out_width=f.out_width, param=f.param, n_buffers=f.n_buffers, flat_index=f.flat_index,
                 bit_width=f.bit_width, is_signed=f.is_signed, precision=f.precision, scale=f.scale, unit=f.unit,
-                byte_width=f.byte_width, nullable=f.nullable, timezone=f.timezone.decode(),
+                byte_width=f.byte_width, nullable=f.nullable, timezone=f.timezone.decode("utf-8", "replace"),
                 has_dictionary=f.has_dictionary, dict_id=f.dict_id, dict_index_bit_width=f.dict_index_bit_width,
                 dict_index_signed=f.dict_index_signed)
 
@@ -126,7 +128,7 @@ class Reader:
                     null_count=[b.null_count[i] for i in range(nc)],
                     buffers=[(b.buffers[i].offset, b.buffers[i].length) for i in range(3 * nc)],
                     column_node=[b.column_node[i] for i in range(nc)],
-                    nodes=[dict(name=b.nodes[i].name.decode(), arrow_type=b.nodes[i].arrow_type, kind=b.nodes[i].kind,
+                    nodes=[dict(name=b.nodes[i].name.decode("utf-8", "replace"), arrow_type=b.nodes[i].arrow_type, kind=b.nodes[i].kind,
                                 out_width=b.nodes[i].out_width, parent=b.nodes[i].parent, depth=b.nodes[i].depth,
                                 n_children=b.nodes[i].n_children, param=b.nodes[i].param, length=b.nodes[i].length,
                                 null_count=b.nodes[i].null_count,

@@ -390,6 +390,8 @@ void IPCStreamReader::DecompressBody(RecordBatchMeta* meta) {
     std::memcpy(&n, cur_ptr + b.offset, 8);
     if (n == -1) n = b.length - 8;
     if (n < 0) throw IOException("Compressed buffer " + std::to_string(i) + " declares a negative uncompressed length");
+    if (n > (int64_t(1) << 40) || total > (int64_t(1) << 41))
+      throw IOException("Compressed buffer " + std::to_string(i) + " declares an implausible uncompressed length of " + std::to_string(n) + " bytes");
     ulen[i] = n;
     total += (n + 63) & ~static_cast<int64_t>(63);
   }
