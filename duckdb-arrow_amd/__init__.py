@@ -258,7 +258,7 @@ def _string_values(data_ptr, n, ok, as_bytes):
             continue
         ln = int(lens[i])
         b = raw[i, 4: 4 + ln].tobytes() if ln <= 12 else C.string_at(int(ptrs[i]), ln)
-        out.append(b if as_bytes else b.decode("utf-8"))
+        out.append(b if as_bytes else b.decode("utf-8", "replace"))   # damaged payloads are not ours to reject
     return out
 
 

@@ -437,6 +437,7 @@ void ThrowForStatus(uint32_t bits) {
   if (bits & MI_ST_STRING_TOO_LARGE) throw ConversionException("DuckDB does not support Strings over 4GB");
   if (bits & MI_ST_MUL_OVERFLOW) throw ConversionException("Could not convert Timestamp to Microsecond");
   if (bits & MI_ST_INDEX_RANGE) throw ConversionException("DuckDB only supports indices that fit on an uint32");
+  if (bits & MI_ST_DICT_INDEX) throw InternalException("Arrow IPC validation failed: dictionary index out of range");
   if (bits & MI_ST_DECIMAL_RANGE) throw ConversionException("Decimal value does not fit the physical type of its declared precision");
   if (bits & MI_ST_OFFSET_OVERFLOW)
     throw InvalidInputException(

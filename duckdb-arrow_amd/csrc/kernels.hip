@@ -697,7 +697,10 @@ __device__ __forceinline__ void tile_dict(const mi_col_task& t, int64_t row0, in
       }
       if (v > 0xFFFFFFFFull) {  // "DuckDB only supports indices that fit on an uint32"
         err = MI_ST_INDEX_RANGE;
-        v = 0;
+        v = dict_len;
+      } else if (v >= dict_len) {  // the selection vector must never point past the dictionary's NULL slot
+        err = MI_ST_DICT_INDEX;
+        v = dict_len;
       }
       sel = static_cast<uint32_t>(v);
     }

@@ -439,11 +439,18 @@ int32_t ArrowScan::AddNode(Slot& s, const DecodedBatch& b, int32_t ni, std::vect
       // the child's windows start at offsets[win[k]] (read from the host copy of the body)
       const uint8_t* offs = b.body + span(1).offset;
       child_win.reserve(win.size());
+      int64_t prev = 0;
       for (int64_t r : win) {
         int64_t v = 0;
         if (n > 0) {
+          if (r < 0 || r > n) throw InternalException("Arrow IPC validation failed: list window outside the column");
           if (kind == MI_K_LIST32) { int32_t x; std::memcpy(&x, offs + 4 * r, 4); v = x; }
           else std::memcpy(&v, offs + 8 * r, 8);
+          // the offsets sampled here place the child vectors of every chunk: they are checked on the host (the device
+          // checks all of them, but only flags) so that no window ever points outside the child column
+          if (v < prev || v > t.param)
+            throw InternalException("Arrow IPC validation failed: offsets buffer is not monotonically non-decreasing or exceeds the data buffer");
+          prev = v;
         }
         child_win.push_back(v);
       }

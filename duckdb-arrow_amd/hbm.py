@@ -148,6 +148,9 @@ class HbmStream:
             if not win_is_tiles:
                 t.update(aux=self._aux_table(np.array(win, np.int64)), buf2_len=len(win))
             child_win = [int(offs[r]) for r in win] if n else [0] * len(win)
+            if any(b < a for a, b in zip(child_win, child_win[1:])) or (child_win and (child_win[0] < 0 or child_win[-1] > t["param"])):
+                # windows place the child vectors (and are dereferenced by the kernel): never from unchecked offsets
+                raise ValueError("list offsets of %r are not monotonically non-decreasing inside the child column" % nd["name"])
         if n > 0 or kind == _ffi.K_STRUCT:
             if n > 0:
                 self._tasks.append((entry, t))

@@ -286,7 +286,9 @@ int orc_dict_sel(const void* idx, int32_t idx_width, int32_t idx_signed, const u
       case 4: v = idx_signed ? (uint64_t)(int64_t)((const int32_t*)idx)[r] : ((const uint32_t*)idx)[r]; break;
       default: v = ((const uint64_t*)idx)[r]; break;
     }
-    if (v > (uint64_t)UINT32_MAX) { rc = ORC_EINVAL; v = 0; }
+    /* an index that does not fit uint32 ("DuckDB only supports indices that fit on an uint32") or points past the
+     * dictionary is an error; the slot then selects the dictionary's NULL entry */
+    if (v > (uint64_t)UINT32_MAX || v >= (uint64_t)dict_len) { rc = ORC_EINVAL; v = dict_len; }
     sel[i] = (uint32_t)v;
   }
   return rc;

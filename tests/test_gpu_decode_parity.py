@@ -206,6 +206,12 @@ def test_device_status_flags(ctx, torch):
     idx = np.array([0, 1, -1, 2], np.int32)
     data, _, st = _run_task(ctx, torch, _ffi.K_DICT, 4, idx, width=4, param=4 | (1 << 8), param2=3)
     assert st == _ffi.ST_INDEX_RANGE
+    # an index past the dictionary: flagged, and the slot selects the dictionary's NULL entry instead of pointing outside
+    idx = np.array([0, 7, 2, 3], np.int32)
+    data, _, st = _run_task(ctx, torch, _ffi.K_DICT, 4, idx, width=4, param=4 | (1 << 8), param2=3)
+    assert st == _ffi.ST_DICT_INDEX and data.view(np.uint32).tolist() == [0, 3, 2, 3]
+    with pytest.raises(da.MiError, match="dictionary index out of range"):
+        _ffi.check(_ffi.lib().mi_status_to_error(st))
     # decimal that does not fit its declared physical type
     dec = np.array([5, 0, 2**40, 0], np.int64)
     _, _, st = _run_task(ctx, torch, _ffi.K_DEC128, 2, dec, width=4, param=4)
