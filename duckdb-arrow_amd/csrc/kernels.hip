@@ -86,11 +86,12 @@ __device__ __forceinline__ bool tile_needs_mask(const mi_col_task& t) {
   return (t.validity != nullptr && t.null_count != 0) || t.out_aux != nullptr;
 }
 
+template <int T = kBlockThreads>  // threads of the workgroup that owns the tile
 __device__ __forceinline__ void tile_validity(const mi_col_task& t, int64_t row0, int n, uint64_t* s_valid = nullptr) {
   const bool need_mask = s_valid != nullptr && tile_needs_mask(t);
   if (t.out_validity == nullptr && !need_mask) return;
   const int nwords = (n + 63) >> 6;
-  for (int lane = threadIdx.x; lane < nwords; lane += kBlockThreads) {
+  for (int lane = threadIdx.x; lane < nwords; lane += T) {
     uint64_t w = ~0ull;
     if (t.validity != nullptr && t.null_count != 0) {
       gptr<const uint64_t> W = GC<uint64_t>(t.validity);
@@ -426,53 +427,57 @@ __global__ __launch_bounds__(kBlockThreads) void transcode_string(const mi_col_t
 // ---------------------------------------------------------------------------------------------------- K2
 // Bit-packed bool -> one byte per row, all rows (valid or not).  Lane i expands rows [8i, 8i+8) = one source byte
 // (two when the bit offset is not byte aligned) into one 8-byte store.
+template <int T = kBlockThreads>
 __device__ __forceinline__ void tile_bool(const mi_col_task& t, int64_t row0, int n) {
   gptr<const uint8_t> bits = GC<uint8_t>(t.buf1);
   gptr<uint8_t> out = GM<uint8_t>(t.out_data) + row0;
-  const int r = 8 * threadIdx.x;
-  if (r >= n) return;
-  const int64_t bit = t.row_offset + row0 + r;
-  const int64_t byte = bit >> 3;
-  const int sh = static_cast<int>(bit & 7);
   const int64_t last_byte = (t.row_offset + t.nrows - 1) >> 3;
-  uint32_t b = bits[byte];
-  if (sh != 0 && byte + 1 <= last_byte) b |= static_cast<uint32_t>(bits[byte + 1]) << 8;
-  b = (b >> sh) & 0xFFu;
-  uint64_t y = (static_cast<uint64_t>(b) * 0x0101010101010101ull) & 0x8040201008040201ull;
-  y = ((y + 0x7F7F7F7F7F7F7F7Full) >> 7) & 0x0101010101010101ull;
-  if (r + 8 <= n) {
-    *(gptr<uint64_t>)(out + r) = y;
-  } else {
-    for (int k = 0; r + k < n; k++) out[r + k] = static_cast<uint8_t>(y >> (8 * k));
+  for (int r = 8 * threadIdx.x; r < n; r += 8 * T) {  // 8 rows per lane and pass: one byte (two when unaligned) -> 8 bytes
+    const int64_t bit = t.row_offset + row0 + r;
+    const int64_t byte = bit >> 3;
+    const int sh = static_cast<int>(bit & 7);
+    uint32_t b = bits[byte];
+    if (sh != 0 && byte + 1 <= last_byte) b |= static_cast<uint32_t>(bits[byte + 1]) << 8;
+    b = (b >> sh) & 0xFFu;
+    uint64_t y = (static_cast<uint64_t>(b) * 0x0101010101010101ull) & 0x8040201008040201ull;
+    y = ((y + 0x7F7F7F7F7F7F7F7Full) >> 7) & 0x0101010101010101ull;
+    if (r + 8 <= n) {
+      *(gptr<uint64_t>)(out + r) = y;
+    } else {
+      for (int k = 0; r + k < n; k++) out[r + k] = static_cast<uint8_t>(y >> (8 * k));
+    }
   }
 }
 
 // ---------------------------------------------------------------------------------------------------- K3c
+template <int T = kBlockThreads>
 __device__ __forceinline__ void tile_date64(const mi_col_task& t, int64_t row0, int n) {
   gptr<const int64_t> src = GC<int64_t>(t.buf1) + t.row_offset + row0;
   gptr<int32_t> out = GM<int32_t>(t.out_data) + row0;
 #pragma unroll 2  // 64-bit division by a constant is register hungry; 4 copies cost the class one occupancy step
-  for (int r = threadIdx.x; r < n; r += kBlockThreads) out[r] = static_cast<int32_t>(src[r] / 86400000ll);
+  for (int r = threadIdx.x; r < n; r += T) out[r] = static_cast<int32_t>(src[r] / 86400000ll);
 }
 
+template <int T = kBlockThreads>
 __device__ __forceinline__ void tile_mul_i32(const mi_col_task& t, int64_t row0, int n, const uint64_t* s_valid) {
   gptr<const int32_t> src = GC<int32_t>(t.buf1) + t.row_offset + row0;
   gptr<int64_t> out = GM<int64_t>(t.out_data) + row0;
   const bool has_nulls = tile_needs_mask(t);
 #pragma unroll 4
-  for (int r = threadIdx.x; r < n; r += kBlockThreads) {
+  for (int r = threadIdx.x; r < n; r += T) {
     const bool ok = row_valid(s_valid, has_nulls, r);
     out[r] = ok ? static_cast<int64_t>(src[r]) * t.param : 0;  // int32 * 1e6 cannot overflow int64
   }
 }
 
+template <int T = kBlockThreads>
 __device__ __forceinline__ void tile_mul_i64(const mi_col_task& t, int64_t row0, int n, uint32_t* status, const uint64_t* s_valid) {
   gptr<const int64_t> src = GC<int64_t>(t.buf1) + t.row_offset + row0;
   gptr<int64_t> out = GM<int64_t>(t.out_data) + row0;
   const bool has_nulls = tile_needs_mask(t);
   uint32_t err = 0;
 #pragma unroll 4
-  for (int r = threadIdx.x; r < n; r += kBlockThreads) {
+  for (int r = threadIdx.x; r < n; r += T) {
     int64_t v = 0;
     if (row_valid(s_valid, has_nulls, r)) {
       if (__builtin_mul_overflow(src[r], t.param, &v)) {  // TryMultiplyOperator => ConversionException
@@ -485,6 +490,7 @@ __device__ __forceinline__ void tile_mul_i64(const mi_col_task& t, int64_t row0,
   raise(status, err);
 }
 
+template <int T = kBlockThreads>
 __device__ __forceinline__ void tile_div_i64(const mi_col_task& t, int64_t row0, int n) {
   gptr<const int64_t> src = GC<int64_t>(t.buf1) + t.row_offset + row0;
   gptr<int64_t> out = GM<int64_t>(t.out_data) + row0;
@@ -493,11 +499,11 @@ __device__ __forceinline__ void tile_div_i64(const mi_col_task& t, int64_t row0,
   // the generic 64-bit division (~100 instructions, dozens of registers) stays out of the unrolled loops
   if (d == 1000) {
 #pragma unroll 4
-    for (int r = threadIdx.x; r < n; r += kBlockThreads) out[r] = src[r] / 1000;  // all rows, like upstream
+    for (int r = threadIdx.x; r < n; r += T) out[r] = src[r] / 1000;  // all rows, like upstream
     return;
   }
 #pragma unroll 1
-  for (int r = threadIdx.x; r < n; r += kBlockThreads) out[r] = src[r] / d;
+  for (int r = threadIdx.x; r < n; r += T) out[r] = src[r] / d;
 }
 
 __device__ __forceinline__ void tile_duration(const mi_col_task& t, int64_t row0, int n, uint32_t* status, const uint64_t* s_valid) {
@@ -674,6 +680,7 @@ __device__ __forceinline__ void tile_strview(const mi_col_task& t, int64_t row0,
 
 // ---------------------------------------------------------------------------------------------------- K5
 // Dictionary indices -> sel_t; NULL -> dict_len (the extra NULL slot of the decoded dictionary).
+template <int T = kBlockThreads>
 __device__ __forceinline__ void tile_dict(const mi_col_task& t, int64_t row0, int n, uint32_t* status, const uint64_t* s_valid) {
   const int iw = static_cast<int>(t.param & 0xFF);
   const bool is_signed = ((t.param >> 8) & 1) != 0;
@@ -683,7 +690,7 @@ __device__ __forceinline__ void tile_dict(const mi_col_task& t, int64_t row0, in
   const uint32_t dict_len = static_cast<uint32_t>(t.param2);
   uint32_t err = 0;
 #pragma unroll 4
-  for (int r = threadIdx.x; r < n; r += kBlockThreads) {
+  for (int r = threadIdx.x; r < n; r += T) {
     uint32_t sel = dict_len;
     if (row_valid(s_valid, has_nulls, r)) {
       uint64_t v;
@@ -707,6 +714,34 @@ __device__ __forceinline__ void tile_dict(const mi_col_task& t, int64_t row0, in
     out[r] = sel;
   }
   raise(status, err);
+}
+
+// The common flat kinds (GROUP 0 of transcode_misc) move 2-16 KB per tile: with 256-thread workgroups a CU holds 8 such
+// tiles and each is one chain of dependent round trips (task lookup, bitmap, data), which left the kernel latency bound
+// (1.8-2.3 TB/s).  Here ONE WAVE owns a tile (32 rows per lane): 32 independent tiles per CU, no workgroup barriers.
+constexpr int kLightThreads = 64;
+__global__ __launch_bounds__(kLightThreads) void transcode_misc_light(const mi_col_task* __restrict__ tasks,
+                                                                      const uint32_t* __restrict__ tile_begin,
+                                                                      const uint32_t* __restrict__ tile_task, int n_tasks,
+                                                                      uint32_t total_tiles, uint32_t* __restrict__ status) {
+  __shared__ uint64_t s_valid[kTileRows / 64];
+  for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    MI_TILE_PROLOGUE();
+    const bool mine = t.kind == MI_K_BOOL || t.kind == MI_K_DICT || t.kind == MI_K_DATE64 || t.kind == MI_K_MUL_I32 ||
+                      t.kind == MI_K_MUL_I64 || t.kind == MI_K_DIV_I64;
+    if (!mine) continue;  // uniform: another group's launch owns this tile
+    if (tile_needs_mask(t)) __syncthreads();
+    tile_validity<kLightThreads>(t, row0, n, s_valid);
+    switch (t.kind) {
+      case MI_K_BOOL: tile_bool<kLightThreads>(t, row0, n); break;
+      case MI_K_DATE64: tile_date64<kLightThreads>(t, row0, n); break;
+      case MI_K_MUL_I32: tile_mul_i32<kLightThreads>(t, row0, n, s_valid); break;
+      case MI_K_MUL_I64: tile_mul_i64<kLightThreads>(t, row0, n, status, s_valid); break;
+      case MI_K_DIV_I64: tile_div_i64<kLightThreads>(t, row0, n); break;
+      case MI_K_DICT: tile_dict<kLightThreads>(t, row0, n, status, s_valid); break;
+      default: break;
+    }
+  }
 }
 
 // GROUP 0: the common flat kinds (bool, dictionary indices, date64, timestamp unit casts) -- small per-row work whose
@@ -1434,6 +1469,7 @@ struct Tune {
   int string_variant = 2;  // 1: 8 rows per lane in flight; 2: + nontemporal stores
   int blocks_per_cu = 0;   // 0: one workgroup per tile (the hardware dispatcher balances the tiles)
   int use_tile_table = 1;
+  int misc_light = 1;          // 1: one wave per tile for the common flat kinds (transcode_misc_light)
   int enc_string_variant = 1;  // 1: encode_string_v5 (batched heap loads, dword LDS assembly, windows); 0: encode_string
 };
 static Tune& TuneRef() {
@@ -1446,6 +1482,7 @@ static Tune& TuneRef() {
     x.blocks_per_cu = env("MI_TUNE_GRID", x.blocks_per_cu);
     x.use_tile_table = env("MI_TUNE_TILE_TABLE", x.use_tile_table);
     x.enc_string_variant = env("MI_TUNE_ENC_STRING", x.enc_string_variant);
+    x.misc_light = env("MI_TUNE_MISC_LIGHT", x.misc_light);
     return x;
   }();
   return t;
@@ -1459,6 +1496,7 @@ bool SetTune(const char* knob, int value) {
   else if (k == "grid") t.blocks_per_cu = value;
   else if (k == "tile_table") t.use_tile_table = value;
   else if (k == "enc_string") t.enc_string_variant = value;
+  else if (k == "misc_light") t.misc_light = value;
   else return false;
   return true;
 }
@@ -1489,7 +1527,12 @@ hipError_t LaunchTranscode(int cls, const mi_col_task* d_tasks, const uint32_t* 
       else MI_LAUNCH(transcode_string<0>);
       break;
     case kClassMisc:
-      if (misc_groups & 1u) MI_LAUNCH(transcode_misc<0>);
+      if (misc_groups & 1u) {
+        if (tune.misc_light)
+          hipLaunchKernelGGL(transcode_misc_light, grid, dim3(kLightThreads), 0, stream, d_tasks, d_tile_begin, tt, n_tasks, total_tiles, d_status);
+        else
+          MI_LAUNCH(transcode_misc<0>);
+      }
       if (misc_groups & 2u) MI_LAUNCH(transcode_misc<1>);
       if (misc_groups & 4u) MI_LAUNCH(transcode_misc<2>);
       break;
