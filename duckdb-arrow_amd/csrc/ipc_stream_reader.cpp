@@ -546,6 +546,21 @@ void IPCStreamReader::SliceBatch(const RecordBatchMeta& meta, DecodedBatch* out)
     const int64_t nulls = meta.nodes[cur.node].second;
     cur.node++;
     if (n < 0) throw InternalException("Field node length is negative");
+    // lengths come from the file: bound them before anything is multiplied by them (ArrowArrayViewValidate checks the
+    // same relations), so a damaged RecordBatch cannot overflow a size computation and slip past the buffer checks
+    if (n > (int64_t(1) << 40)) throw InternalException("Field node length " + std::to_string(n) + " is implausible");
+    if (nulls < -1 || nulls > n) throw InternalException("Field node null_count " + std::to_string(nulls) + " is outside [0, length]");
+    if (depth == 0 && !value_only && n != meta.length)
+      throw InternalException("Expected array length " + std::to_string(meta.length) + " for column " + f.name + " but found " + std::to_string(n));
+    if (keep && parent >= 0) {
+      const DecodedNode& pn = out->nodes[static_cast<size_t>(parent)];
+      const int32_t pt = pn.field->type;
+      if (pt == MI_AT_STRUCT && n != pn.length)
+        throw InternalException("Struct child " + f.name + " has length " + std::to_string(n) + ", its parent " + std::to_string(pn.length));
+      if (pt == MI_AT_FIXED_LIST && n != pn.length * pn.field->byte_width)
+        throw InternalException("Fixed-size list child " + f.name + " has length " + std::to_string(n) + ", expected " +
+                                std::to_string(pn.length * pn.field->byte_width));
+    }
     const bool dict = f.has_dictionary && !value_only;
     size_t own;
     if (dict) {
