@@ -25,6 +25,17 @@ static int Drain(const std::vector<uint8_t>& buf, bool project, std::mt19937_64&
     bufs.push_back(ArrowIPCBuffer{reinterpret_cast<uint64_t>(buf.data()), static_cast<uint64_t>(buf.size())});
     IPCBufferStreamReader rd(bufs);
     const ArrowSchemaModel& schema = rd.GetBaseSchema();
+    {  // the flatbuffer builder under the sanitizers too: re-encode the schema, read it back, same top-level shape
+      const std::vector<uint8_t> msg = EncodeSchemaMessage(schema);
+      std::vector<ArrowIPCBuffer> again;
+      again.push_back(ArrowIPCBuffer{reinterpret_cast<uint64_t>(msg.data()), static_cast<uint64_t>(msg.size())});
+      IPCBufferStreamReader rd2(again);
+      if (rd2.GetBaseSchema().fields.size() != schema.fields.size()) std::abort();
+      std::vector<std::pair<int64_t, int64_t>> nodes(3, {5, 1});
+      std::vector<mi_buffer_span> spans(7, mi_buffer_span{64, 8});
+      const std::vector<uint8_t> rb = EncodeRecordBatchMessage(5, nodes, spans, 4096);
+      if (rb.size() < 16) std::abort();
+    }
     if (project && !schema.fields.empty()) {
       std::vector<std::string> names;
       for (auto& f : schema.fields)
