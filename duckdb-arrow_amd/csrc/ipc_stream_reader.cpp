@@ -780,6 +780,9 @@ MessageType IPCFileStreamReader::ReadNextMessage() {
 }
 
 bool IPCFileStreamReader::DecodeHeader(const idx_t message_header_size) {
+  // sizes come from the file: nothing is allocated for bytes the file cannot hold (BufferedFileReader::ReadData's
+  // "not enough data in file to deserialize result")
+  if (offset + static_cast<int64_t>(message_prefix.metadata_size) > file_size) throw SerializationException();
   if (message_header.size() < message_header_size) message_header.resize(message_header_size);
   std::memcpy(message_header.data(), &message_prefix, sizeof(message_prefix));
   ReadData(message_header.data() + sizeof(message_prefix), static_cast<idx_t>(message_prefix.metadata_size));
@@ -797,8 +800,8 @@ void IPCFileStreamReader::DecodeBody() {
   if (message.body_length > 0) {
     EnsureInputStreamAligned();
     cur_body_offset = offset;
+    if (message.body_length > file_size - offset) throw SerializationException();  // before anything is allocated for it
     if (skip_record_batch_body && message.type == MessageType::RECORD_BATCH) {
-      if (offset + message.body_length > file_size) throw SerializationException();
       offset += message.body_length;  // step over the body without reading it
       return;
     }

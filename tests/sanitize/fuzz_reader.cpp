@@ -59,6 +59,40 @@ static int Drain(const std::vector<uint8_t>& buf, bool project, std::mt19937_64&
   return batches;
 }
 
+// the file reader: footer index (IPC file format), header walk, partial projected preads, Seek
+static int DrainFile(const std::vector<uint8_t>& buf, const std::string& tmp, bool project, std::mt19937_64& rng) {
+  {
+    std::ofstream out(tmp, std::ios::binary | std::ios::trunc);
+    out.write(reinterpret_cast<const char*>(buf.data()), static_cast<std::streamsize>(buf.size()));
+  }
+  int batches = 0;
+  try {
+    IPCFileStreamReader rd(tmp);
+    const ArrowSchemaModel& schema = rd.GetBaseSchema();
+    const auto& index = rd.BuildIndex();
+    if (project && !schema.fields.empty()) {
+      std::vector<std::string> names;
+      for (auto& f : schema.fields)
+        if (rng() % 2) names.push_back(f.name);
+      if (names.empty()) names.push_back(schema.fields[0].name);
+      rd.SetColumnProjection(names);
+    }
+    if (!index.empty() && rng() % 2) rd.Seek(index[rng() % index.size()].prefix_offset);
+    DecodedBatch b;
+    while (batches < 64 && rd.GetNextBatch(&b, true, /*skip_body*/ rng() % 5 == 0)) {
+      batches++;
+      uint64_t sum = 0;
+      for (auto& nd : b.nodes)
+        for (auto& sp : nd.spans)
+          for (int64_t i = 0; i < sp.length; i += 61) sum += b.body[sp.offset + i];
+      (void)sum;
+    }
+  } catch (const std::exception&) {
+    return -1;
+  }
+  return batches;
+}
+
 int main(int argc, char** argv) {
   if (argc < 3) {
     std::fprintf(stderr, "usage: %s iterations file...\n", argv[0]);
@@ -92,7 +126,11 @@ int main(int argc, char** argv) {
           for (int k = 0; k < 8; k++) buf[rng() % buf.size()] = static_cast<uint8_t>(rng());
           break;
       }
-      const int r = Drain(buf, (it / 4) % 2 == 1, rng);
+      int r = Drain(buf, (it / 4) % 2 == 1, rng);
+      if (it % 3 == 0) {
+        const char* dir = std::getenv("TMPDIR");
+        r = DrainFile(buf, std::string(dir ? dir : "/tmp") + "/mi_fuzz_reader.bin", (it / 3) % 2 == 1, rng);
+      }
       if (r < 0) errors++; else clean++;
     }
   }
