@@ -56,7 +56,7 @@ struct SerializationException : std::runtime_error {
 
 std::shared_ptr<void> DefaultBodyAlloc(size_t bytes, MessageType, uint8_t** ptr) {
   void* p = nullptr;
-  if (posix_memalign(&p, 256, bytes ? bytes : 8) != 0) throw std::bad_alloc();
+  if (posix_memalign(&p, 256, bytes ? bytes : 8) != 0 || p == nullptr) throw std::bad_alloc();
   *ptr = static_cast<uint8_t*>(p);
   return std::shared_ptr<void>(p, [](void* q) { std::free(q); });
 }
@@ -293,6 +293,7 @@ struct ZstdApi {
   size_t (*decompress)(void*, size_t, const void*, size_t) = nullptr;
   unsigned (*is_error)(size_t) = nullptr;
   const char* (*error_name)(size_t) = nullptr;
+  unsigned long long (*frame_content_size)(const void*, size_t) = nullptr;  // optional
   bool ok = false;
 };
 const ZstdApi& Zstd() {
@@ -304,6 +305,7 @@ const ZstdApi& Zstd() {
       a.decompress = reinterpret_cast<size_t (*)(void*, size_t, const void*, size_t)>(dlsym(h, "ZSTD_decompress"));
       a.is_error = reinterpret_cast<unsigned (*)(size_t)>(dlsym(h, "ZSTD_isError"));
       a.error_name = reinterpret_cast<const char* (*)(size_t)>(dlsym(h, "ZSTD_getErrorName"));
+      a.frame_content_size = reinterpret_cast<unsigned long long (*)(const void*, size_t)>(dlsym(h, "ZSTD_getFrameContentSize"));
       a.ok = a.decompress && a.is_error && a.error_name;
     }
     return a;
@@ -386,12 +388,19 @@ void IPCStreamReader::DecompressBody(RecordBatchMeta* meta) {
     if (b.length == 0) continue;
     if (b.offset < 0 || b.length < 8 || b.offset + b.length > cur_size)
       throw InternalException("Compressed buffer " + std::to_string(i) + " lies outside the message body");
-    int64_t n;
-    std::memcpy(&n, cur_ptr + b.offset, 8);
-    if (n == -1) n = b.length - 8;
+    int64_t declared;
+    std::memcpy(&declared, cur_ptr + b.offset, 8);
+    const int64_t n = declared == -1 ? b.length - 8 : declared;
     if (n < 0) throw IOException("Compressed buffer " + std::to_string(i) + " declares a negative uncompressed length");
     if (n > (int64_t(1) << 40) || total > (int64_t(1) << 41))
       throw IOException("Compressed buffer " + std::to_string(i) + " declares an implausible uncompressed length of " + std::to_string(n) + " bytes");
+    if (!lz4 && declared != -1 && z.frame_content_size) {
+      // the ZSTD frame header carries the content size too: a length prefix that disagrees with it is rejected before
+      // anything is allocated for it (the reference finds out after decompressing: base_stream_reader.cpp:24-29)
+      const unsigned long long fcs = z.frame_content_size(cur_ptr + b.offset + 8, static_cast<size_t>(b.length - 8));
+      if (fcs < 0xFFFFFFFFFFFFFFFEull && fcs != static_cast<unsigned long long>(n))
+        throw IOException("Expected decompressed size of " + std::to_string(n) + " bytes but got " + std::to_string(fcs) + " bytes");
+    }
     ulen[i] = n;
     total += (n + 63) & ~static_cast<int64_t>(63);
   }

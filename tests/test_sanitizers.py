@@ -25,7 +25,22 @@ def test_host_reader_is_clean_under_asan_and_ubsan(tmp_path, golden_dir):
     assert build.returncode == 0, build.stderr[-2000:]
     files = [os.path.join(golden_dir, f) for f in ("edge_nested.arrows", "ref_data/test.arrows", "edge_dict.arrows",
                                                    "edge_file_format.arrow", "edge_types2.arrows", "edge_empty.arrows")]
+    # + ZSTD / LZ4 bodies, stream and file format (written here by pyarrow)
+    import numpy as np
+    import pyarrow as pa
+    import pyarrow.ipc as ipc
+    rng = np.random.default_rng(5)
+    t = pa.table({"a": rng.integers(0, 50, 12000), "s": ["row %d" % (i % 97) for i in range(12000)],
+                  "l": pa.array([[int(x) for x in rng.integers(0, 9, int(rng.integers(0, 4)))] for _ in range(12000)], pa.list_(pa.int32()))})
+    for codec in ("zstd", "lz4"):
+        p1, p2 = str(tmp_path / ("c_%s.arrows" % codec)), str(tmp_path / ("c_%s.arrow" % codec))
+        with ipc.new_stream(p1, t.schema, options=ipc.IpcWriteOptions(compression=codec)) as w:
+            w.write_table(t, max_chunksize=5000)
+        with ipc.new_file(p2, t.schema, options=ipc.IpcWriteOptions(compression=codec)) as w:
+            w.write_table(t, max_chunksize=5000)
+        files += [p1, p2]
     run = subprocess.run([exe, os.environ.get("MI_SANITIZE_ITERS", "400")] + files, capture_output=True, text=True,
-                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", MI_IO_THREADS="2"))
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:allocator_may_return_null=1", MI_IO_THREADS="2",
+                                  TMPDIR=str(tmp_path)))
     assert run.returncode == 0, (run.stdout[-1000:], run.stderr[-3000:])
     assert "no sanitizer report" in run.stdout and "runtime error" not in run.stderr and "AddressSanitizer" not in run.stderr
