@@ -434,3 +434,70 @@ def test_arrow_large_buffer_size_exports_int64_offsets(con, tmp_path):
     # and the scan reads its own large output back (int64 offsets -> K4b / LIST64)
     back = con.read_arrow(path).project(["s", "l", "b"]).fetch_columns()
     assert back[0] == cols[6] and back[1] == cols[0] and back[2] == blobs
+
+
+def test_sink_string_staging_modes_mix(con, tmp_path):
+    """The sink stages long-string payloads as one growing run while chunks lay them out back to back, and gathers them
+    string by string when they do not (shuffled pointers, a second heap); a row group that mixes both must still come out
+    right.  Chunks are built by hand: string_t rows pointing into numpy heaps."""
+    import ctypes as C
+    rng = np.random.default_rng(21)
+    L = _ffi.lib()
+    o = _ffi.WriteOptions()
+    _ffi.check(L.mi_write_options_init(C.byref(o)))
+    _ffi.check(L.mi_write_options_set(C.byref(o), b"row_group_size", b"100000"))
+    _ffi.check(L.mi_write_options_finalize(C.byref(o)))
+    fields = (_ffi.Field * 1)()
+    fields[0].name, fields[0].duck_type = b"s", b"VARCHAR"
+    path = str(tmp_path / "mix.arrows")
+    w = C.c_void_p()
+    _ffi.check(L.mi_writer_open(con.ctx._h, path.encode(), fields, 1, C.byref(o), C.byref(w)))
+    keep, want = [], []
+
+    def sink(strings, order):
+        """strings laid out in one heap in `order`; rows keep their original order"""
+        n = len(strings)
+        enc = [None if s is None else s.encode() for s in strings]
+        heap = np.zeros(sum(len(e) for e in enc if e is not None) + 64, np.uint8)
+        at, pos = {}, 0
+        for i in order:
+            if enc[i] is not None:
+                heap[pos: pos + len(enc[i])] = np.frombuffer(enc[i], np.uint8)
+                at[i] = pos
+                pos += len(enc[i])
+        data = np.zeros((n, 16), np.uint8)
+        ok = np.ones(n, bool)
+        for i, e in enumerate(enc):
+            if e is None:
+                ok[i] = False
+                data[i, :] = 0xAB          # garbage in a NULL row must not matter
+                continue
+            data[i, :4] = np.frombuffer(np.uint32(len(e)).tobytes(), np.uint8)
+            if len(e) <= 12:
+                data[i, 4: 4 + len(e)] = np.frombuffer(e, np.uint8)
+            else:
+                data[i, 4:8] = np.frombuffer(e[:4], np.uint8)
+                data[i, 8:] = np.frombuffer(np.uint64(heap.ctypes.data + at[i]).tobytes(), np.uint8)
+        valid = np.packbits(np.concatenate([ok, np.ones((-n) % 64, bool)]), bitorder="little").view(np.uint64).copy()
+        vec = (_ffi.Vector * 1)()
+        vec[0].data, vec[0].validity, vec[0].count = data.ctypes.data, valid.ctypes.data, n
+        ch = _ffi.DataChunk(size=n, n_columns=1, columns=vec)
+        keep.extend([heap, data, valid, vec])
+        _ffi.check(L.mi_writer_sink(w, C.byref(ch)))
+        want.extend(strings)
+
+    def strings(n):
+        return [None if rng.random() < 0.1 else "x" * int(rng.integers(0, 40)) + str(i) for i in range(n)]
+
+    for rep in range(3):
+        s1 = strings(2048)
+        sink(s1, range(2048))                              # back to back: starts / continues a run
+        s2 = strings(1500)
+        sink(s2, list(rng.permutation(1500)))              # shuffled inside its heap: gathered
+        s3 = strings(2048)
+        sink(s3, range(2048))                              # ordered again, but the run is closed for this row group
+        sink(["short"] * 100, range(100))                  # inline only
+    _ffi.check(L.mi_writer_finalize(w))
+    L.mi_writer_close(w)
+    got = ipc.open_stream(path).read_all().column("s").to_pylist()
+    assert got == want
