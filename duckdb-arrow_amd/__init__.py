@@ -136,6 +136,15 @@ class Reader:
                                        for j in range(b.nodes[i].first_span, b.nodes[i].first_span + b.nodes[i].n_spans)])
                            for i in range(b.n_nodes)])
 
+    def export_stream(self, accept_dictionaries=False):
+        """The reader (with its projection) as an Arrow C stream (mi_reader_export_stream), imported into pyarrow: what
+        DuckDB's arrow scan would consume in place of the reference's IpcArrayStream.  The reader is consumed."""
+        import pyarrow as pa
+        stream = _ffi.ArrowArrayStream()
+        _ffi.check(_ffi.lib().mi_reader_export_stream(self._h, 1 if accept_dictionaries else 0, C.byref(stream)))
+        self._keep.append(stream)
+        return pa.RecordBatchReader._import_from_c(C.addressof(stream))
+
     def index(self):
         ent = C.POINTER(_ffi.BatchIndexEntry)()
         n = C.c_int32(0)

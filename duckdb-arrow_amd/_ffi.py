@@ -82,6 +82,11 @@ class SumProductResult(C.Structure):
     _fields_ = [("sum_lo", C.c_uint64), ("sum_hi", C.c_int64), ("rows_scanned", C.c_int64), ("rows_selected", C.c_int64)]
 
 
+class ArrowArrayStream(C.Structure):   # Arrow C stream interface: 4 callbacks + private_data
+    _fields_ = [("get_schema", C.c_void_p), ("get_next", C.c_void_p), ("get_last_error", C.c_void_p),
+                ("release", C.c_void_p), ("private_data", C.c_void_p)]
+
+
 class Vector(C.Structure):
     pass
 
@@ -148,6 +153,7 @@ SIGNATURES = {
     "mi_plan_null_counts": (C.c_int, [P, C.POINTER(C.c_int64), C.c_int32]),
     "mi_status_to_error": (C.c_int, [C.c_uint32]),
     "mi_filter_range": (C.c_int, [P, P, C.c_int32, P, C.c_int64, C.c_int64, C.c_int64, P, P, P]),
+    "mi_reader_export_stream": (C.c_int, [P, C.c_int32, C.POINTER(ArrowArrayStream)]),
     "mi_scan_open_files": (C.c_int, [P, C.POINTER(C.c_char_p), C.c_int32, C.POINTER(ScanOptions), PP]),
     "mi_scan_open_buffers": (C.c_int, [P, C.POINTER(IpcBuffer), C.c_int32, C.POINTER(ScanOptions), PP]),
     "mi_scan_close": (None, [P]),

@@ -49,6 +49,10 @@ struct mi_reader {
 struct mi_ctx {
   std::unique_ptr<Context> ctx;
 };
+namespace miarrow {
+// the reader moves into an exported Arrow C stream (c_stream.cpp); the handle stays valid for mi_reader_close only
+std::unique_ptr<IPCStreamReader> TakeReader(mi_reader* r) { return std::move(r->reader); }
+}  // namespace miarrow
 struct mi_plan {
   std::unique_ptr<Plan> plan;
 };

@@ -210,6 +210,50 @@ typedef struct mi_batch_index_entry { int64_t prefix_offset; int32_t meta_len; i
                                       int64_t body_len; int64_t n_rows; } mi_batch_index_entry;
 int mi_reader_index(mi_reader* r, const mi_batch_index_entry** entries, int32_t* n);
 
+/* The reader as an Arrow C stream -- the narrowest seam of the reference: IpcArrayStream::{GetSchema, GetNext, Wrap}
+ * (src/ipc/array_stream.cpp:11-26, src/include/ipc/array_stream.hpp:29-48) behind ArrowIPCStreamFactory::Produce
+ * (src/ipc/stream_factory.cpp:14-30), i.e. what DuckDB's own arrow scan consumes.  The reader (with its projection) moves
+ * into the stream: afterwards `r` only accepts mi_reader_close.  Arrays are zero-copy views of the message bodies, each
+ * keeps its body alive until released; get_next errors are EIO / ENOTSUP / ENOMEM + get_last_error, like the reference.
+ * Host only.  The structs are the Arrow C data / stream interface (apache/arrow: format/CDataInterface.rst). */
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+struct ArrowSchema {
+  const char* format;
+  const char* name;
+  const char* metadata;
+  int64_t flags;
+  int64_t n_children;
+  struct ArrowSchema** children;
+  struct ArrowSchema* dictionary;
+  void (*release)(struct ArrowSchema*);
+  void* private_data;
+};
+struct ArrowArray {
+  int64_t length;
+  int64_t null_count;
+  int64_t offset;
+  int64_t n_buffers;
+  int64_t n_children;
+  const void** buffers;
+  struct ArrowArray** children;
+  struct ArrowArray* dictionary;
+  void (*release)(struct ArrowArray*);
+  void* private_data;
+};
+#endif
+#ifndef ARROW_C_STREAM_INTERFACE
+#define ARROW_C_STREAM_INTERFACE
+struct ArrowArrayStream {
+  int (*get_schema)(struct ArrowArrayStream*, struct ArrowSchema* out);
+  int (*get_next)(struct ArrowArrayStream*, struct ArrowArray* out);
+  const char* (*get_last_error)(struct ArrowArrayStream*);
+  void (*release)(struct ArrowArrayStream*);
+  void* private_data;
+};
+#endif
+int mi_reader_export_stream(mi_reader* r, int32_t accept_dictionaries, struct ArrowArrayStream* out);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Device context + transcode plans.  Replace the per-value loops of DuckDB core that the reference calls:
  * ArrowTableFunction::ArrowScanFunction -> ArrowToDuckDB (call sites src/scanner/scan_arrow_ipc.cpp:56,
