@@ -53,6 +53,10 @@ namespace miarrow {
 // the reader moves into an exported Arrow C stream (c_stream.cpp); the handle stays valid for mi_reader_close only
 std::unique_ptr<IPCStreamReader> TakeReader(mi_reader* r) { return std::move(r->reader); }
 }  // namespace miarrow
+static IPCStreamReader& Live(mi_reader* r) {
+  if (!r || !r->reader) throw InvalidInputException("the reader was exported as an Arrow C stream (or is NULL): only mi_reader_close is valid");
+  return *r->reader;
+}
 struct mi_plan {
   std::unique_ptr<Plan> plan;
 };
@@ -91,7 +95,7 @@ void mi_reader_close(mi_reader* r) { delete r; }
 int mi_reader_schema(mi_reader* r, mi_field* fields, int32_t cap, int32_t* n_fields) {
   return Wrap([&] {
     if (!r || !n_fields) throw InvalidInputException("mi_reader_schema: NULL argument");
-    const ArrowSchemaModel& s = r->reader->GetBaseSchema();
+    const ArrowSchemaModel& s = Live(r).GetBaseSchema();
     *n_fields = static_cast<int32_t>(s.fields.size());
     int64_t flat = 0;
     for (size_t i = 0; i < s.fields.size(); i++) {
@@ -105,7 +109,7 @@ int mi_reader_schema_metadata(mi_reader* r, int32_t idx, const char** key, int32
                               int32_t* value_len, int32_t* count) {
   return Wrap([&] {
     if (!r) throw InvalidInputException("mi_reader_schema_metadata: NULL reader");
-    const ArrowSchemaModel& s = r->reader->GetBaseSchema();
+    const ArrowSchemaModel& s = Live(r).GetBaseSchema();
     if (count) *count = static_cast<int32_t>(s.metadata.size());
     if (idx < 0 || static_cast<size_t>(idx) >= s.metadata.size()) {
       if (key || value) throw InvalidInputException("schema metadata index out of range");
@@ -123,7 +127,7 @@ int mi_reader_set_projection(mi_reader* r, const char* const* names, int32_t n) 
     if (!r) throw InvalidInputException("mi_reader_set_projection: NULL reader");
     std::vector<std::string> v;
     for (int32_t i = 0; i < n; i++) v.emplace_back(names[i]);
-    r->reader->SetColumnProjection(v);
+    Live(r).SetColumnProjection(v);
   });
 }
 
@@ -131,7 +135,7 @@ int mi_reader_next_batch(mi_reader* r, int32_t accept_dictionaries, mi_batch* ou
   bool got = false;
   int rc = Wrap([&] {
     if (!r || !out) throw InvalidInputException("mi_reader_next_batch: NULL argument");
-    got = r->reader->GetNextBatch(&r->batch, accept_dictionaries != 0);
+    got = Live(r).GetNextBatch(&r->batch, accept_dictionaries != 0);
     if (!got) return;
     const DecodedBatch& b = r->batch;
     out->length = b.length;
@@ -179,12 +183,12 @@ int mi_reader_next_batch(mi_reader* r, int32_t accept_dictionaries, mi_batch* ou
   return got ? MI_OK : MI_ENODATA;
 }
 
-double mi_reader_progress(mi_reader* r) { return r ? r->reader->GetProgress() : 0; }
+double mi_reader_progress(mi_reader* r) { return (r && r->reader) ? r->reader->GetProgress() : 0; }
 
 int mi_reader_index(mi_reader* r, const mi_batch_index_entry** entries, int32_t* n) {
   return Wrap([&] {
     if (!r || !entries || !n) throw InvalidInputException("mi_reader_index: NULL argument");
-    const auto& idx = r->reader->BuildIndex();
+    const auto& idx = Live(r).BuildIndex();
     r->index.clear();
     for (auto& e : idx) r->index.push_back(mi_batch_index_entry{e.prefix_offset, e.meta_len, e.type, e.body_offset, e.body_len, e.n_rows});
     *entries = r->index.data();

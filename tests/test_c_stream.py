@@ -97,3 +97,8 @@ def test_exported_stream_errors_like_the_reference(golden_dir, tmp_path):
     rd.export_stream().read_all()
     with pytest.raises(da.MiError):
         rd.export_stream()
+    with pytest.raises(da.MiError, match="only mi_reader_close is valid"):
+        rd.schema()
+    with pytest.raises(da.MiError, match="only mi_reader_close is valid"):
+        rd.next_batch()
+    rd.close()
