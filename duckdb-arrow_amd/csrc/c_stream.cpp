@@ -125,8 +125,81 @@ struct DictValues {  // the last DictionaryBatch of an id, kept for the record b
   DecodedBatch batch;
 };
 
+// NANOARROW_VALIDATION_LEVEL_FULL's data-dependent part (base_stream_reader.cpp:112-140), which the GPU path does on the
+// device: a consumer of the C stream trusts offsets, view fields and dictionary indices, so they are walked here once.
+template <typename OFF>
+void CheckOffsets(const DecodedBatch& b, const DecodedNode& nd, int64_t limit, const char* what) {
+  if (nd.length == 0) return;
+  const OFF* off = reinterpret_cast<const OFF*>(b.body + nd.spans[1].offset);
+  int64_t prev = static_cast<int64_t>(off[0]);
+  bool ok = prev >= 0;
+  for (int64_t i = 1; i <= nd.length; i++) {
+    const int64_t v = static_cast<int64_t>(off[i]);
+    ok = ok && v >= prev;
+    prev = v;
+  }
+  if (!ok || prev > limit)
+    throw IOException(std::string("Arrow IPC validation failed: ") + what + " offsets of '" + nd.field->name +
+                      "' are not monotonically non-decreasing or exceed the data buffer");
+}
+
+void ValidateNodeFull(const DecodedBatch& b, const DecodedNode& nd, const std::map<int64_t, std::shared_ptr<DictValues>>& dicts) {
+  int32_t kind, w, nb;
+  int64_t param;
+  if (!nd.field->Plan(&kind, &param, &w, &nb, nd.value_only))
+    throw NotImplementedException("Arrow type " + nd.field->Format() + " of field '" + nd.field->name + "' is not exported by this reader");
+  switch (kind) {
+    case MI_K_STR32: CheckOffsets<int32_t>(b, nd, nd.spans[2].length, "string"); break;
+    case MI_K_STR64: CheckOffsets<int64_t>(b, nd, nd.spans[2].length, "string"); break;
+    case MI_K_LIST32: CheckOffsets<int32_t>(b, nd, b.nodes[static_cast<size_t>(nd.children[0])].length, "list"); break;
+    case MI_K_LIST64: CheckOffsets<int64_t>(b, nd, b.nodes[static_cast<size_t>(nd.children[0])].length, "list"); break;
+    case MI_K_STRVIEW: {
+      const uint8_t* v = b.body + nd.spans[1].offset;
+      const uint64_t* valid = nd.spans[0].length ? reinterpret_cast<const uint64_t*>(b.body + nd.spans[0].offset) : nullptr;
+      const uint8_t* vbytes = reinterpret_cast<const uint8_t*>(valid);
+      for (int64_t i = 0; i < nd.length; i++) {
+        if (vbytes && !((vbytes[i >> 3] >> (i & 7)) & 1)) continue;
+        int32_t len, bi, bo;
+        std::memcpy(&len, v + 16 * i, 4);
+        if (len <= 12 && len >= 0) continue;
+        std::memcpy(&bi, v + 16 * i + 8, 4);
+        std::memcpy(&bo, v + 16 * i + 12, 4);
+        const int64_t nvar = static_cast<int64_t>(nd.spans.size()) - 2;
+        if (len < 0 || bi < 0 || bi >= nvar || bo < 0 || static_cast<int64_t>(bo) + len > nd.spans[static_cast<size_t>(2 + bi)].length)
+          throw IOException("Arrow IPC validation failed: string view " + std::to_string(i) + " of '" + nd.field->name + "' points outside its data buffers");
+      }
+      break;
+    }
+    case MI_K_DICT: {
+      auto it = dicts.find(nd.field->dict_id);
+      if (it == dicts.end()) break;  // reported by the caller
+      const int64_t dict_len = it->second->batch.nodes[static_cast<size_t>(it->second->batch.column_node[0])].length;
+      const int iw = static_cast<int>(param & 0xFF);
+      const bool sgn = ((param >> 8) & 1) != 0;
+      const uint8_t* idx = b.body + nd.spans[1].offset;
+      const uint8_t* vbytes = nd.spans[0].length ? b.body + nd.spans[0].offset : nullptr;
+      for (int64_t i = 0; i < nd.length; i++) {
+        if (vbytes && !((vbytes[i >> 3] >> (i & 7)) & 1)) continue;
+        int64_t v = 0;
+        switch (iw) {
+          case 1: v = sgn ? static_cast<int64_t>(reinterpret_cast<const int8_t*>(idx)[i]) : idx[i]; break;
+          case 2: { int16_t x; std::memcpy(&x, idx + 2 * i, 2); v = sgn ? x : static_cast<uint16_t>(x); break; }
+          case 4: { int32_t x; std::memcpy(&x, idx + 4 * i, 4); v = sgn ? x : static_cast<uint32_t>(x); break; }
+          default: std::memcpy(&v, idx + 8 * i, 8); break;
+        }
+        if (v < 0 || v >= dict_len)
+          throw IOException("Arrow IPC validation failed: dictionary index out of range in '" + nd.field->name + "'");
+      }
+      break;
+    }
+    default: break;
+  }
+}
+
 void ExportNode(const DecodedBatch& b, int32_t ni, const std::map<int64_t, std::shared_ptr<DictValues>>& dicts, ArrowArray* out) {
   const DecodedNode& nd = b.nodes[static_cast<size_t>(ni)];
+  std::memset(out, 0, sizeof(*out));
+  ValidateNodeFull(b, nd, dicts);
   auto* p = new ArrayPrivate();
   std::memset(out, 0, sizeof(*out));
   out->release = ReleaseArray;  // from here on a throw releases what was built

@@ -102,3 +102,38 @@ def test_exported_stream_errors_like_the_reference(golden_dir, tmp_path):
     with pytest.raises(da.MiError, match="only mi_reader_close is valid"):
         rd.next_batch()
     rd.close()
+
+
+@pytest.mark.parametrize("rel", ["edge_nested.arrows", "ref_data/test.arrows", "edge_dict.arrows"])
+def test_exported_stream_of_damaged_bodies_is_rejected_or_valid(golden_dir, rel):
+    """A consumer of the C stream trusts offsets, views and dictionary indices (DuckDB does), so the export walks them like
+    nanoarrow's FULL validation: a damaged body either fails in get_next or imports as arrays pyarrow's own full validation
+    accepts -- never as arrays that point outside their buffers."""
+    from oracle import pyoracle as po
+    src = np.fromfile(os.path.join(golden_dir, rel), np.uint8)
+    bodies = [(m["body_off"], m["body_len"]) for m in po.walk_stream(src) if m["body_len"] > 0]
+    rng = np.random.default_rng(abs(hash(rel)) % 2**32)
+    rejected = accepted = 0
+    for it in range(int(os.environ.get("MI_FUZZ_ITERS", "120"))):
+        buf = src.copy()
+        for _ in range(int(rng.integers(1, 4))):
+            off, ln = bodies[int(rng.integers(0, len(bodies)))]
+            p = off + int(rng.integers(0, ln))
+            if it % 3 == 0:
+                p = p // 8 * 8
+                buf[p: p + 8] = np.frombuffer(np.int64(rng.choice([-1, 2**31 - 1, 2**40, -2**31, 2**62])).tobytes(), np.uint8)
+            else:
+                buf[p] = int(rng.integers(0, 256))
+        try:
+            t = da.Reader(buffers=[buf]).export_stream(accept_dictionaries=True).read_all()
+        except Exception:  # noqa: BLE001  (pyarrow raises OSError / ArrowInvalid with the stream's message)
+            rejected += 1
+            continue
+        try:
+            t.validate(full=True)
+        except pa.ArrowInvalid as e:
+            # content-level complaints (a flipped payload byte is not UTF-8 any more, an inline view's pad bytes are not
+            # zero) are fine; anything about offsets, sizes or indices would mean the export let a bad pointer through
+            assert any(k in str(e) for k in ("UTF8", "utf8", "UTF-8", "padding bytes", "inlined prefix", "null_count", "Null count")), str(e)
+        accepted += 1
+    assert rejected + accepted > 0
