@@ -18,6 +18,58 @@
 
 using namespace miarrow;
 
+// ---- the Arrow C stream export (c_stream.cpp) under the sanitizers: stubs for what c_api.cpp provides in the library
+struct mi_reader {
+  std::unique_ptr<IPCStreamReader> reader;
+};
+namespace miarrow {
+std::unique_ptr<IPCStreamReader> TakeReader(mi_reader* r) { return std::move(r->reader); }
+int WrapC(const std::function<void()>& f) {
+  try {
+    f();
+    return 0;
+  } catch (const std::exception&) {
+    return 22;
+  }
+}
+}  // namespace miarrow
+extern "C" int mi_reader_export_stream(mi_reader* r, int32_t accept_dictionaries, struct ArrowArrayStream* out);
+
+static void TouchArray(const ArrowArray* a, uint64_t* sum) {
+  *sum += static_cast<uint64_t>(a->length + a->n_buffers);
+  for (int64_t i = 0; i < a->n_children; i++) TouchArray(a->children[i], sum);
+  if (a->dictionary) TouchArray(a->dictionary, sum);
+}
+
+static int DrainStream(const std::vector<uint8_t>& buf) {
+  int batches = 0;
+  try {
+    std::vector<ArrowIPCBuffer> bufs;
+    bufs.push_back(ArrowIPCBuffer{reinterpret_cast<uint64_t>(buf.data()), static_cast<uint64_t>(buf.size())});
+    mi_reader r;
+    r.reader = std::make_unique<IPCBufferStreamReader>(bufs);
+    ArrowArrayStream st;
+    if (mi_reader_export_stream(&r, 1, &st) != 0) return -1;
+    ArrowSchema schema;
+    if (st.get_schema(&st, &schema) == 0) schema.release(&schema);
+    std::vector<ArrowArray> held;   // arrays may outlive the stream: released afterwards
+    while (batches < 64) {
+      ArrowArray a;
+      if (st.get_next(&st, &a) != 0) { (void)st.get_last_error(&st); break; }
+      if (!a.release) break;
+      uint64_t sum = 0;
+      TouchArray(&a, &sum);
+      held.push_back(a);
+      batches++;
+    }
+    st.release(&st);
+    for (auto& a : held) a.release(&a);
+  } catch (const std::exception&) {
+    return -1;
+  }
+  return batches;
+}
+
 static int Drain(const std::vector<uint8_t>& buf, bool project, std::mt19937_64& rng) {
   int batches = 0;
   try {
@@ -127,6 +179,7 @@ int main(int argc, char** argv) {
           break;
       }
       int r = Drain(buf, (it / 4) % 2 == 1, rng);
+      if (it % 5 == 0) r = DrainStream(buf);
       if (it % 3 == 0) {
         const char* dir = std::getenv("TMPDIR");
         r = DrainFile(buf, std::string(dir ? dir : "/tmp") + "/mi_fuzz_reader.bin", (it / 3) % 2 == 1, rng);

@@ -18,7 +18,8 @@ def test_host_reader_is_clean_under_asan_and_ubsan(tmp_path, golden_dir):
         ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
          "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "sanitize", "fuzz_reader.cpp"),
          os.path.join(ROOT, "duckdb-arrow_amd", "csrc", "ipc_format.cpp"),
-         os.path.join(ROOT, "duckdb-arrow_amd", "csrc", "ipc_stream_reader.cpp"), "-ldl", "-lpthread", "-o", exe],
+         os.path.join(ROOT, "duckdb-arrow_amd", "csrc", "ipc_stream_reader.cpp"),
+         os.path.join(ROOT, "duckdb-arrow_amd", "csrc", "c_stream.cpp"), "-ldl", "-lpthread", "-o", exe],
         capture_output=True, text=True)
     if build.returncode != 0 and "sanitize" in build.stderr.lower() and "cannot find" in build.stderr.lower():
         pytest.skip("sanitizer runtime not installed")
