@@ -149,7 +149,6 @@ SIGNATURES = {
     "mi_plan_class_stats": (C.c_int, [P, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                       C.POINTER(C.c_int64), C.POINTER(C.c_char_p)]),
     "mi_plan_launch_timed": (C.c_int, [P, P, C.POINTER(C.c_float)]),
-    "mi_tune": (C.c_int, [C.c_char_p, C.c_int32]),
     "mi_plan_null_counts": (C.c_int, [P, C.POINTER(C.c_int64), C.c_int32]),
     "mi_status_to_error": (C.c_int, [C.c_uint32]),
     "mi_filter_range": (C.c_int, [P, P, C.c_int32, P, C.c_int64, C.c_int64, C.c_int64, P, P, P]),

@@ -270,12 +270,6 @@ int mi_plan_launch_timed(mi_plan* plan, void* stream, float* ms_per_class) {
   });
 }
 
-int mi_tune(const char* knob, int32_t value) {
-  return Wrap([&] {
-    if (!device::SetTune(knob, value)) throw InvalidInputException(std::string("mi_tune: unknown knob '") + (knob ? knob : "") + "'");
-  });
-}
-
 int mi_plan_null_counts(mi_plan* plan, int64_t* out, int32_t n_tasks) {
   return Wrap([&] {
     if (!plan || !out) throw InvalidInputException("mi_plan_null_counts: NULL argument");

@@ -275,10 +275,7 @@ void Plan::Set(const mi_col_task* in_tasks, int32_t n_tasks, hipStream_t upload_
         if (tiles > 0xFFFFFFF0ull) throw InvalidInputException("plan has too many tiles");
         tile_task.insert(tile_task.end(), static_cast<size_t>(nt), local_task);
         if (c == device::kClassEncString) sl.misc_groups |= t.kind == MI_K_ENC_LIST32 ? 2u : 1u;
-        if (c == device::kClassMisc)
-          sl.misc_groups |= (t.kind == MI_K_LIST32 || t.kind == MI_K_LIST64 || t.kind == MI_K_STRVIEW || t.kind == MI_K_STRUCT) ? 2u
-                            : (t.kind == MI_K_BOOL || t.kind == MI_K_DICT || t.kind == MI_K_DATE64 || t.kind == MI_K_MUL_I32 ||
-                               t.kind == MI_K_MUL_I64 || t.kind == MI_K_DIV_I64) ? 1u : 4u;
+        if (c == device::kClassMisc) sl.misc_groups |= 1u << device::MiscGroupOfKind(t.kind);
         order[i] = {static_cast<int>(slices.size()), static_cast<int32_t>(local_task)};
         local_task++;
         tasks.push_back(t);
@@ -353,23 +350,21 @@ Plan::~Plan() {
 }
 
 void Plan::LaunchSlice(const ClassSlice& cs, hipStream_t s) {
-  const int grid = ctx->GridBlocks();
   if (cs.total_tiles == 0) return;
   const mi_col_task* t = d_tasks + cs.first_task;
   const uint32_t* tb = d_tile_begin + cs.tile_begin_at;
   const uint32_t* tt = d_tile_task + cs.tile_task_at;
   switch (cs.cls) {
     case device::kClassEncFixed:
-      MI_HIP_CHECK(device::LaunchEncodeFixed(t, tb, tt, cs.n_tasks, cs.total_tiles, d_null_counts, grid, s));
+      MI_HIP_CHECK(device::LaunchEncodeFixed(t, tb, tt, cs.n_tasks, cs.total_tiles, d_null_counts, s));
       break;
     case device::kClassEncString:
-      MI_HIP_CHECK(device::LaunchEncodeStringTileSums(t, tb, tt, cs.n_tasks, cs.total_tiles, d_tile_sums, grid, s));
+      MI_HIP_CHECK(device::LaunchEncodeStringTileSums(t, tb, tt, cs.n_tasks, cs.total_tiles, d_tile_sums, s));
       MI_HIP_CHECK(device::LaunchEncodeStringScan(t, tb, cs.n_tasks, d_tile_sums, d_status, s));
-      MI_HIP_CHECK(device::LaunchEncodeString(t, tb, tt, cs.n_tasks, cs.total_tiles, d_tile_sums, d_null_counts, grid, cs.misc_groups, s));
+      MI_HIP_CHECK(device::LaunchEncodeString(t, tb, tt, cs.n_tasks, cs.total_tiles, d_tile_sums, d_null_counts, cs.misc_groups, s));
       break;
     default:
-      MI_HIP_CHECK(device::LaunchTranscode(cs.cls, t, tb, tt, cs.n_tasks, cs.total_tiles, d_status, cs.misc_groups,
-                                           ctx->num_cus, s));
+      MI_HIP_CHECK(device::LaunchTranscode(cs.cls, t, tb, tt, cs.n_tasks, cs.total_tiles, d_status, cs.misc_groups, s));
       break;
   }
 }

@@ -31,7 +31,6 @@ struct Context {
   explicit Context(int device_id);
   ~Context();
   void Bind() const;  // hipSetDevice
-  int GridBlocks() const { return num_cus * device::kBlocksPerCU; }
 };
 
 int OutWidth(int32_t kind, int64_t param);

@@ -281,11 +281,14 @@ static ArrowField DecodeField(const fb::Table& f, int depth) {
       o.precision = t.scalar<int32_t>(0, 0);
       o.scale = t.scalar<int32_t>(1, 0);
       o.bit_width = t.scalar<int32_t>(2, 128);
+      if (o.bit_width != 32 && o.bit_width != 64 && o.bit_width != 128 && o.bit_width != 256)
+        throw IOException("Expected decimal bit width of 32, 64, 128 or 256 but got " + std::to_string(o.bit_width));
       break;
     case MI_AT_DATE: o.unit = t.scalar<int16_t>(0, 1); break;
     case MI_AT_TIME:
       o.unit = t.scalar<int16_t>(0, 1);
       o.bit_width = t.scalar<int32_t>(1, 32);
+      if (o.bit_width != 32 && o.bit_width != 64) throw IOException("Expected time bit width of 32 or 64 but got " + std::to_string(o.bit_width));
       break;
     case MI_AT_TIMESTAMP:
       o.unit = t.scalar<int16_t>(0, 0);
@@ -293,8 +296,15 @@ static ArrowField DecodeField(const fb::Table& f, int depth) {
       break;
     case MI_AT_DURATION: o.unit = t.scalar<int16_t>(0, 1); break;
     case MI_AT_INTERVAL: o.unit = t.scalar<int16_t>(0, 0); break;
-    case MI_AT_FIXED_BINARY: o.byte_width = t.scalar<int32_t>(0, 0); break;
-    case MI_AT_FIXED_LIST: o.byte_width = t.scalar<int32_t>(0, 0); break;
+    // widths taken from the file multiply row counts and addresses later: nanoarrow rejects these at schema decode too
+    case MI_AT_FIXED_BINARY:
+      o.byte_width = t.scalar<int32_t>(0, 0);
+      if (o.byte_width <= 0) throw IOException("Expected FixedSizeBinary byteWidth > 0 but got " + std::to_string(o.byte_width));
+      break;
+    case MI_AT_FIXED_LIST:
+      o.byte_width = t.scalar<int32_t>(0, 0);
+      if (o.byte_width < 0) throw IOException("Expected FixedSizeList listSize >= 0 but got " + std::to_string(o.byte_width));
+      break;
     case MI_AT_UNION: o.unit = t.scalar<int16_t>(0, 0); break;  // UnionMode: 0 sparse, 1 dense
     default: break;
   }
@@ -306,6 +316,8 @@ static ArrowField DecodeField(const fb::Table& f, int depth) {
     fb::Table it = d.table(1);
     o.dict_index_bit_width = it ? it.scalar<int32_t>(0, 32) : 32;
     o.dict_index_signed = it ? it.scalar<uint8_t>(1, 1) != 0 : true;
+    if (o.dict_index_bit_width != 8 && o.dict_index_bit_width != 16 && o.dict_index_bit_width != 32 && o.dict_index_bit_width != 64)
+      throw IOException("Expected dictionary index bit width of 8, 16, 32 or 64 but got " + std::to_string(o.dict_index_bit_width));
     o.dict_ordered = d.scalar<uint8_t>(2, 0) != 0;
   }
   uint32_t nchild;

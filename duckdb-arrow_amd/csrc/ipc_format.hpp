@@ -18,6 +18,12 @@ namespace miarrow {
 
 using idx_t = uint64_t;
 
+//! [offset, offset + length) lies inside [0, size).  Written without the addition: offsets and lengths come from files,
+//! and `offset + length > size` wraps for values near INT64_MAX and then passes.
+inline bool SpanInside(int64_t offset, int64_t length, int64_t size) {
+  return offset >= 0 && length >= 0 && offset <= size && length <= size - offset;
+}
+
 // Exception types mirror the DuckDB exception classes the reference throws; the C ABI maps them to errno codes
 // the way IpcArrayStream::Wrap does (src/include/ipc/array_stream.hpp:29-48).
 struct Exception : std::runtime_error {

@@ -83,62 +83,56 @@ const ArrowSchemaModel& IPCStreamReader::GetOutputSchema() {
   return GetBaseSchema();
 }
 
+// Projection pushdown by column name (the seam of base_stream_reader.cpp:146-212; error texts are the reference's).
+// Names are the deduplicated top-level names; a name that two columns still share after deduplication cannot be
+// addressed.  Per projected column the reader keeps its top-level index and its depth-first flattened field index
+// (children count as fields of their own), which is how the decoder of the reference addresses columns.
 void IPCStreamReader::SetColumnProjection(const std::vector<std::string>& column_names) {
-  if (column_names.empty()) {
-    throw InternalException("Can't request zero fields projected from IpcStreamReader");
-  }
+  if (column_names.empty()) throw InternalException("Can't request zero fields projected from IpcStreamReader");
   GetBaseSchema();
-
-  std::vector<std::string> names;
-  for (auto& f : base_schema.fields) names.push_back(f.name);
+  const size_t n_top = base_schema.fields.size();
+  std::vector<std::string> names(n_top);
+  std::vector<int64_t> flat_start(n_top + 1, 0);  // flattened index of every top-level field = fields before it
+  for (size_t i = 0; i < n_top; i++) {
+    names[i] = base_schema.fields[i].name;
+    flat_start[i + 1] = flat_start[i] + CountFields(base_schema.fields[i]);
+  }
   DeduplicateColumns(names);
-
-  // flattened field index (the decoder addresses columns depth-first) + top-level index per name
-  std::unordered_map<std::string, std::pair<int64_t, int32_t>> name_to_field;
-  std::unordered_set<std::string> duplicate_column_names;
-  int64_t field_count = 0;
-  for (size_t i = 0; i < base_schema.fields.size(); i++) {
-    if (name_to_field.find(names[i]) != name_to_field.end()) duplicate_column_names.insert(names[i]);
-    name_to_field.insert({names[i], {field_count, static_cast<int32_t>(i)}});
-    field_count += CountFields(base_schema.fields[i]);
-  }
-
-  std::vector<int64_t> new_fields;
-  std::vector<int32_t> new_columns;
-  ArrowSchemaModel schema;
-  schema.endianness = base_schema.endianness;
-  schema.metadata = base_schema.metadata;
-  for (const auto& column_name : column_names) {
-    if (duplicate_column_names.find(column_name) != duplicate_column_names.end()) {
-      throw InternalException(std::string("Field '") + column_name + "' refers to a duplicate column name in IPC file schema");
+  auto locate = [&](const std::string& wanted) -> size_t {
+    size_t hit = n_top, hits = 0;
+    for (size_t i = 0; i < n_top; i++) {
+      if (names[i] != wanted) continue;
+      if (hits++ == 0) hit = i;
     }
-    auto item = name_to_field.find(column_name);
-    if (item == name_to_field.end()) {
-      throw InternalException(std::string("Field '") + column_name + "' does not exist in IPC file schema");
-    }
-    new_fields.push_back(item->second.first);
-    new_columns.push_back(item->second.second);
-    schema.fields.push_back(base_schema.fields[static_cast<size_t>(item->second.second)]);
+    if (hits > 1) throw InternalException("Field '" + wanted + "' refers to a duplicate column name in IPC file schema");
+    if (hits == 0) throw InternalException("Field '" + wanted + "' does not exist in IPC file schema");
+    return hit;
+  };
+  ArrowSchemaModel picked;
+  picked.endianness = base_schema.endianness;
+  picked.metadata = base_schema.metadata;
+  std::vector<int64_t> flat;
+  std::vector<int32_t> top;
+  for (const std::string& wanted : column_names) {
+    const size_t i = locate(wanted);
+    top.push_back(static_cast<int32_t>(i));
+    flat.push_back(flat_start[i]);
+    picked.fields.push_back(base_schema.fields[i]);
   }
-  projected_fields = std::move(new_fields);
-  projected_columns = std::move(new_columns);
-  projected_schema = std::move(schema);
+  // nothing changes unless every name resolved
+  projected_columns.swap(top);
+  projected_fields.swap(flat);
+  projected_schema = std::move(picked);
 }
 
-idx_t IPCStreamReader::DecodeMetadata() const {
-  // little-endian host: no BSWAP (base_stream_reader.cpp:216-220)
-  int64_t metadata_size = message_prefix.metadata_size;
-  if (metadata_size < 0) {
-    throw IOException(std::string("Expected metadata size >= 0 but got " + std::to_string(metadata_size)));
-  }
-  return static_cast<idx_t>(metadata_size) + sizeof(message_prefix);
-}
-
-MessageType IPCStreamReader::DecodeMessage() {
-  auto message_header_size = DecodeMetadata();
-  if (DecodeHeader(message_header_size)) {
-    return MessageType::UNINITIALIZED;
-  }
+// The prefix has been read into message_prefix: header (flatbuffer) next, then the body.  UNINITIALIZED = the
+// end-of-stream marker.  (The reference splits this into DecodeMetadata + DecodeMessage, base_stream_reader.cpp:214-236;
+// its BSWAP of the length only happens on big-endian hosts, which gfx950 hosts are not.)
+MessageType IPCStreamReader::FinishMessage() {
+  const int64_t metadata_size = message_prefix.metadata_size;
+  if (metadata_size < 0) throw IOException("Expected metadata size >= 0 but got " + std::to_string(metadata_size));
+  const bool end_of_stream = DecodeHeader(static_cast<idx_t>(metadata_size) + sizeof(message_prefix));
+  if (end_of_stream) return MessageType::UNINITIALIZED;
   DecodeBody();
   return message.type;
 }
@@ -153,19 +147,16 @@ bool IPCStreamReader::ParseHeader(const uint8_t* header_with_prefix, idx_t size)
 }
 
 MessageType IPCStreamReader::ReadNextMessage(std::vector<MessageType> expected_types, bool end_of_stream_ok) {
-  MessageType actual_type = ReadNextMessage();
-  if (end_of_stream_ok && actual_type == MessageType::UNINITIALIZED) return actual_type;
-  for (const auto expected_type : expected_types) {
-    if (expected_type == actual_type) return actual_type;
+  const MessageType got = ReadNextMessage();
+  const bool at_end = got == MessageType::UNINITIALIZED;
+  if (at_end && end_of_stream_ok) return got;
+  if (std::find(expected_types.begin(), expected_types.end(), got) != expected_types.end()) return got;
+  std::string wanted;
+  for (MessageType t : expected_types) {
+    if (!wanted.empty()) wanted += " or ";
+    wanted += MessageTypeString(t);
   }
-  std::stringstream expected_types_label;
-  for (size_t i = 0; i < expected_types.size(); i++) {
-    if (i > 0) expected_types_label << " or ";
-    expected_types_label << MessageTypeString(expected_types[i]);
-  }
-  std::string actual_type_label =
-      actual_type == MessageType::UNINITIALIZED ? "end of stream" : MessageTypeString(actual_type);
-  throw IOException(std::string("Expected ") + expected_types_label.str() + " Arrow IPC message but got " + actual_type_label);
+  throw IOException("Expected " + wanted + " Arrow IPC message but got " + (at_end ? "end of stream" : MessageTypeString(got)));
 }
 
 bool IPCStreamReader::GetNextBatch(DecodedBatch* out, bool accept_dictionaries, bool skip_body) {
@@ -386,7 +377,7 @@ void IPCStreamReader::DecompressBody(RecordBatchMeta* meta) {
       continue;
     }
     if (b.length == 0) continue;
-    if (b.offset < 0 || b.length < 8 || b.offset + b.length > cur_size)
+    if (b.length < 8 || !SpanInside(b.offset, b.length, cur_size))
       throw InternalException("Compressed buffer " + std::to_string(i) + " lies outside the message body");
     int64_t declared;
     std::memcpy(&declared, cur_ptr + b.offset, 8);
@@ -501,7 +492,7 @@ std::vector<std::pair<int64_t, int64_t>> IPCStreamReader::ProjectedBodyRanges(co
     if (!needed[k]) continue;
     const mi_buffer_span& b = meta.buffers[k];
     if (b.length <= 0) continue;
-    if (b.offset < 0 || b.offset + b.length > body_length) return {};  // malformed: read everything, validation reports it
+    if (!SpanInside(b.offset, b.length, body_length)) return {};  // malformed: read everything, validation reports it
     need.emplace_back(b.offset, b.offset + ((b.length + 7) & ~int64_t(7)));  // + the 8-byte padding kernels may touch
   }
   std::sort(need.begin(), need.end());
@@ -536,9 +527,9 @@ void IPCStreamReader::SliceBatch(const RecordBatchMeta& meta, DecodedBatch* out)
   if (meta.compression != -1 && cur_size > 0) throw InternalException("compressed body reached SliceBatch");
 
   auto check_span = [&](const mi_buffer_span& s) {
-    if (s.offset < 0 || s.length < 0 || s.offset + s.length > cur_size) {
-      throw InternalException("Buffer requires body offsets [" + std::to_string(s.offset) + ", " +
-                              std::to_string(s.offset + s.length) + ") but body has size " + std::to_string(cur_size));
+    if (!SpanInside(s.offset, s.length, cur_size)) {
+      throw InternalException("Buffer requires body offsets [" + std::to_string(s.offset) + ", " + std::to_string(s.offset) + " + " +
+                              std::to_string(s.length) + ") but body has size " + std::to_string(cur_size));
     }
     if (s.offset % 8 != 0) throw InternalException("Buffer offset " + std::to_string(s.offset) + " is not 8-byte aligned");
   };
@@ -566,9 +557,12 @@ void IPCStreamReader::SliceBatch(const RecordBatchMeta& meta, DecodedBatch* out)
       const int32_t pt = pn.field->type;
       if (pt == MI_AT_STRUCT && n != pn.length)
         throw InternalException("Struct child " + f.name + " has length " + std::to_string(n) + ", its parent " + std::to_string(pn.length));
-      if (pt == MI_AT_FIXED_LIST && n != pn.length * pn.field->byte_width)
-        throw InternalException("Fixed-size list child " + f.name + " has length " + std::to_string(n) + ", expected " +
-                                std::to_string(pn.length * pn.field->byte_width));
+      if (pt == MI_AT_FIXED_LIST) {
+        int64_t expect = 0;  // length <= 2^40 and listSize < 2^31: checked anyway, the product sizes buffers
+        if (__builtin_mul_overflow(pn.length, static_cast<int64_t>(pn.field->byte_width), &expect) || n != expect)
+          throw InternalException("Fixed-size list child " + f.name + " has length " + std::to_string(n) + ", expected " +
+                                  std::to_string(pn.length) + " x " + std::to_string(pn.field->byte_width));
+      }
     }
     const bool dict = f.has_dictionary && !value_only;
     size_t own;
@@ -616,19 +610,23 @@ void IPCStreamReader::SliceBatch(const RecordBatchMeta& meta, DecodedBatch* out)
         if (s0.length != 0 && s0.length < (n + 7) / 8) throw InternalException(BufferSizeError(f.name, 0, (n + 7) / 8, s0.length));
         if (kind != MI_K_NULL && s0.length == 0 && n > 0 && nulls > 0)
           throw InternalException("Column " + f.name + " has null_count " + std::to_string(nulls) + " but no validity buffer");
-        int64_t need1 = 0;
+        int64_t need1 = 0, per_row = 0, rows = n;
         switch (kind) {
-          case MI_K_COPY: case MI_K_FIXED_BINARY: need1 = n * param; break;
+          case MI_K_COPY: case MI_K_FIXED_BINARY: per_row = param; break;
           case MI_K_BOOL: need1 = (n + 7) / 8; break;
-          case MI_K_DEC128: case MI_K_INTERVAL_MDN: case MI_K_STRVIEW: need1 = n * 16; break;
-          case MI_K_DATE64: case MI_K_MUL_I64: case MI_K_DIV_I64: case MI_K_DURATION: need1 = n * 8; break;
-          case MI_K_MUL_I32: case MI_K_INTERVAL_MONTHS: need1 = n * 4; break;
-          case MI_K_STR32: case MI_K_LIST32: need1 = n > 0 ? (n + 1) * 4 : 0; break;
-          case MI_K_STR64: case MI_K_LIST64: need1 = n > 0 ? (n + 1) * 8 : 0; break;
-          case MI_K_DICT: case MI_K_NARROW: need1 = n * (param & 0xFF); break;
-          case MI_K_HALF_FLOAT: need1 = n * 2; break;
+          case MI_K_DEC128: case MI_K_INTERVAL_MDN: case MI_K_STRVIEW: per_row = 16; break;
+          case MI_K_DATE64: case MI_K_MUL_I64: case MI_K_DIV_I64: case MI_K_DURATION: per_row = 8; break;
+          case MI_K_MUL_I32: case MI_K_INTERVAL_MONTHS: per_row = 4; break;
+          case MI_K_STR32: case MI_K_LIST32: per_row = 4; rows = n > 0 ? n + 1 : 0; break;
+          case MI_K_STR64: case MI_K_LIST64: per_row = 8; rows = n > 0 ? n + 1 : 0; break;
+          case MI_K_DICT: case MI_K_NARROW: per_row = param & 0xFF; break;
+          case MI_K_HALF_FLOAT: per_row = 2; break;
           default: break;
         }
+        // rows <= 2^40 + 1 and widths come from the schema (validated, but up to 2^31 for fixed_size_binary): the
+        // product is formed with an overflow check so that a wrapped size can never pass for a small one
+        if (per_row < 0 || (per_row > 0 && __builtin_mul_overflow(rows, per_row, &need1)))
+          throw InternalException("Column " + f.name + " needs more bytes than a buffer can hold (" + std::to_string(rows) + " x " + std::to_string(per_row) + ")");
         if (s1.length < need1) throw InternalException(BufferSizeError(f.name, 1, need1, s1.length));
       }
       out->nodes[static_cast<size_t>(idx)] = std::move(nd);
@@ -654,15 +652,19 @@ void IPCStreamReader::SliceBatch(const RecordBatchMeta& meta, DecodedBatch* out)
   out->column_node.clear();
 
   if (meta.is_dictionary) {
-    // one node: the dictionary values of the field(s) that carry this id
+    // one node: the dictionary values of the field that carries this id -- anywhere in the field tree (a list or struct
+    // child may be dictionary-encoded too); `top` = the top-level column it belongs to
     const ArrowField* owner_field = nullptr;
     int32_t top = -1;
-    for (size_t i = 0; i < base_schema.fields.size(); i++) {
-      if (base_schema.fields[i].has_dictionary && base_schema.fields[i].dict_id == meta.dict_id) {
-        owner_field = &base_schema.fields[i];
-        top = static_cast<int32_t>(i);
-        break;
-      }
+    std::function<const ArrowField*(const ArrowField&)> find = [&](const ArrowField& f) -> const ArrowField* {
+      if (f.has_dictionary && f.dict_id == meta.dict_id) return &f;
+      for (auto& c : f.children)
+        if (const ArrowField* hit = find(c)) return hit;
+      return nullptr;
+    };
+    for (size_t i = 0; i < base_schema.fields.size() && !owner_field; i++) {
+      owner_field = find(base_schema.fields[i]);
+      if (owner_field) top = static_cast<int32_t>(i);
     }
     if (!owner_field) throw IOException("DictionaryBatch refers to unknown dictionary id " + std::to_string(meta.dict_id));
     Cursor cur;
@@ -724,7 +726,7 @@ const uint8_t* IPCFileStreamReader::ReadData(uint8_t* ptr, idx_t size) {
   // BufferedFileReader::ReadData throws SerializationException when the file ends early
   constexpr idx_t kSlice = 256u << 10;  // smallest piece worth a thread hand-off
   if (size >= 4 * kSlice && IoPool::Get().Threads() > 1) {
-    if (offset + static_cast<int64_t>(size) > file_size) throw SerializationException();
+    if (!SpanInside(offset, static_cast<int64_t>(size), file_size)) throw SerializationException();
     const int n = static_cast<int>(std::min<idx_t>((size + kSlice - 1) / kSlice, static_cast<idx_t>(2 * IoPool::Get().Threads())));
     const idx_t per = ((size + n - 1) / n + 4095) & ~static_cast<idx_t>(4095);
     const int64_t base = offset;
@@ -757,41 +759,45 @@ const uint8_t* IPCFileStreamReader::ReadData(uint8_t* ptr, idx_t size) {
   return ptr;
 }
 
-void IPCFileStreamReader::EnsureInputStreamAligned() {
-  uint8_t padding[8];
-  int padding_bytes = 8 - static_cast<int>(offset % 8);
-  if (padding_bytes != 8) ReadData(padding, static_cast<idx_t>(padding_bytes));
+// Positions the reader on the next 8-byte boundary and reads one message prefix.  false = the file ends before a whole
+// prefix could be read, which the reference treats as a clean end of stream (its aligned read throws
+// SerializationException, ipc_file_stream_reader.cpp:103-129); the file size is known here, so no read is attempted.
+bool IPCFileStreamReader::ReadPrefix() {
+  const int64_t at = (offset + 7) & ~static_cast<int64_t>(7);
+  if (at > file_size || file_size - at < static_cast<int64_t>(sizeof(message_prefix))) return false;
+  offset = at;
+  ReadData(reinterpret_cast<uint8_t*>(&message_prefix), sizeof(message_prefix));
+  return true;
 }
 
+void IPCFileStreamReader::SkipBodyPadding() { offset = std::min(file_size, (offset + 7) & ~static_cast<int64_t>(7)); }
+
 MessageType IPCFileStreamReader::ReadNextMessage() {
-  if (finished) return MessageType::UNINITIALIZED;
-  // If there is no more data to be read, we're done!
-  try {
-    EnsureInputStreamAligned();
-    ReadData(reinterpret_cast<uint8_t*>(&message_prefix), sizeof(message_prefix));
-    // Arrow *file* format: skip the magic and read the stream embedded in the file (ipc_file_stream_reader.cpp:107-119)
-    if (offset == 8 && std::memcmp("ARROW1\0\0", &message_prefix, 8) == 0) {
-      return ReadNextMessage();
+  static const char kFileMagic[8] = {'A', 'R', 'R', 'O', 'W', '1', 0, 0};
+  while (!finished) {
+    try {
+      if (!ReadPrefix()) break;
+    } catch (SerializationException&) {
+      break;  // the file shrank under us: same outcome
     }
-    if (message_prefix.continuation_token != kContinuationToken) {
-      throw IOException(std::string("Expected continuation token (0xFFFFFFFF) but got " +
-                                    std::to_string(message_prefix.continuation_token)));
+    // Arrow *file* format: the first 8 bytes are the magic, then comes an ordinary stream (ipc_file_stream_reader.cpp:107-119)
+    if (offset == 8 && std::memcmp(kFileMagic, &message_prefix, 8) == 0) continue;
+    if (message_prefix.continuation_token != kContinuationToken)
+      throw IOException("Expected continuation token (0xFFFFFFFF) but got " + std::to_string(message_prefix.continuation_token));
+    try {
+      return FinishMessage();
+    } catch (SerializationException& e) {
+      throw IOException(std::string("SerializationException: ") + e.what());
     }
-  } catch (SerializationException&) {
-    finished = true;
-    return MessageType::UNINITIALIZED;
   }
-  try {
-    return DecodeMessage();
-  } catch (SerializationException& e) {
-    throw IOException(std::string("SerializationException: ") + e.what());
-  }
+  finished = true;
+  return MessageType::UNINITIALIZED;
 }
 
 bool IPCFileStreamReader::DecodeHeader(const idx_t message_header_size) {
   // sizes come from the file: nothing is allocated for bytes the file cannot hold (BufferedFileReader::ReadData's
   // "not enough data in file to deserialize result")
-  if (offset + static_cast<int64_t>(message_prefix.metadata_size) > file_size) throw SerializationException();
+  if (!SpanInside(offset, static_cast<int64_t>(message_prefix.metadata_size), file_size)) throw SerializationException();
   if (message_header.size() < message_header_size) message_header.resize(message_header_size);
   std::memcpy(message_header.data(), &message_prefix, sizeof(message_prefix));
   ReadData(message_header.data() + sizeof(message_prefix), static_cast<idx_t>(message_prefix.metadata_size));
@@ -807,7 +813,7 @@ void IPCFileStreamReader::DecodeBody() {
   cur_ptr = nullptr;
   cur_size = 0;
   if (message.body_length > 0) {
-    EnsureInputStreamAligned();
+    SkipBodyPadding();
     cur_body_offset = offset;
     if (message.body_length > file_size - offset) throw SerializationException();  // before anything is allocated for it
     if (skip_record_batch_body && message.type == MessageType::RECORD_BATCH) {
@@ -829,7 +835,7 @@ void IPCFileStreamReader::DecodeBody() {
     if (ranges.empty()) {
       ReadData(p, static_cast<idx_t>(message.body_length));
     } else {
-      if (offset + message.body_length > file_size) throw SerializationException();
+      if (!SpanInside(offset, message.body_length, file_size)) throw SerializationException();
       const int64_t body0 = offset;
       for (auto& r : ranges) {
         if (r.second <= r.first) continue;
@@ -870,7 +876,8 @@ bool IPCFileStreamReader::IndexFromFooter() {
   std::vector<uint8_t> meta;
   auto add = [&](const FooterBlock& b, MessageType type) {
     // block.metaDataLength covers the 8-byte prefix + the padded flatbuffer
-    if (b.offset < 8 || b.meta_len < 8 || b.offset + b.meta_len + b.body_len > file_size) throw IOException("Footer block out of bounds");
+    if (b.offset < 8 || b.meta_len < 8 || !SpanInside(b.offset, b.meta_len, file_size) || !SpanInside(b.offset + b.meta_len, b.body_len, file_size))
+      throw IOException("Footer block out of bounds");
     BatchIndexEntry e{b.offset, b.meta_len - 8, static_cast<int32_t>(type), b.offset + b.meta_len, b.body_len, 0};
     meta.resize(static_cast<size_t>(b.meta_len - 8));
     if (::pread(fd, meta.data(), meta.size(), static_cast<off_t>(b.offset + 8)) != static_cast<ssize_t>(meta.size()))
@@ -911,14 +918,14 @@ const std::vector<BatchIndexEntry>& IPCFileStreamReader::BuildIndex() {
       ReadData(reinterpret_cast<uint8_t*>(&p), 8);
     } catch (SerializationException&) { break; }
     if (p.continuation_token != kContinuationToken || p.metadata_size <= 0) break;
-    if (pos + 8 + p.metadata_size > file_size) break;
+    if (!SpanInside(pos + 8, p.metadata_size, file_size)) break;
     meta.resize(static_cast<size_t>(p.metadata_size));
     ReadData(meta.data(), static_cast<idx_t>(p.metadata_size));
     MessageHeader h = DecodeMessageHeader(meta.data(), p.metadata_size);
     BatchIndexEntry e{pos, p.metadata_size, static_cast<int32_t>(h.type), 0, h.body_length, 0};
     int64_t body = (offset + 7) & ~static_cast<int64_t>(7);
     e.body_offset = body;
-    if (body + h.body_length > file_size) break;
+    if (!SpanInside(body, h.body_length, file_size)) break;
     if (h.type == MessageType::RECORD_BATCH || h.type == MessageType::DICTIONARY_BATCH)
       e.n_rows = DecodeRecordBatch(meta.data(), p.metadata_size).length;
     index.push_back(e);
@@ -935,7 +942,7 @@ IPCBufferStreamReader::IPCBufferStreamReader(std::vector<ArrowIPCBuffer> buffers
 
 const uint8_t* IPCBufferStreamReader::ReadData(idx_t size) {
   // the reference only asserts (ipc_buffer_stream_reader.cpp:37); a short buffer is reported instead of read past
-  if (cur_buffer.pos + static_cast<int64_t>(size) > cur_buffer.size) {
+  if (!SpanInside(cur_buffer.pos, static_cast<int64_t>(size), cur_buffer.size)) {
     throw IOException("Unexpected end of Arrow IPC buffer: need " + std::to_string(size) + " bytes at position " +
                       std::to_string(cur_buffer.pos) + " of " + std::to_string(cur_buffer.size));
   }
@@ -970,7 +977,7 @@ MessageType IPCBufferStreamReader::ReadNextMessage() {
     throw IOException(std::string("Expected continuation token (0xFFFFFFFF) but got " +
                                   std::to_string(message_prefix.continuation_token)));
   }
-  return DecodeMessage();
+  return FinishMessage();
 }
 
 bool IPCBufferStreamReader::DecodeHeader(idx_t message_header_size) {
@@ -1022,10 +1029,10 @@ const std::vector<BatchIndexEntry>& IPCBufferStreamReader::BuildIndex() {
       ArrowIpcMessagePrefix p;
       std::memcpy(&p, base + pos, 8);
       if (p.continuation_token != kContinuationToken || p.metadata_size <= 0) break;
-      if (pos + 8 + p.metadata_size > size) break;
+      if (!SpanInside(pos + 8, p.metadata_size, size)) break;
       MessageHeader h = DecodeMessageHeader(base + pos + 8, p.metadata_size);
       int64_t body = (pos + 8 + p.metadata_size + 7) & ~static_cast<int64_t>(7);
-      if (body + h.body_length > size) break;
+      if (!SpanInside(body, h.body_length, size)) break;
       BatchIndexEntry e{global_base + pos, p.metadata_size, static_cast<int32_t>(h.type), global_base + body, h.body_length, 0};
       if (h.type == MessageType::RECORD_BATCH || h.type == MessageType::DICTIONARY_BATCH)
         e.n_rows = DecodeRecordBatch(base + pos + 8, p.metadata_size).length;

@@ -1,6 +1,6 @@
 // ipc_stream_reader.hpp -- host half of the scan path: Arrow IPC message framing.
 //
-// Mirrors the reference's reader classes one to one (same names, same virtual seams, same error strings):
+// Takes the place of the reference's reader classes (same class names, same error strings):
 //   IPCStreamReader        src/include/ipc/stream_reader/base_stream_reader.hpp:44-126, base_stream_reader.cpp
 //   IPCFileStreamReader    src/ipc/stream_reader/ipc_file_stream_reader.cpp
 //   IPCBufferStreamReader  src/ipc/stream_reader/ipc_buffer_stream_reader.cpp
@@ -123,13 +123,12 @@ class IPCStreamReader {
   static constexpr uint32_t kContinuationToken = 0xFFFFFFFF;
 
  protected:
-  //! Decode Message is composed of 3 steps (base_stream_reader.cpp:229-236)
-  MessageType DecodeMessage();
-  //! 1. We decode the message metadata, and return the message_header_size
-  idx_t DecodeMetadata() const;
-  //! 2. We decode the message head, if message is finished we return true
+  //! With the prefix in message_prefix: checks the metadata size, then header and body through the two virtual seams
+  //! below (what the reference does in DecodeMetadata + DecodeMessage, base_stream_reader.cpp:214-236)
+  MessageType FinishMessage();
+  //! Reads and parses the flatbuffer header (message_header_size = prefix + metadata); true = end-of-stream marker
   virtual bool DecodeHeader(idx_t message_header_size) = 0;
-  //! 3. We decode the message body
+  //! Makes the message body available at cur_ptr / cur_size
   virtual void DecodeBody() = 0;
 
   //! Parses the current header into `message` (ENODATA == metadata_size 0 => returns false)
@@ -186,7 +185,8 @@ class IPCFileStreamReader : public IPCStreamReader {
   const uint8_t* ReadData(uint8_t* ptr, idx_t size);
   bool DecodeHeader(idx_t message_header_size) override;
   void DecodeBody() override;
-  void EnsureInputStreamAligned();
+  bool ReadPrefix();
+  void SkipBodyPadding();
   bool IndexFromFooter();
 
  private:

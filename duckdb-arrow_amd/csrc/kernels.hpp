@@ -22,21 +22,17 @@ constexpr int kCopyTileRows = MI_COPY_TILE_ROWS;  // copy / dec128 tiles may spa
 constexpr int kDecTileRows = MI_DEC_TILE_ROWS;
 int TileRowsOfClass(int cls);
 
-// Persistent grid: at most this many workgroups per CU (256 threads each => 8 x 4 waves = 32 waves/CU = full).
-constexpr int kBlocksPerCU = 8;
-
 // Kernel classes: a plan groups its tasks by class and launches one kernel per non-empty class.
 enum KernelClass { kClassCopy = 0, kClassDec128 = 1, kClassString = 2, kClassMisc = 3, kClassEncFixed = 4, kClassEncString = 5, kNumClasses = 6 };
 int ClassOfKind(int32_t kind);  // -1 for an unknown kind
 
 // One launch over a device-resident task table slice.  `tile_begin[i]` = first tile of task i within the slice,
 // tile_begin[n_tasks] = total_tiles.  `status` accumulates MI_ST_* bits.
-// `tile_task[tile]` = task index of every tile of the slice (optional, NULL = binary search over tile_begin).
+// `tile_task[tile]` = task index (within the slice) of every tile of the slice.  One workgroup per tile.
 hipError_t LaunchTranscode(int cls, const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
-                           int32_t n_tasks, uint32_t total_tiles, uint32_t* d_status, uint32_t misc_groups, int num_cus, hipStream_t stream);
-// measurement knobs: "copy" | "dec128" | "string" = kernel variant, "grid" = workgroups per CU (0 = one per tile),
-// "tile_table" = 0/1
-bool SetTune(const char* knob, int value);
+                           int32_t n_tasks, uint32_t total_tiles, uint32_t* d_status, uint32_t misc_groups, hipStream_t stream);
+// which transcode_misc kernel owns a kind of the misc class: 0 common flat kinds (one wave per tile), 1 nested, 2 rare flat
+int MiscGroupOfKind(int32_t kind);
 
 // K6: range filter -> selection vector, one workgroup per 2048-row window.
 //! Fused consumer: sum(a * b) over the rows that pass up to 4 conjunctive range filters, straight
@@ -61,15 +57,13 @@ hipError_t LaunchFilterRange(const void* values, int32_t width, const void* vali
 
 // K7d helpers (string encode needs a scan across the batch): per-tile payload byte sums, then per-task exclusive scan
 hipError_t LaunchEncodeStringTileSums(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
-                                      int32_t n_tasks, uint32_t total_tiles, int64_t* d_tile_sums, int grid_blocks,
-                                      hipStream_t stream);
+                                      int32_t n_tasks, uint32_t total_tiles, int64_t* d_tile_sums, hipStream_t stream);
 hipError_t LaunchEncodeStringScan(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, int32_t n_tasks,
                                   int64_t* d_tile_sums, uint32_t* d_status, hipStream_t stream);
 hipError_t LaunchEncodeFixed(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
-                             int32_t n_tasks, uint32_t total_tiles, int64_t* d_null_counts, int grid_blocks,
-                             hipStream_t stream);
+                             int32_t n_tasks, uint32_t total_tiles, int64_t* d_null_counts, hipStream_t stream);
 hipError_t LaunchEncodeString(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
-                              int32_t n_tasks, uint32_t total_tiles, const int64_t* d_tile_sums, int64_t* d_null_counts, int grid_blocks, uint32_t groups,
+                              int32_t n_tasks, uint32_t total_tiles, int64_t* d_tile_sums, int64_t* d_null_counts, uint32_t groups,
                               hipStream_t stream);
 
 }  // namespace device

@@ -1,0 +1,550 @@
+// kernels_encode.hip -- K7: DuckDB vectors -> Arrow buffers (COPY TO / to_arrow_ipc), ArrowAppender semantics
+// (call site in the reference: src/writer/column_data_collection_serializer.cpp:85).
+#include "device_common.hpp"
+
+#include <algorithm>
+
+namespace miarrow {
+namespace device {
+
+namespace {
+
+// ==================================================================================================== K7 (encode)
+// DuckDB vectors -> Arrow buffers, ArrowAppender semantics.  Task fields for encode kinds:
+//   validity  = DuckDB validity words of the whole column (NULL = all valid)   buf1 = vector data
+//   buf2      = string heap base (long string_t pointers are ptr - ptr_base into it)
+//   out_validity = Arrow bitmap (ceil(n/8) bytes, always emitted, pad bits 1)  out_data = Arrow buffer 1
+//   out_aux   = Arrow buffer 2 (string data)          param2 = index of this task's null counter
+
+// K7a: DuckDB validity words have Arrow's bit order and polarity, so the bitmap is a byte copy of the words with
+// the pad bits of the last byte forced to 1 (ResizeValidity fills with 0xFF) and NULLs counted on the way.
+__device__ __forceinline__ void enc_tile_validity(const mi_col_task& t, int64_t row0, int n, int64_t* null_counts,
+                                                  uint64_t* s_valid = nullptr) {
+  const int lane = threadIdx.x;
+  const int nwords = (n + 63) >> 6;
+  if (lane >= nwords || (t.out_validity == nullptr && s_valid == nullptr)) return;
+  uint64_t w = ~0ull;
+  if (t.validity != nullptr) w = GC<uint64_t>(t.validity)[(row0 >> 6) + lane];
+  const int rem = n - 64 * lane;
+  if (rem < 64) w |= ~0ull << rem;
+  if (s_valid) s_valid[lane] = w;
+  if (t.out_validity == nullptr) return;
+  const int nulls = 64 - __builtin_popcountll(w);
+  if (nulls) atomicAdd(reinterpret_cast<unsigned long long*>(null_counts + t.param2), static_cast<unsigned long long>(nulls));
+  gptr<uint8_t> out = GM<uint8_t>(t.out_validity) + (row0 >> 3) + 8 * lane;
+  const int nbytes = rem >= 64 ? 8 : (rem + 7) >> 3;
+  if (nbytes == 8 && (reinterpret_cast<uintptr_t>(out) & 7) == 0) {
+    *(gptr<uint64_t>)out = w;
+  } else {
+    for (int k = 0; k < nbytes; k++) out[k] = static_cast<uint8_t>(w >> (8 * k));
+  }
+}
+
+__device__ __forceinline__ bool enc_row_valid(gptr<const uint64_t> v, bool has, int64_t row) {
+  return !has || ((v[row >> 6] >> (row & 63)) & 1);
+}
+
+// K7b: DECIMAL physical int16/32/64 -> decimal128 by sign extension, one 16-byte store per row
+template <typename IN>
+__device__ __forceinline__ void enc_tile_dec128(const mi_col_task& t, int64_t row0, int n) {
+  gptr<const IN> src = GC<IN>(t.buf1) + row0;
+  gptr<u32x4> out = GM<u32x4>(t.out_data) + row0;
+#pragma unroll 4
+  for (int r = threadIdx.x; r < n; r += kBlockThreads) {
+    const int64_t v = static_cast<int64_t>(__builtin_nontemporal_load(src + r));
+    const uint32_t sign = static_cast<uint32_t>(v >> 63);
+    u32x4 o;
+    o.x = static_cast<uint32_t>(static_cast<uint64_t>(v));
+    o.y = static_cast<uint32_t>(static_cast<uint64_t>(v) >> 32);
+    o.z = sign;
+    o.w = sign;
+    __builtin_nontemporal_store(o, out + r);
+  }
+}
+
+// K7c: byte bool -> bit; data bits start as 1, a valid false clears its bit, NULL rows keep 1
+__device__ __forceinline__ void enc_tile_bool(const mi_col_task& t, int64_t row0, int n) {
+  gptr<const uint8_t> src = GC<uint8_t>(t.buf1) + row0;
+  gptr<const uint64_t> valid = GC<uint64_t>(t.validity);
+  const bool has = t.validity != nullptr;
+  gptr<uint8_t> out = GM<uint8_t>(t.out_data) + (row0 >> 3);
+  const int r = 8 * threadIdx.x;
+  if (r >= n) return;
+  uint32_t b = 0xFF;
+  for (int k = 0; k < 8 && r + k < n; k++) {
+    if (enc_row_valid(valid, has, row0 + r + k) && src[r + k] == 0) b &= ~(1u << k);
+  }
+  out[threadIdx.x] = static_cast<uint8_t>(b);
+}
+
+__global__ __launch_bounds__(kBlockThreads) void encode_fixed(const mi_col_task* __restrict__ tasks,
+                                                              const uint32_t* __restrict__ tile_begin, const uint32_t* __restrict__ tile_task, int n_tasks,
+                                                              uint32_t total_tiles, int64_t* __restrict__ null_counts) {
+  for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    MI_TILE_PROLOGUE();
+    enc_tile_validity(t, row0, n, null_counts);
+    switch (t.kind) {
+      case MI_K_ENC_COPY: {  // NULL slots copy whatever the source slot holds, like ArrowScalarData::Append
+        const int w = static_cast<int>(t.param);
+        copy_bytes(GC<uint8_t>(t.buf1) + row0 * w, GM<uint8_t>(t.out_data) + row0 * w, n * w);
+        break;
+      }
+      case MI_K_ENC_DEC128:
+        if (t.param == 8) enc_tile_dec128<int64_t>(t, row0, n);
+        else if (t.param == 4) enc_tile_dec128<int32_t>(t, row0, n);
+        else enc_tile_dec128<int16_t>(t, row0, n);
+        break;
+      case MI_K_ENC_BOOL: enc_tile_bool(t, row0, n); break;
+      default: break;
+    }
+  }
+}
+
+// block-wide exclusive scan of one value per thread (4 waves); returns the exclusive prefix, *total = block sum
+__device__ __forceinline__ int64_t block_exclusive_scan(int64_t v, int64_t* total, int64_t* lds4) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int64_t incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int64_t up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
+  }
+  if (lane == 63) lds4[wave] = incl;
+  __syncthreads();
+  int64_t base = 0, sum = 0;
+  for (int w = 0; w < kBlockThreads / 64; w++) {
+    if (w < wave) base += lds4[w];
+    sum += lds4[w];
+  }
+  *total = sum;
+  __syncthreads();
+  return base + incl - v;
+}
+
+// K7d pass 1: payload bytes per tile (valid rows only) -> tile_sums[tile]
+__global__ __launch_bounds__(kBlockThreads) void encode_string_tile_sums(const mi_col_task* __restrict__ tasks,
+                                                                         const uint32_t* __restrict__ tile_begin, const uint32_t* __restrict__ tile_task,
+                                                                         int n_tasks, uint32_t total_tiles,
+                                                                         int64_t* __restrict__ tile_sums) {
+  __shared__ int64_t lds4[kBlockThreads / 64];
+  for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    MI_TILE_PROLOGUE();
+    // string_t.length (dword 0) or, for MI_K_ENC_LIST32, list_entry_t.length (low dword of the second u64) every 16 B
+    gptr<const uint32_t> lens = GC<uint32_t>(t.buf1) + 4 * row0 + (t.kind == MI_K_ENC_LIST32 ? 2 : 0);
+    gptr<const uint64_t> valid = GC<uint64_t>(t.validity);
+    const bool has = t.validity != nullptr;
+    int64_t local = 0;
+    for (int r = threadIdx.x; r < n; r += kBlockThreads)
+      if (enc_row_valid(valid, has, row0 + r)) local += lens[4 * r];
+    int64_t total;
+    block_exclusive_scan(local, &total, lds4);
+    if (threadIdx.x == 0) tile_sums[tile] = total;
+  }
+}
+
+// K7d pass 2: per task, exclusive scan of its tiles' sums (in place) + INT32_MAX overflow check.  One workgroup
+// per task; a 122880-row batch has 60 tiles, so this is a handful of waves.
+__global__ __launch_bounds__(kBlockThreads) void encode_string_scan(const mi_col_task* __restrict__ tasks,
+                                                                    const uint32_t* __restrict__ tile_begin,
+                                                                    int n_tasks, int64_t* __restrict__ tile_sums,
+                                                                    uint32_t* __restrict__ status) {
+  __shared__ int64_t lds4[kBlockThreads / 64];
+  for (int ti = blockIdx.x; ti < n_tasks; ti += gridDim.x) {
+    const uint32_t first = tile_begin[ti], last = tile_begin[ti + 1];
+    int64_t carry = 0;
+    for (uint32_t base = first; base < last; base += kBlockThreads) {
+      const uint32_t i = base + threadIdx.x;
+      const int64_t v = i < last ? tile_sums[i] : 0;
+      int64_t total;
+      const int64_t ex = block_exclusive_scan(v, &total, lds4);
+      if (i < last) tile_sums[i] = carry + ex;
+      carry += total;
+    }
+    if (threadIdx.x == 0 && carry > 0x7FFFFFFFll && !(tasks[ti].flags & 1)) atomicOr(status, MI_ST_OFFSET_OVERFLOW);
+  }
+}
+
+// K7d pass 3: offsets + payload.  The tile is processed as 8 sub-blocks of 256 rows (lane r = row, so the 16-byte
+// string_t loads and the 4-byte offset stores are coalesced); per sub-block a wave scan + 4-wave LDS combine gives every
+// row its output position, the payload bytes of the sub-block are assembled in LDS (inline bytes come from the string_t
+// registers, long strings from the heap behind the pointer) and leave as coalesced 16-byte stores.  A sub-block whose
+// payload exceeds the LDS stage falls back to direct byte stores.
+constexpr int kEncStage = 16 * 1024;  // bytes of payload staged per 256-row sub-block (16 KB x 8 workgroups per CU)
+
+// One tile of K7d pass 3 with 64-bit positions: sub-block by sub-block (256 rows), byte-wise LDS assembly, a sub-block
+// whose payload exceeds the stage falls back to direct byte stores.  Used for list offsets and as the fallback of
+// encode_string_v5 for tiles that hold a string of >= 8 MiB (encode_string_redo).
+__device__ __forceinline__ void encode_string_tile_generic(const mi_col_task& t, int64_t row0, int n, int64_t base,
+                                                           int64_t* lds4, uint8_t* stage) {
+  gptr<const u32x4> str = GC<u32x4>(t.buf1) + row0;
+  gptr<const uint64_t> valid = GC<uint64_t>(t.validity);
+  const bool has = t.validity != nullptr;
+  gptr<const uint8_t> heap = GC<uint8_t>(t.buf2);
+  gptr<int32_t> off = GM<int32_t>(t.out_data);
+  gptr<int64_t> off64 = GM<int64_t>(t.out_data);
+  const bool large = (t.flags & 1) != 0;  // LargeUtf8 / LargeList: int64 offsets (arrow_large_buffer_size)
+  gptr<uint8_t> data = GM<uint8_t>(t.out_aux);
+  if (row0 == 0 && threadIdx.x == 0) {
+    if (large) off64[0] = 0;
+    else off[0] = 0;
+  }
+  for (int k = 0; k < kTileRows / kBlockThreads; k++) {
+    const int r = threadIdx.x + k * kBlockThreads;
+    if (k * kBlockThreads >= n) break;  // uniform
+    u32x4 s = {0u, 0u, 0u, 0u};
+    uint32_t len = 0;
+    if (r < n) {
+      s = str[r];
+      len = enc_row_valid(valid, has, row0 + r) ? (t.kind == MI_K_ENC_LIST32 ? s.z : s.x) : 0u;
+    }
+    int64_t total;
+    const int64_t ex = block_exclusive_scan(static_cast<int64_t>(len), &total, lds4);
+    const int64_t pos = base + ex;
+    if (r < n) {
+      if (large) off64[row0 + r + 1] = pos + len;
+      else off[row0 + r + 1] = static_cast<int32_t>(pos + len);
+    }
+    if (t.kind == MI_K_ENC_LIST32) {  // offsets only
+      base += total;
+      continue;
+    }
+    // LDS image: byte i of the sub-block's payload lives at stage[shift + i], shift = base mod 16, so that 16-byte
+    // aligned global addresses are 16-byte aligned LDS addresses
+    const int shift = static_cast<int>(base & 15);
+    const bool staged = total + shift <= kEncStage;
+    uint8_t* dst_l = stage + shift + static_cast<int>(ex);
+    gptr<uint8_t> dst_g = data + pos;
+    if (len != 0) {
+      if (s.x <= 12) {
+        const uint32_t w0 = s.y, w1 = s.z, w2 = s.w;
+        for (uint32_t j = 0; j < len; j++) {
+          const uint32_t w = j < 4 ? w0 : (j < 8 ? w1 : w2);
+          const uint8_t byte = static_cast<uint8_t>(w >> (8 * (j & 3)));
+          if (staged) dst_l[j] = byte; else dst_g[j] = byte;
+        }
+      } else {
+        const uint64_t p = static_cast<uint64_t>(s.z) | (static_cast<uint64_t>(s.w) << 32);
+        gptr<const uint8_t> src = heap + (p - t.ptr_base);
+        const uint32_t mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(src) & 3);
+        gptr<const uint32_t> q = (gptr<const uint32_t>)(src - mis);
+        const uint32_t ndw = (mis + len + 3) >> 2;
+        uint32_t j = 0;
+        for (uint32_t d = 0; d < ndw; d++) {
+          const uint32_t w = q[d];
+          const uint32_t first = d == 0 ? mis : 0;
+          for (uint32_t bidx = first; bidx < 4 && j < len; bidx++, j++) {
+            const uint8_t byte = static_cast<uint8_t>(w >> (8 * bidx));
+            if (staged) dst_l[j] = byte; else dst_g[j] = byte;
+          }
+        }
+      }
+    }
+    if (staged) {
+      __syncthreads();
+      // stage[shift .. shift+total) -> data[base .. base+total): unaligned head and tail bytewise, the middle as 16-byte rows
+      const int64_t g0 = base, g1 = base + total;
+      const int64_t a0 = (g0 + 15) & ~static_cast<int64_t>(15), a1 = g1 & ~static_cast<int64_t>(15);
+      if (a0 >= a1) {
+        for (int64_t i = g0 + threadIdx.x; i < g1; i += kBlockThreads) data[i] = stage[shift + (i - g0)];
+      } else {
+        for (int64_t i = g0 + threadIdx.x; i < a0; i += kBlockThreads) data[i] = stage[shift + (i - g0)];
+        for (int64_t i = a1 + threadIdx.x; i < g1; i += kBlockThreads) data[i] = stage[shift + (i - g0)];
+        const int nvec = static_cast<int>((a1 - a0) >> 4);
+        const u32x4* ls = reinterpret_cast<const u32x4*>(stage + shift + (a0 - g0));
+        gptr<u32x4> gd = (gptr<u32x4>)(data + a0);
+        for (int i = threadIdx.x; i < nvec; i += kBlockThreads) __builtin_nontemporal_store(ls[i], gd + i);
+      }
+      __syncthreads();
+    }
+    base += total;
+  }
+}
+
+// list / map offsets (MI_K_ENC_LIST32 tiles: running sums of list_entry_t lengths, no payload); string tiles belong to
+// encode_string_v5
+__global__ __launch_bounds__(kBlockThreads) void encode_list_offsets(const mi_col_task* __restrict__ tasks,
+                                                                     const uint32_t* __restrict__ tile_begin,
+                                                                     const uint32_t* __restrict__ tile_task, int n_tasks,
+                                                                     uint32_t total_tiles, const int64_t* __restrict__ tile_sums,
+                                                                     int64_t* __restrict__ null_counts) {
+  __shared__ int64_t lds4[kBlockThreads / 64];
+  __shared__ __attribute__((aligned(16))) uint8_t stage[kEncStage + 16];
+  for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    MI_TILE_PROLOGUE();
+    if (t.kind != MI_K_ENC_LIST32) continue;  // uniform
+    enc_tile_validity(t, row0, n, null_counts);
+    encode_string_tile_generic(t, row0, n, tile_sums[tile], lds4, stage);
+    __syncthreads();
+  }
+}
+
+// ---- dword-granular LDS assembly ------------------------------------------------------------------------------
+// W[0..N] hold a source byte stream that starts at byte `sh` (0..3) of W[0] (W[N+1] readable, zero); writes its first
+// cnt <= 4N bytes at dst (LDS): <= 3 head bytes up to dst's 4-byte boundary, whole dwords funnel-shifted to the
+// destination phase with v_alignbyte_b32, <= 3 tail bytes.  Straight-line code (predicated stores, no loops): the
+// kernel is bound by VALU issue, not by memory.  W is consumed (shifted in place).
+template <int N>
+__device__ __forceinline__ void lds_put_stream(uint8_t* dst, uint32_t (&W)[N + 2], uint32_t sh, uint32_t cnt) {
+  const uint32_t dm = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dst)) & 3u;
+  uint32_t head = (4u - dm) & 3u;
+  if (head > cnt) head = cnt;
+  const uint32_t first = __builtin_amdgcn_alignbyte(W[1], W[0], sh);
+  if (head > 0) dst[0] = static_cast<uint8_t>(first);
+  if (head > 1) dst[1] = static_cast<uint8_t>(first >> 8);
+  if (head > 2) dst[2] = static_cast<uint8_t>(first >> 16);
+  uint32_t tsh = sh + head;  // 0..6: where the dword stream starts inside W
+  if (tsh >= 4) {
+#pragma unroll
+    for (int i = 0; i <= N; i++) W[i] = W[i + 1];
+    tsh -= 4;
+  }
+  const uint32_t nd = (cnt - head) >> 2;
+  uint32_t* d4 = reinterpret_cast<uint32_t*>(dst + head);
+  uint32_t tailw = 0;
+#pragma unroll
+  for (int i = 0; i <= N; i++) {
+    const uint32_t v = __builtin_amdgcn_alignbyte(W[i + 1], W[i], tsh);
+    if (static_cast<uint32_t>(i) < nd) d4[i] = v;
+    if (static_cast<uint32_t>(i) == nd) tailw = v;
+  }
+  const uint32_t tc = (cnt - head) & 3u;
+  uint8_t* tp = dst + head + 4 * nd;
+  if (tc > 0) tp[0] = static_cast<uint8_t>(tailw);
+  if (tc > 1) tp[1] = static_cast<uint8_t>(tailw >> 8);
+  if (tc > 2) tp[2] = static_cast<uint8_t>(tailw >> 16);
+}
+
+// The first <= 48 bytes of a heap string starting at `src`: 13 aligned dwords cover them at any misalignment.
+__device__ __forceinline__ void heap_load13(gptr<const uint8_t> src, uint32_t cnt, uint32_t (&W)[14]) {
+  const uint32_t mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(src) & 3);
+  gptr<const uint32_t> q = (gptr<const uint32_t>)(src - mis);
+  const uint32_t ndw = (mis + (cnt < 48u ? cnt : 48u) + 3) >> 2;
+#pragma unroll
+  for (int d = 0; d < 13; d++) W[d] = static_cast<uint32_t>(d) < ndw ? __builtin_nontemporal_load(q + d) : 0u;
+  W[13] = 0u;
+}
+
+// Bytes [c0, c0 + cnt) of one string -> LDS at dst.  W: the string's first 48 heap bytes (heap_load13 of the string
+// start) when it is a long string; it is used when c0 == 0 and is scratch otherwise.
+__device__ __forceinline__ void string_bytes_to_lds(uint8_t* dst, const u32x4& s, gptr<const uint8_t> heap, uint64_t ptr_base,
+                                                    uint32_t c0, uint32_t cnt, uint32_t (&W)[14]) {
+  if (s.x <= 12) {
+    uint32_t a = s.y, b = s.z, c = s.w;
+    if (c0 >= 8) { a = c; b = 0u; c = 0u; }
+    else if (c0 >= 4) { a = b; b = c; c = 0u; }
+    uint32_t S[5] = {a, b, c, 0u, 0u};
+    lds_put_stream<3>(dst, S, c0 & 3u, cnt);
+    return;
+  }
+  const uint64_t p = static_cast<uint64_t>(s.z) | (static_cast<uint64_t>(s.w) << 32);
+  gptr<const uint8_t> src = heap + (p - ptr_base) + c0;
+  const uint32_t mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(src) & 3);
+  uint32_t done = 0;
+  if (c0 == 0) {
+    lds_put_stream<12>(dst, W, mis, cnt < 48u ? cnt : 48u);
+    done = 48;
+  }
+#pragma clang loop unroll(disable)
+  for (; done < cnt; done += 48) {
+    heap_load13(src + done, cnt - done, W);
+    lds_put_stream<12>(dst + done, W, mis, cnt - done < 48u ? cnt - done : 48u);
+  }
+}
+
+// K7d pass 3.  rocprofv3 counters showed the first formulations bound by VALU issue
+// (1.1 G wave-instructions per SF10 table, 165 per 64 one-byte strings), not by HBM, so everything here is about fewer
+// instructions per row and fewer dependent round trips:
+//  * the tile's validity words are fetched once (LDS); the NEXT sub-block's string_t is requested (clamped address,
+//    so unconditionally) before this one is touched;
+//  * a long string's first 48 heap bytes arrive as ONE batch of 13 aligned dword loads (the original walked the string
+//    one dependent dword at a time: 7 HBM round trips for a 27-byte l_comment);
+//  * the scan is a 6-step DPP wave scan + one LDS exchange of the 4 wave totals, in 32-bit arithmetic (a sub-block
+//    holding a string of >= 8 MiB is handed to the 64-bit formulation);
+//  * payload is assembled in LDS with dword stores (source stream funnel-shifted with v_alignbyte_b32 to the string
+//    start, then to the destination's 4-byte phase; <= 3 head and <= 3 tail byte stores, all predicated straight-line
+//    code), in windows of <= 8 KiB so a sub-block of any size is staged; two stage buffers alternate: one barrier per
+//    window; all positions inside a sub-block are 32-bit;
+//  * the stage leaves as coalesced 16-byte nontemporal stores through a 16-byte aligned uniform base pointer.
+constexpr uint32_t kEncBigLen = 1u << 23;
+constexpr int kEncStage5 = 8 * 1024;       // bytes per stage buffer
+constexpr int kEncStageBuf = kEncStage5 + 64;
+static_assert(2 * kEncStageBuf >= kEncStage + 16, "the 64-bit formulation borrows both stage buffers");
+
+__global__ __launch_bounds__(kBlockThreads, 6) void encode_string_v5(const mi_col_task* __restrict__ tasks,
+                                                                  const uint32_t* __restrict__ tile_begin,
+                                                                  const uint32_t* __restrict__ tile_task, int n_tasks,
+                                                                  uint32_t total_tiles, int64_t* __restrict__ tile_sums,
+                                                                  int64_t* __restrict__ null_counts) {
+  constexpr int kWaves = kBlockThreads / 64;
+  static_assert(kWaves == 4, "wave totals travel as one 16-byte LDS row");
+  __shared__ int64_t lds4[kWaves];
+  __shared__ uint64_t s_valid[kTileRows / 64];
+  __shared__ __attribute__((aligned(16))) uint32_t s_tot[2][kWaves];
+  __shared__ __attribute__((aligned(16))) uint8_t stage[2 * kEncStageBuf];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    MI_TILE_PROLOGUE();
+    if (t.kind == MI_K_ENC_LIST32) continue;  // uniform: list offsets are the other launch's tiles (encode_list_offsets)
+    enc_tile_validity(t, row0, n, null_counts, s_valid);
+    gptr<const u32x4> str = GC<u32x4>(t.buf1) + row0;
+    gptr<const uint8_t> heap = GC<uint8_t>(t.buf2);
+    gptr<int32_t> offp = GM<int32_t>(t.out_data) + row0 + 1;
+    gptr<int64_t> offp64 = GM<int64_t>(t.out_data) + row0 + 1;
+    const bool large = (t.flags & 1) != 0;  // LargeUtf8: int64 offsets (arrow_large_buffer_size)
+    gptr<uint8_t> data = GM<uint8_t>(t.out_aux);
+    const int64_t tile_base = tile_sums[tile];
+    int64_t base = tile_base;
+    if (row0 == 0 && threadIdx.x == 0) {
+      if (large) offp64[-1] = 0;
+      else offp[-1] = 0;
+    }
+    const int nsub = (n + kBlockThreads - 1) / kBlockThreads;
+    u32x4 nxt = __builtin_nontemporal_load(str + (static_cast<int>(threadIdx.x) < n ? static_cast<int>(threadIdx.x) : n - 1));
+    __syncthreads();  // s_valid
+    uint32_t buf = 0;
+#pragma clang loop unroll(disable)
+    for (int k = 0; k < nsub; k++) {
+      const int r = threadIdx.x + k * kBlockThreads;
+      const u32x4 s = nxt;
+      {
+        const int rn = r + kBlockThreads;
+        nxt = __builtin_nontemporal_load(str + (rn < n ? rn : n - 1));
+      }
+      const bool ok = r < n && ((s_valid[r >> 6] >> (r & 63)) & 1);
+      const uint32_t len = ok ? s.x : 0u;
+      uint32_t W[14];
+      if (len > 12) {
+        const uint64_t p = static_cast<uint64_t>(s.z) | (static_cast<uint64_t>(s.w) << 32);
+        heap_load13(heap + (p - t.ptr_base), len, W);
+      }
+      // exclusive scan of the sub-block's lengths
+      const uint32_t incl = wave_inclusive_scan_u32(len);
+      const bool wave_big = __any(len >= kEncBigLen);
+      if (lane == 63) s_tot[k & 1][wave] = wave_big ? 0x80000000u : incl;
+      __syncthreads();
+      const u32x4 tot = *reinterpret_cast<const u32x4*>(&s_tot[k & 1][0]);
+      if ((tot.x | tot.y | tot.z | tot.w) & 0x80000000u) {
+        // uniform: a string of >= 8 MiB in this sub-block -- 32-bit sums may wrap.  The tile is handed to the 64-bit
+        // formulation (encode_string_redo, launched right after this kernel) by setting the sign bit of its base; the
+        // rare path stays out of this kernel's register budget (inlined here it cost 28 VGPRs = two occupancy steps)
+        if (threadIdx.x == 0) tile_sums[tile] = tile_base | static_cast<int64_t>(0x8000000000000000ull);
+        break;
+      }
+      const uint32_t before = (wave > 0 ? tot.x : 0u) + (wave > 1 ? tot.y : 0u) + (wave > 2 ? tot.z : 0u);
+      const uint32_t total = tot.x + tot.y + tot.z + tot.w;
+      const uint32_t ex = before + incl - len;
+      if (r < n) {
+        if (large) offp64[r] = base + ex + len;
+        else offp[r] = static_cast<int32_t>(base + ex + len);
+      }
+      for (uint32_t w0 = 0; w0 < total;) {  // uniform: stage windows
+        const uint32_t shiftw = static_cast<uint32_t>((base + w0) & 15);
+        const uint32_t room = static_cast<uint32_t>(kEncStage5) - shiftw;
+        const uint32_t w1 = total - w0 < room ? total : w0 + room;
+        uint8_t* st = stage + buf * kEncStageBuf;
+        const uint32_t lo = ex > w0 ? ex : w0, hi = ex + len < w1 ? ex + len : w1;
+        if (lo < hi) string_bytes_to_lds(st + shiftw + (lo - w0), s, heap, t.ptr_base, lo - ex, hi - lo, W);
+        __syncthreads();
+        // stage bytes [shiftw, end) -> gbase[shiftw, end); gbase is 16-byte aligned
+        const uint32_t end = shiftw + (w1 - w0);
+        gptr<uint8_t> gbase = data + (base + w0) - shiftw;
+        const uint32_t nch = (end + 15) >> 4;
+        for (uint32_t c = threadIdx.x; c < nch; c += kBlockThreads) {
+          const uint32_t clo = c << 4;
+          if (clo >= shiftw && clo + 16 <= end)
+            __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(st + clo), (gptr<u32x4>)(gbase + clo));
+        }
+        if (threadIdx.x < 32) {  // the (at most two) partial 16-byte rows, one byte per lane
+          const uint32_t lastlo = (end - 1) & ~15u;
+          const uint32_t idx = threadIdx.x < 16 ? threadIdx.x : lastlo + (threadIdx.x - 16);
+          const bool first_partial = shiftw != 0 || end < 16;
+          const bool last_partial = (end & 15u) != 0 && lastlo != 0;
+          const bool mine = threadIdx.x < 16 ? first_partial : last_partial;
+          if (mine && idx >= shiftw && idx < end) gbase[idx] = st[idx];
+        }
+        buf ^= 1u;
+        w0 = w1;
+      }
+      base += total;
+    }
+    __syncthreads();  // s_valid / stage are rewritten by the next tile
+  }
+}
+
+// Tiles encode_string_v5 gave up on (sign bit of tile_sums set): 64-bit positions, sub-block by sub-block.  A small
+// persistent grid sweeps the flags 256 at a time; validity bitmap and NULL count were already written by v5.
+__global__ __launch_bounds__(kBlockThreads) void encode_string_redo(const mi_col_task* __restrict__ tasks,
+                                                                    const uint32_t* __restrict__ tile_begin,
+                                                                    const uint32_t* __restrict__ tile_task, int n_tasks,
+                                                                    uint32_t total_tiles, const int64_t* __restrict__ tile_sums,
+                                                                    int64_t* __restrict__ null_counts) {
+  __shared__ int64_t lds4[kBlockThreads / 64];
+  __shared__ __attribute__((aligned(16))) uint8_t stage[kEncStage + 16];
+  __shared__ uint32_t s_todo[kBlockThreads];
+  __shared__ uint32_t s_ntodo;
+  for (uint32_t first = blockIdx.x * kBlockThreads; first < total_tiles; first += gridDim.x * kBlockThreads) {
+    if (threadIdx.x == 0) s_ntodo = 0;
+    __syncthreads();
+    const uint32_t mine = first + threadIdx.x;
+    if (mine < total_tiles && tile_sums[mine] < 0) s_todo[atomicAdd(&s_ntodo, 1u)] = mine;
+    __syncthreads();
+    const uint32_t ntodo = s_ntodo;
+    for (uint32_t j = 0; j < ntodo; j++) {
+      const uint32_t tile = s_todo[j];
+      MI_TILE_PROLOGUE();
+      encode_string_tile_generic(t, row0, n, tile_sums[tile] & 0x7FFFFFFFFFFFFFFFll, lds4, stage);
+      __syncthreads();
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+// Encode launches follow the decode rule: one workgroup per tile (the dispatcher balances them), owner of a tile from
+// the tile -> task table.
+hipError_t LaunchEncodeStringTileSums(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
+                                      int32_t n_tasks, uint32_t total_tiles, int64_t* d_tile_sums, hipStream_t stream) {
+  if (total_tiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(encode_string_tile_sums, dim3(total_tiles), dim3(kBlockThreads), 0, stream, d_tasks, d_tile_begin, d_tile_task,
+                     n_tasks, total_tiles, d_tile_sums);
+  return hipGetLastError();
+}
+
+hipError_t LaunchEncodeStringScan(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, int32_t n_tasks,
+                                  int64_t* d_tile_sums, uint32_t* d_status, hipStream_t stream) {
+  if (n_tasks == 0) return hipSuccess;
+  const uint32_t grid = n_tasks < 2048 ? static_cast<uint32_t>(n_tasks) : 2048u;
+  hipLaunchKernelGGL(encode_string_scan, dim3(grid), dim3(kBlockThreads), 0, stream, d_tasks, d_tile_begin, n_tasks,
+                     d_tile_sums, d_status);
+  return hipGetLastError();
+}
+
+hipError_t LaunchEncodeFixed(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
+                             int32_t n_tasks, uint32_t total_tiles, int64_t* d_null_counts, hipStream_t stream) {
+  if (total_tiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(encode_fixed, dim3(total_tiles), dim3(kBlockThreads), 0, stream, d_tasks, d_tile_begin, d_tile_task, n_tasks,
+                     total_tiles, d_null_counts);
+  return hipGetLastError();
+}
+
+hipError_t LaunchEncodeString(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
+                              int32_t n_tasks, uint32_t total_tiles, int64_t* d_tile_sums, int64_t* d_null_counts,
+                              uint32_t groups, hipStream_t stream) {
+  if (total_tiles == 0) return hipSuccess;
+  const dim3 grid(total_tiles), block(kBlockThreads);
+  if (groups & 1u) {  // strings
+    hipLaunchKernelGGL(encode_string_v5, grid, block, 0, stream, d_tasks, d_tile_begin, d_tile_task, n_tasks, total_tiles, d_tile_sums,
+                       d_null_counts);
+    const uint32_t sweep = (total_tiles + kBlockThreads - 1) / kBlockThreads;
+    hipLaunchKernelGGL(encode_string_redo, dim3(sweep < 512u ? sweep : 512u), block, 0, stream, d_tasks, d_tile_begin, d_tile_task,
+                       n_tasks, total_tiles, d_tile_sums, d_null_counts);
+  }
+  if (groups & 2u)  // list / map offsets
+    hipLaunchKernelGGL(encode_list_offsets, grid, block, 0, stream, d_tasks, d_tile_begin, d_tile_task, n_tasks, total_tiles, d_tile_sums,
+                       d_null_counts);
+  return hipGetLastError();
+}
+
+}  // namespace device
+}  // namespace miarrow

@@ -252,11 +252,23 @@ ArrowScan::Slot* ArrowScan::FreeSlot() {
 
 void ArrowScan::DecodeDictionary(Source& src, const DecodedBatch& b) {
   ctx->Bind();
-  const ArrowField& f = src.reader->GetBaseSchema().fields[static_cast<size_t>(b.column_field[0])];
+  if (b.column_node.empty() || b.nodes.empty()) throw InternalException("DictionaryBatch without a value node");
+  const ArrowField& f = *b.nodes[static_cast<size_t>(b.column_node[0])].field;  // the field that carries the id (any depth)
   int32_t kind, w, nb;
   int64_t param;
   if (!f.Plan(&kind, &param, &w, &nb, /*value_only*/ true))
     throw NotImplementedException("Dictionary value type " + f.Format() + " is not decoded by the MI355X scan path");
+  // the values are decoded as ONE flat task below: value types that need more than {validity, buffer 1, buffer 2}
+  // (string views: a table of variadic buffers; lists / structs: child nodes) are refused instead of mis-wired
+  switch (kind) {
+    case MI_K_COPY: case MI_K_BOOL: case MI_K_DEC128: case MI_K_DATE64: case MI_K_MUL_I32: case MI_K_MUL_I64: case MI_K_DIV_I64:
+    case MI_K_STR32: case MI_K_STR64: case MI_K_FIXED_BINARY: case MI_K_DURATION: case MI_K_INTERVAL_MONTHS: case MI_K_INTERVAL_MDN:
+    case MI_K_NARROW: case MI_K_HALF_FLOAT:
+      break;
+    default:
+      throw NotImplementedException("Dictionary of value type " + f.Format() + " (field '" + f.name +
+                                    "') is not decoded by the MI355X scan path: only flat value types are");
+  }
   // isDelta: the new values are appended to the existing dictionary (indices keep their meaning); otherwise the
   // dictionary is replaced.  Either way a NEW version is built; batches already in flight keep theirs.
   std::shared_ptr<DictState> old = dicts.count(b.dict_id) ? dicts[b.dict_id] : nullptr;

@@ -318,10 +318,6 @@ int mi_plan_class_stats(const mi_plan* plan, int32_t kernel_class, int64_t* byte
 /* Like mi_plan_launch, but brackets every class launch with HIP events on `stream` and, after synchronising,
  * returns the device time of each class in milliseconds (0 for unused classes).  Measurement aid for bench.py. */
 int mi_plan_launch_timed(mi_plan* plan, void* stream, float* ms_per_class /* [MI_NUM_KERNEL_CLASSES] */);
-/* Measurement knob for A/B runs inside one process (tools/ab_bench.py): knob = "copy" | "dec128" | "string" (kernel
- * variant), "grid" (workgroups per CU, 0 = one workgroup per tile), "tile_table" (0/1).  Returns MI_EINVAL for an
- * unknown knob.  Results never depend on the knobs, only speed does. */
-int mi_tune(const char* knob, int32_t value);
 /* Encode plans: NULL count per task (FieldNode.null_count), in the order the tasks were given. Waits for the plan. */
 int mi_plan_null_counts(mi_plan* plan, int64_t* out, int32_t n_tasks);
 /* Maps a status word to the errno + message the reference would raise. Returns MI_OK for 0. */

@@ -160,7 +160,18 @@ int main(int argc, char** argv) {
     const size_t head = std::min<size_t>(src.size(), 1 << 16);
     for (int it = 0; it < iters; it++) {
       std::vector<uint8_t> buf = src;
-      switch (it % 4) {
+      switch (it % 5) {
+        case 4: {  // an extreme 64-bit word on an 8-byte boundary of the first 64 KB: Buffer{offset, length} and Block entries
+                   // near INT64_MAX make `offset + length` wrap (random byte flips essentially never produce these)
+          const uint64_t vals[] = {0x7FFFFFFFFFFFFFF8ull, 0x7FFFFFFFFFFFFFFFull, 0x8000000000000000ull, 0x4000000000000000ull,
+                                   0xFFFFFFFFFFFFFFF8ull, 0x7FFFFFFFFFFFFE58ull};
+          for (int k = 0; k < 2; k++) {
+            const size_t p8 = (rng() % (head - 8)) & ~size_t(7);
+            const uint64_t v = vals[rng() % 6];
+            std::memcpy(&buf[p8], &v, 8);
+          }
+          break;
+        }
         case 0:  // bytes in the first 64 KB (schema, first messages)
           for (int k = 0; k < 6; k++) buf[rng() % head] = static_cast<uint8_t>(rng());
           break;

@@ -87,3 +87,85 @@ def test_mutated_compressed_bodies_never_crash_the_reader(codec):
             p = off + int(rng.integers(0, max(ln - 8, 1))) // 8 * 8
             buf[p: p + 8] = np.frombuffer(np.int64(rng.choice([-2, 2**40, 2**62, 0, 7])).tobytes(), np.uint8)
         _drain(buf)
+
+
+def _utf8_stream():
+    import pyarrow as pa
+    import pyarrow.ipc as ipc
+    t = pa.table({"s": ["value %d" % i for i in range(100)], "k": pa.array(range(100), pa.int64())})
+    sink = pa.BufferOutputStream()
+    with ipc.new_stream(sink, t.schema) as w:
+        w.write_table(t)
+    return np.frombuffer(sink.getvalue(), np.uint8).copy()
+
+
+def test_buffer_span_near_int64_max_is_rejected_not_wrapped():
+    """`offset + length > size` wraps for offset = 0x7FFFFFFFFFFFFFF8 and passed the bounds check; the
+    span then reached pointer arithmetic.  Random mutation never produces this value, so it is seeded."""
+    src = _utf8_stream()
+    rd = da.Reader(buffers=[src])
+    rd.schema()
+    b = rd.next_batch()
+    off, ln = b["nodes"][0]["spans"][1]   # the offsets buffer of `s`
+    rd.close()
+    msgs = [m for m in po.walk_stream(src) if m["type"] == po.MSG_RECORD_BATCH]
+    meta = src[msgs[0]["meta_off"]: msgs[0]["meta_off"] + msgs[0]["meta_len"]]
+    needle = np.array([off, ln], np.int64).view(np.uint8).tobytes()
+    at = meta.tobytes().find(needle)
+    assert at >= 0
+    for bad_off, bad_len in [(0x7FFFFFFFFFFFFFF8, 420), (0x7FFFFFFFFFFFFFF8, 8), (8, 0x7FFFFFFFFFFFFFF8), (-8, 16), (0, -1)]:
+        buf = src.copy()
+        p = msgs[0]["meta_off"] + at
+        buf[p: p + 16] = np.array([bad_off, bad_len], np.int64).view(np.uint8)
+        rd = da.Reader(buffers=[buf])
+        rd.schema()
+        with pytest.raises(da.MiError, match="Buffer requires body offsets|size >="):
+            rd.next_batch()
+        rd.close()
+        with pytest.raises(Exception):   # the Arrow C stream export walks the offsets: it must refuse first
+            da.Reader(buffers=[buf]).export_stream().read_all()
+
+
+def _patch_every_int32(src, lo, hi, value, bad):
+    """Yields copies of `src` with one 4-byte aligned int32 == value inside [lo, hi) replaced by `bad`."""
+    words = src[lo: lo + (hi - lo) // 4 * 4].view(np.int32)
+    for i in np.nonzero(words == value)[0]:
+        buf = src.copy()
+        buf[lo + 4 * int(i): lo + 4 * int(i) + 4] = np.array([bad], np.int32).view(np.uint8)
+        yield buf
+
+
+@pytest.mark.parametrize("what,value,bads,expect", [
+    ("fixed_size_binary", 0x1234, [-1, 0, -2**31], "FixedSizeBinary byteWidth"),
+    ("fixed_size_list", 0x1234, [-1, -2**31], "FixedSizeList listSize"),
+    ("dictionary", 16, [0, 24, -8, 7], "dictionary index bit width"),
+])
+def test_schema_scalars_used_as_widths_are_validated(what, value, bads, expect):
+    """byteWidth / listSize / index bitWidth from the file were used as widths unchecked (negative
+    byteWidth => negative size products pass every check; index width 24 => 8-byte reads of 3-byte slots)."""
+    import pyarrow as pa
+    import pyarrow.ipc as ipc
+    if what == "fixed_size_binary":
+        t = pa.table({"x": pa.array([b"\0" * 0x1234] * 3, pa.binary(0x1234))})
+    elif what == "fixed_size_list":
+        t = pa.table({"x": pa.array([[1] * 0x1234] * 2, pa.list_(pa.int8(), 0x1234))})
+    else:
+        t = pa.table({"x": pa.array(["a", "b", "a", None]).dictionary_encode().cast(pa.dictionary(pa.int16(), pa.utf8()))})
+    sink = pa.BufferOutputStream()
+    with ipc.new_stream(sink, t.schema) as w:
+        w.write_table(t)
+    src = np.frombuffer(sink.getvalue(), np.uint8).copy()
+    m = po.walk_stream(src)[0]
+    seen = []
+    for bad in bads:
+        for buf in _patch_every_int32(src, m["meta_off"], m["meta_off"] + m["meta_len"], value, bad):
+            rd = da.Reader(buffers=[buf])
+            try:
+                rd.schema()
+                while rd.next_batch(accept_dictionaries=True) is not None:
+                    pass
+            except da.MiError as e:
+                seen.append(str(e))
+            finally:
+                rd.close()
+    assert any(expect in s for s in seen), seen
