@@ -4,7 +4,9 @@
 One STEP = one pass of the hot path over the whole resident table: every column of every record batch of a
 synthetic `lineitem.arrows` (122880-row batches, DuckDB export schema, validity bitmaps present) is transcoded
 from Arrow IPC buffers to DuckDB vectors by the HIP kernels (3 launches per step: copy, dec128, string).  The IPC
-stream is resident in HBM when the timed region starts (PCIe-inclusive numbers are in DESIGN.md, never `value`).
+stream is resident in HBM when the timed region starts (PCIe-inclusive numbers ride along as `operator_path`, never
+`value`).  Everything goes through the C ABI (mi_hbm_* / mi_scan_*); torch only provides the stream handle, the
+barrier and the max-over-ranks reduction.
 
   N = 1   workload = BASELINE.json configs[1]: TPC-H SF10 lineitem (59 986 052 rows, 489 record batches) on one GPU.
   N > 1   one process per GPU (torch.distributed / RCCL only for the barrier and the max-over-ranks reduction):
@@ -12,11 +14,17 @@ stream is resident in HBM when the timed region starts (PCIe-inclusive numbers a
           (weak scaling, no data-path collective); value = rows of all ranks / max-over-ranks time.
 
 Besides the contract's fields the JSON line carries
-  roofline      HBM roofline of the dominant kernel, from HIP-event timings taken live (mi_plan_launch_timed)
-  kernels       the same for every kernel class
-  cpu_baseline  the CPU oracle (a port of the reference's scan path, single thread like the reference's single-file
-                scan) timed on a bounded sample of the same stream, rank 0 / N=1 only
-  parity        sampled record batches of the measured run compared bit for bit with the oracle
+  roofline           HBM roofline of the dominant kernel, from HIP-event timings taken live (mi_hbm_launch_timed)
+  kernels            the same for every kernel class
+  reference_shaped   secondary, never `value`: the same scan laid out the way the reference's vectors are (plain
+                     fixed-width columns alias the Arrow buffer, all-valid columns carry no mask) with its own roofline
+  operator_path      secondary: the scan OPERATOR (file in /dev/shm -> pread -> pinned -> H2D -> kernels -> D2H) over
+                     the SF10 table written as 8 files, every rank taking its share of the record batches
+                     (rank / world): full-column host-consumer scan and BASELINE config 3's l_shipdate pushdown
+  cpu_baseline       the CPU oracle (a port of the reference's scan path, single thread like the reference's
+                     single-file scan) timed on a bounded sample of the same stream, rank 0 / N=1 only
+  cpu_baseline_encode  the same for the COPY TO direction (K7), beside BASELINE config 4's kernel numbers
+  parity             sampled record batches of the measured run compared bit for bit with the oracle
 """
 import argparse
 import json
@@ -30,6 +38,30 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec; ~6.3 TB/s achievable copy)
+SHIP_LO, SHIP_HI = 8766, 9131   # config 3: 1994-01-01 <= l_shipdate < 1995-01-01
+
+
+def kernel_table(cstats, per_class, pmc, same_workload):
+    kernels = []
+    for cs, ms in zip(cstats, per_class):
+        if cs["tiles"] == 0:
+            continue
+        b = cs["bytes_read"] + cs["bytes_written"]
+        kernels.append({"kernel": cs["kernel"], "ms": float(ms), "algorithmic_bytes": b,
+                        "achieved_GBps": b / (ms * 1e-3) / 1e9 if ms > 0 else None,
+                        "frac_of_8TBps": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None,
+                        "traffic": pmc.get(cs["kernel"]) if same_workload else None})
+    return kernels
+
+
+def roofline_of(kernels, alg_bytes, ms_per_step):
+    dom = max(kernels, key=lambda k: k["ms"])
+    return {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": dom["frac_of_8TBps"], "traffic": dom["traffic"],
+            "traffic_source": "profiles/pmc_traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                              "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch)" if dom["traffic"] else None,
+            "algorithmic_bytes": dom["algorithmic_bytes"],
+            "whole_step_frac": alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
 def main():
@@ -42,11 +74,13 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-validity", action="store_true", help="pyarrow-style stream without validity bitmaps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget")
+    ap.add_argument("--no-operator-path", action="store_true", help="skip the /dev/shm operator-path legs")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (decode; the encode leg gets half)")
     ap.add_argument("--prewarm-seconds", type=float, default=1.5, help="untimed clock ramp before the warmup steps")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the "
                                                       "multi-process path with all ranks on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--shm-dir", default="/dev/shm", help="where the operator-path legs put their files")
     args = ap.parse_args()
 
     import torch
@@ -74,10 +108,21 @@ def main():
     import duckdb_arrow_amd as da
     from duckdb_arrow_amd.hbm import HbmStream
 
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(seconds):
+        if world > 1:
+            t = torch.tensor([seconds], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return seconds
+
     # ---- this rank's shard: SF(sf) rows starting at rank * rows (row groups of one SF(sf*N) table) ----
     rows_per_batch = 122880
-    probe = da._ffi.SynthOptions(scale_factor=args.sf, seed=args.seed, rows_per_batch=rows_per_batch, n_rows=args.rows,
-                                 first_row=0, with_validity=0 if args.no_validity else 1, n_threads=0)
     n_rows = args.rows if args.rows else {1.0: 6001215, 10.0: 59986052, 100.0: 600037902}.get(args.sf, int(6001215 * args.sf))
     batches_per_rank = (n_rows + rows_per_batch - 1) // rows_per_batch
     first_row = rank * batches_per_rank * rows_per_batch
@@ -86,81 +131,79 @@ def main():
     buf, info = da.synth_lineitem_stream(scale_factor=args.sf, seed=args.seed, n_rows=n_rows, rows_per_batch=rows_per_batch,
                                          with_validity=not args.no_validity, n_threads=threads, first_row=first_row)
     t_gen = time.time() - t0
-    del probe
 
     ctx = da.Context(local_rank)
     t0 = time.time()
-    hs = HbmStream(ctx, buf, device="cuda:%d" % local_rank)
+    hs = HbmStream(ctx, buf, device="cuda:%d" % local_rank)   # mi_hbm_open: parse + upload + layout + plan, all in the library
     torch.cuda.synchronize()
     t_upload = time.time() - t0
     stats = hs.stats()
     cstats = hs.plan.class_stats()
     stream = torch.cuda.current_stream().cuda_stream
 
-    def barrier():
+    def timed_steps(h):
+        """W untimed warmup steps, then exactly K steps between barriers; returns the max-over-ranks seconds."""
+        for _ in range(args.warmup):
+            h.launch(stream)
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        assert h.status() == 0, "device status after warmup"
+        barrier()
+        t_start = time.perf_counter()
+        for _ in range(args.steps):
+            h.launch(stream)
         torch.cuda.synchronize()
+        dt = time.perf_counter() - t_start
+        barrier()
+        assert h.status() == 0, "device status"
+        return max_over_ranks(dt)
 
     # ---- setup: bring the GPU out of its idle clock state (a fresh process measures ~4 % slower for the first
-    # few hundred milliseconds), then the W untimed warmup steps ----
+    # few hundred milliseconds) ----
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < args.prewarm_seconds:
         for _ in range(10):
             hs.launch(stream)
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        hs.launch(stream)
-    torch.cuda.synchronize()
-    assert hs.status() == 0, "device status after warmup"
 
-    # ---- timed region: exactly K steps ----
-    barrier()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        hs.launch(stream)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t_start
-    barrier()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    status = hs.status()
-    assert status == 0, "device status %d" % status
-
-    # ---- secondary, never `value`: the same scan when plain fixed-width columns alias the IPC body in HBM (the
-    # reference's zero-copy DirectConversion, mi_scan_options.zero_copy_direct) -- only columns that need work run ----
-    zc = None
-    if world == 1:
-        zp = hs.zero_copy_plan()
-        for _ in range(max(1, args.warmup)):
-            zp.launch(stream)
-        torch.cuda.synchronize()
-        t_z = time.perf_counter()
-        for _ in range(args.steps):
-            zp.launch(stream)
-        torch.cuda.synchronize()
-        dz = time.perf_counter() - t_z
-        zst = zp.stats()
-        zc = {"ms_per_step": dz / args.steps * 1e3, "rows_per_s": info["n_rows"] * args.steps / dz,
-              "algorithmic_bytes_per_row": (zst["bytes_read"] + zst["bytes_written"]) / info["n_rows"],
-              "achieved_GBps": (zst["bytes_read"] + zst["bytes_written"]) * args.steps / dz / 1e9,
-              "tasks": zp.n_tasks, "of_tasks": hs.plan.n_tasks,
-              "note": "secondary figure, not `value`: int64 keys and date32 columns are not materialised, their vectors "
-                      "point into the record-batch body in HBM exactly as the reference's vectors point into the Arrow buffer"}
+    # ---- timed region: exactly K steps of the fully materialised scan (`value`) ----
+    elapsed = timed_steps(hs)
 
     # ---- per-kernel HIP-event timings (same stream, same launches, outside the timed region) ----
-    per_class = np.zeros(6)
-    reps = max(3, min(args.steps, 10))
-    for _ in range(reps):
-        per_class += np.array(hs.plan.launch_timed(stream))
-    per_class /= reps
+    def per_class_ms(h):
+        acc = np.zeros(len(cstats))
+        reps = max(3, min(args.steps, 10))
+        for _ in range(reps):
+            acc += np.array(h.plan.launch_timed(stream))
+        return acc / reps
+
+    per_class = per_class_ms(hs)
+    traffic_src = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
+    pmc = json.load(open(traffic_src)).get("traffic_bytes_per_launch", {}) if os.path.exists(traffic_src) else {}
+    same_workload = args.sf == 10.0 and not args.rows and not args.no_validity
+
+    # ---- secondary, never `value`: the reference-shaped layout over the same resident stream -- plain fixed-width columns
+    # alias the Arrow buffer in HBM (DirectConversion) and all-valid columns carry no validity words (unset ValidityMask) ----
+    ref_shaped = None
+    if world == 1:
+        zs = HbmStream(ctx, buf, zero_copy_direct=True, unset_all_valid=True, share_stream_of=hs)
+        dz = timed_steps(zs)
+        zst, zcs = zs.stats(), zs.plan.class_stats()
+        zk = kernel_table(zcs, per_class_ms(zs), {}, False)
+        z_alg = zst["bytes_read"] + zst["bytes_written"]
+        aliased = sorted({e["name"] for lay in zs.layout[:1] for e in lay["columns"] if e["alias_off"] >= 0})
+        unmasked = sorted({e["name"] for lay in zs.layout[:1] for e in lay["columns"] if e["valid_off"] < 0 and e["alias_off"] < 0})
+        ref_shaped = {"ms_per_step": dz / args.steps * 1e3, "rows_per_s": info["n_rows"] * args.steps / dz,
+                      "algorithmic_bytes_per_row": {"read": zst["bytes_read"] / info["n_rows"], "written": zst["bytes_written"] / info["n_rows"]},
+                      "achieved_GBps": z_alg * args.steps / dz / 1e9,
+                      "roofline": roofline_of(zk, z_alg, dz / args.steps * 1e3), "kernels": zk,
+                      "tasks": zs.n_tasks, "of_tasks": hs.n_tasks, "aliased_columns": aliased, "columns_without_validity_words": unmasked,
+                      "note": "secondary figure, not `value`: mi_hbm_options.zero_copy_direct + unset_all_valid = the shape of the "
+                              "reference's own vectors (DirectConversion points the vector at the Arrow buffer, an array without "
+                              "NULLs leaves the ValidityMask unset); what a device-resident consumer gets by default"}
+        zs.close()
 
     # ---- parity of the measured run: sampled batches vs the oracle (rank 0) ----
-    parity = None
-    cpu_baseline = None
+    parity = cpu_baseline = cpu_baseline_encode = None
     if rank == 0:
         from oracle import pyoracle as po
         msgs = [m for m in po.walk_stream(buf) if m["type"] == po.MSG_RECORD_BATCH]
@@ -197,28 +240,81 @@ def main():
                                       "same stream, oracle_scan.c: body copy + FULL offset validation + 2048-row pull loop"
                                       % (passes, st["batches"], st["rows"], st["bytes_in"] / 1e9),
                             "seconds": dt, "host_cpus": os.cpu_count()}
+            # the COPY TO direction (BASELINE config 4): K7 + the reference's two extra copies per record batch, one core
+            rc, st = po.encode_stream(buf, max_batches=1)
+            per_batch = max(st["seconds"], 1e-6)
+            nb = int(max(1, min(len(msgs), args.cpu_seconds * 0.5 / per_batch)))
+            rc, st = po.encode_stream(buf, max_batches=nb, verify=True)
+            assert rc == 0 and st["mismatches"] == 0
+            cpu_baseline_encode = {"value": st["rows"] / st["seconds"], "unit": "rows/s", "cores": 1, "kind": "port",
+                                   "sample": "the first %d record batches (%d rows) of the same table as DuckDB vectors, oracle_scan.c "
+                                             "orc_encode_stream: chunk concatenation + ArrowAppender loops + body copy; every produced "
+                                             "buffer equals the source stream's" % (st["batches"], st["rows"]),
+                                   "seconds": st["seconds"], "GBps_out": st["bytes_out"] / st["seconds"] / 1e9}
+    hs.close()
+    del hs
+
+    # ---- secondary, never `value`: the scan OPERATOR over files (BASELINE config 3) ----
+    operator_path = None
+    if not args.no_operator_path:
+        d = os.path.join(args.shm_dir, "mi_bench_%d" % (os.getppid() if world > 1 else os.getpid()))
+        n_files = 8
+        paths = [os.path.join(d, "lineitem_%d.arrows" % i) for i in range(n_files)]
+        try:
+            if rank == 0:   # rank 0's shard IS the SF(sf) table (first_row 0): written once, read by every rank
+                os.makedirs(d, exist_ok=True)
+                offs, nb = info["batch_offsets"], info["n_batches"]
+                per = (nb + n_files - 1) // n_files
+                for i, p in enumerate(paths):
+                    lo, hi = offs[min(nb, i * per)], offs[min(nb, (i + 1) * per)]
+                    with open(p, "wb") as f:
+                        f.write(buf[: offs[0]].tobytes())
+                        f.write(memoryview(buf[lo:hi]))
+                        f.write(b"\xff\xff\xff\xff\x00\x00\x00\x00")
+            barrier()
+            con = da.Connection(local_rank)
+            legs = {}
+            for leg, kw, flt in (("full_scan_host_consumer", {}, False),
+                                 ("config3_shipdate_pushdown", {"filter_compact": True}, True)):
+                best = None
+                for _ in range(2):   # first pass warms the page cache mappings and the pinned rings
+                    rel = con.read_arrow(paths, rank=rank, world=world, **kw)
+                    if flt:
+                        rel.filter_range("l_shipdate", SHIP_LO, SHIP_HI)
+                    barrier()
+                    t1 = time.perf_counter()
+                    got = rel.count(detail=True)
+                    dt = time.perf_counter() - t1
+                    rel.close()
+                    dt = max_over_ranks(dt)
+                    cnt = torch.tensor([got["rows"], got["selected"]], dtype=torch.int64, device="cuda" if (world > 1 and args.backend == "nccl") else "cpu")
+                    if world > 1:
+                        dist.all_reduce(cnt)
+                    best = dt if best is None else min(best, dt)
+                    rows_all, sel_all = int(cnt[0].item()), int(cnt[1].item())
+                assert rows_all == info["n_rows"], (rows_all, info["n_rows"])
+                legs[leg] = {"seconds": best, "rows_per_s": rows_all / best, "rows": rows_all, "selected": sel_all,
+                             "file_GBps": sum(os.path.getsize(p) for p in paths) / best / 1e9}
+            con.close()
+            operator_path = dict(legs, scaling="strong", files=n_files, table="TPC-H SF%g lineitem (%d rows) in %s" % (args.sf, info["n_rows"], args.shm_dir),
+                                 rows_per_s=legs["full_scan_host_consumer"]["rows_per_s"],
+                                 note="secondary figures, never `value`: PCIe / page-cache inclusive; one table shared by all ranks, every "
+                                      "rank takes the record batches k with k mod world == rank (mi_scan_options.rank / world)")
+            barrier()
+        finally:
+            if rank == 0:
+                for p in paths:
+                    if os.path.exists(p):
+                        os.remove(p)
+                if os.path.isdir(d):
+                    os.rmdir(d)
 
     if rank == 0:
         total_rows = info["n_rows"] * world
         ms_per_step = elapsed / args.steps * 1e3
         rows_per_s = total_rows * args.steps / elapsed
         alg_bytes = stats["bytes_read"] + stats["bytes_written"]
-        kernels = []
-        for cs, ms in zip(cstats, per_class):
-            if cs["tiles"] == 0:
-                continue
-            b = cs["bytes_read"] + cs["bytes_written"]
-            kernels.append({"kernel": cs["kernel"], "ms": float(ms), "algorithmic_bytes": b,
-                            "achieved_GBps": b / (ms * 1e-3) / 1e9 if ms > 0 else None,
-                            "frac_of_8TBps": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None})
-        # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command (profiles/): the counters
-        # need their own profiler runs, so the live line quotes the last committed measurement and says so
-        traffic_src = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
-        pmc = json.load(open(traffic_src)).get("traffic_bytes_per_launch", {}) if os.path.exists(traffic_src) else {}
-        same_workload = args.sf == 10.0 and not args.rows and not args.no_validity
-        for k in kernels:
-            k["traffic"] = pmc.get(k["kernel"]) if same_workload else None
-        dom = max(kernels, key=lambda k: k["ms"])
+        kernels = kernel_table(cstats, per_class, pmc, same_workload)
         out = {
             "metric": "rows/sec + achieved HBM GB/s, TPC-H lineitem.arrows scan at 1/2/4/8 GPUs",
             "value": rows_per_s,
@@ -233,21 +329,19 @@ def main():
             "dtype": "u8/int32/int64 (byte and integer transcode, no FP)",
             "data": "synthetic",
             "config": {"workload": "TPC-H SF%g lineitem.arrows full-column scan per GPU (%d rows, %d record batches of 122880, "
-                                   "16 columns, validity bitmaps %s), IPC bodies resident in HBM"
+                                   "16 columns, validity bitmaps %s), IPC bodies resident in HBM, every vector materialised"
                                    % (args.sf, info["n_rows"], info["n_batches"], "absent" if args.no_validity else "present"),
                        "rows_per_gpu": info["n_rows"], "record_batches_per_gpu": info["n_batches"],
                        "sharding": "row groups, no collective"},
             "achieved_hbm_GBps_whole_step": alg_bytes * world / (elapsed / args.steps) / 1e9,
             "algorithmic_bytes_per_row": {"read": stats["bytes_read"] / info["n_rows"], "written": stats["bytes_written"] / info["n_rows"]},
-            "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBps"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": dom["frac_of_8TBps"], "traffic": dom["traffic"],
-                         "traffic_source": "profiles/pmc_traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
-                                           "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch)" if dom["traffic"] else None,
-                         "algorithmic_bytes": dom["algorithmic_bytes"],
-                         "whole_step_frac": alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "roofline": roofline_of(kernels, alg_bytes, ms_per_step),
             "kernels": kernels,
             "cpu_baseline": cpu_baseline,
-            "parity": parity, "zero_copy_direct": zc,
+            "cpu_baseline_encode": cpu_baseline_encode,
+            "parity": parity,
+            "reference_shaped": ref_shaped,
+            "operator_path": operator_path,
             "setup_seconds": {"generate": t_gen, "parse_upload_plan": t_upload},
         }
         print(json.dumps(out))

@@ -175,12 +175,13 @@ class Context:
 
 
 def make_task(kind, nrows, buf1, out_data, *, validity=0, buf2=0, out_validity=0, out_aux=0, ptr_base=0, row_offset=0,
-              buf2_len=0, param=0, param2=0, null_count=-1, depth=0, parent_div=0):
-    """mi_col_task from raw device addresses (decode: out_aux = parent validity words, parent_div = rows per parent row)."""
+              buf2_len=0, param=0, param2=0, null_count=-1, depth=0, parent_div=0, sel=0, sel_count=0):
+    """mi_col_task from raw device addresses (decode: out_aux = parent validity words, parent_div = rows per parent row;
+    sel / sel_count: gather mode, only the selected rows are decoded, densely packed)."""
     return _ffi.ColTask(validity=validity or None, buf1=buf1 or None, buf2=buf2 or None, out_data=out_data or None,
                         out_validity=out_validity or None, out_aux=out_aux or None, ptr_base=ptr_base, nrows=nrows,
                         row_offset=row_offset, buf2_len=buf2_len, param=param, param2=param2, null_count=null_count,
-                        kind=kind, flags=parent_div, depth=depth)
+                        kind=kind, flags=parent_div, depth=depth, sel=sel or None, sel_count=sel_count or None)
 
 
 class Plan:
@@ -215,7 +216,7 @@ class Plan:
     def class_stats(self):
         """Per kernel class: algorithmic bytes read / written, rows, tiles and the kernel's name."""
         out = []
-        for cls in range(6):
+        for cls in range(_ffi.NUM_KERNEL_CLASSES):
             r, w, rows, tiles, name = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64(), C.c_char_p()
             _ffi.check(_ffi.lib().mi_plan_class_stats(self._h, cls, C.byref(r), C.byref(w), C.byref(rows), C.byref(tiles),
                                                       C.byref(name)))
@@ -225,7 +226,7 @@ class Plan:
 
     def launch_timed(self, stream=0):
         """One launch with HIP events around every kernel class; returns [ms per class] after synchronising."""
-        ms = (C.c_float * 6)()
+        ms = (C.c_float * _ffi.NUM_KERNEL_CLASSES)()
         _ffi.check(_ffi.lib().mi_plan_launch_timed(self._h, C.c_void_p(stream or None), ms))
         return list(ms)
 
@@ -432,6 +433,39 @@ class Relation:
         _ffi.check(_ffi.lib().mi_scan_set_filter_range(self._h, column.encode(), lo, hi))
         return self
 
+    def filter(self, expr):
+        """Pushed-down predicate tree (mi_scan_set_filter).  `expr` is nested tuples:
+            ("and", e1, e2, ...) | ("or", e1, e2, ...) | (column, op, value) with op in = <> != < <= > >= |
+            (column, "in", [values]) | (column, "is null") | (column, "is not null")
+        Constants are the stored integers.  NULL semantics are SQL's: a comparison with NULL is not true."""
+        ops = {"=": _ffi.F_EQ, "==": _ffi.F_EQ, "<>": _ffi.F_NE, "!=": _ffi.F_NE, "<": _ffi.F_LT, "<=": _ffi.F_LE,
+               ">": _ffi.F_GT, ">=": _ffi.F_GE, "is null": _ffi.F_IS_NULL, "is not null": _ffi.F_IS_NOT_NULL, "in": _ffi.F_IN}
+        nodes, keep = [None], []
+
+        def emit(at, e):
+            if e[0] in ("and", "or") and len(e) > 1 and isinstance(e[1], tuple):
+                kids = list(e[1:])
+                first = len(nodes)
+                nodes.extend([None] * len(kids))
+                nodes[at] = _ffi.FilterNode(op=_ffi.F_AND if e[0] == "and" else _ffi.F_OR, first_child=first, n_children=len(kids))
+                for k, kid in enumerate(kids):
+                    emit(first + k, kid)
+                return
+            col, op = e[0], e[1].lower()
+            n = _ffi.FilterNode(op=ops[op], column=col.encode())
+            if op == "in":
+                arr = (C.c_int64 * max(len(e[2]), 1))(*[int(v) for v in e[2]])
+                keep.append(arr)
+                n.values, n.n_values = arr, len(e[2])
+            elif op not in ("is null", "is not null"):
+                n.value = int(e[2])
+            nodes[at] = n
+
+        emit(0, expr)
+        arr = (_ffi.FilterNode * len(nodes))(*nodes)
+        _ffi.check(_ffi.lib().mi_scan_set_filter(self._h, arr, len(nodes), 0))
+        return self
+
     def chunks(self):
         self._init()
         ch = _ffi.DataChunk()
@@ -448,7 +482,7 @@ class Relation:
             cols = chunk_to_columns(ch, self._out_fields)
             if apply_filter and ch.sel:
                 sel = [ch.sel[i] for i in range(ch.sel_count)]
-                cols = [[c[i] for i in sel] for c in cols]
+                cols = [[c[i] for i in sel] for c in cols]   # (compacted chunks carry no sel: their rows are the selected ones)
             for o, c in zip(out, cols):
                 o.extend(c)
         return out
@@ -660,17 +694,23 @@ class Connection:
     # -- scan ------------------------------------------------------------------------------------------
     @staticmethod
     def _options(union_by_name=False, filename=False, hive_partitioning=False, rank=0, world=1, device_resident=False,
-                 accept_dictionaries=False, zero_copy_direct=False, **unknown):
+                 accept_dictionaries=False, zero_copy_direct=None, unset_all_valid=False, filter_compact=False,
+                 pipeline_depth=0, host_decompress=False, **unknown):
         for k in unknown:
             # MultiFileFunction rejects unknown named parameters (test/sql/read_arrow.test:40-43)
             raise MiError(_ffi.MI_EINVAL, 'Invalid named parameter "%s" for function read_arrow' % k)
         return _ffi.ScanOptions(union_by_name=int(union_by_name), filename=int(filename),
                                 hive_partitioning=int(hive_partitioning), rank=rank, world=world,
                                 device_resident=int(device_resident), accept_dictionaries=int(accept_dictionaries),
-                                zero_copy_direct=int(zero_copy_direct))
+                                # None = the library's default (on for device-resident consumers), False = never
+                                zero_copy_direct=0 if zero_copy_direct is None else (1 if zero_copy_direct else -1),
+                                unset_all_valid=int(unset_all_valid), filter_compact=int(filter_compact),
+                                pipeline_depth=int(pipeline_depth), host_decompress=int(host_decompress))
 
-    def read_arrow(self, paths, **options):
-        """FROM read_arrow('file') / read_arrow(['a', 'b']) / read_arrow('dir/*.arrow') (globs expanded here)."""
+    def read_arrow(self, paths, contexts=None, **options):
+        """FROM read_arrow('file') / read_arrow(['a', 'b']) / read_arrow('dir/*.arrow') (globs expanded here).
+        `contexts`: a list of Context objects (one per GPU, or several on one GPU) = the in-library multi-device scan
+        (mi_scan_open_files_multi): record batches are dealt over them and chunks come back in record-batch order."""
         import glob as _glob
         if isinstance(paths, (str, bytes, os.PathLike)):
             paths = [paths]
@@ -687,6 +727,10 @@ class Connection:
         opts = self._options(**options)
         arr = (C.c_char_p * len(expanded))(*[os.fsencode(p) for p in expanded])
         h = C.c_void_p()
+        if contexts:
+            cs = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+            _ffi.check(_ffi.lib().mi_scan_open_files_multi(cs, len(contexts), arr, len(expanded), C.byref(opts), C.byref(h)))
+            return self._relation(h, keep=list(contexts))
         _ffi.check(_ffi.lib().mi_scan_open_files(self.ctx._h, arr, len(expanded), C.byref(opts), C.byref(h)))
         return self._relation(h)
 

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libmi_arrow_ipc.so")
 
 MI_OK, MI_EIO, MI_ENOMEM, MI_ENODEV, MI_EINVAL, MI_ERANGE, MI_ENODATA, MI_ENOTSUP = 0, 5, 12, 19, 22, 34, 61, 95
 VECTOR_SIZE = 2048
+NUM_KERNEL_CLASSES = 7
 
 # enum mi_kind
 K_COPY, K_BOOL, K_DEC128, K_DATE64, K_MUL_I32, K_MUL_I64, K_DIV_I64, K_STR32, K_STR64, K_DICT, K_FIXED_BINARY, \
@@ -65,17 +66,58 @@ class ColTask(C.Structure):
                 ("out_validity", C.c_void_p), ("out_aux", C.c_void_p), ("ptr_base", C.c_uint64),
                 ("nrows", C.c_int64), ("row_offset", C.c_int64), ("buf2_len", C.c_int64), ("param", C.c_int64),
                 ("param2", C.c_int64), ("null_count", C.c_int64), ("kind", C.c_int32), ("flags", C.c_int32),
-                ("depth", C.c_int32), ("_reserved", C.c_int32)]
+                ("depth", C.c_int32), ("_reserved", C.c_int32), ("sel", C.c_void_p), ("sel_count", C.c_void_p)]
 
 
 class ScanOptions(C.Structure):
     _fields_ = [("union_by_name", C.c_int32), ("filename", C.c_int32), ("hive_partitioning", C.c_int32),
                 ("rank", C.c_int32), ("world", C.c_int32), ("device_resident", C.c_int32),
-                ("accept_dictionaries", C.c_int32), ("zero_copy_direct", C.c_int32)]
+                ("accept_dictionaries", C.c_int32), ("zero_copy_direct", C.c_int32), ("unset_all_valid", C.c_int32),
+                ("filter_compact", C.c_int32), ("pipeline_depth", C.c_int32), ("host_decompress", C.c_int32),
+                ("_reserved", C.c_int32 * 3)]
 
 
 class RangeFilter(C.Structure):
     _fields_ = [("column", C.c_char_p), ("lo", C.c_int64), ("hi", C.c_int64)]
+
+
+class FilterNode(C.Structure):
+    _fields_ = [("op", C.c_int32), ("first_child", C.c_int32), ("n_children", C.c_int32), ("n_values", C.c_int32),
+                ("column", C.c_char_p), ("value", C.c_int64), ("values", C.POINTER(C.c_int64))]
+
+
+F_EQ, F_NE, F_LT, F_LE, F_GT, F_GE, F_IS_NULL, F_IS_NOT_NULL, F_IN, F_AND, F_OR = 1, 2, 3, 4, 5, 6, 7, 8, 9, 16, 17
+
+
+class HbmOptions(C.Structure):
+    _fields_ = [("columns", C.POINTER(C.c_char_p)), ("n_columns", C.c_int32), ("accept_dictionaries", C.c_int32),
+                ("zero_copy_direct", C.c_int32), ("unset_all_valid", C.c_int32), ("pointer_mode", C.c_int32),
+                ("defer_arena", C.c_int32), ("array_align", C.c_int64), ("device_stream", C.c_void_p),
+                ("device_arena", C.c_void_p), ("device_arena_bytes", C.c_int64)]
+
+
+HBM_PTR_DEVICE, HBM_PTR_STREAM_OFFSET, HBM_PTR_HOST = 0, 1, 2
+
+
+class HbmNode(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("kind", C.c_int32), ("out_width", C.c_int32), ("arrow_type", C.c_int32),
+                ("depth", C.c_int32), ("parent", C.c_int32), ("batch", C.c_int32), ("param", C.c_int64),
+                ("nrows", C.c_int64), ("null_count", C.c_int64), ("dict_id", C.c_int64), ("data_off", C.c_int64),
+                ("valid_off", C.c_int64), ("alias_off", C.c_int64), ("ptr_base", C.c_uint64), ("first_span", C.c_int32),
+                ("n_spans", C.c_int32), ("first_window", C.c_int32), ("n_windows", C.c_int32)]
+
+
+class HbmBatch(C.Structure):
+    _fields_ = [("nrows", C.c_int64), ("body_off", C.c_int64), ("body_len", C.c_int64), ("arena_begin", C.c_int64),
+                ("arena_end", C.c_int64), ("first_node", C.c_int32), ("n_nodes", C.c_int32), ("n_columns", C.c_int32),
+                ("is_dictionary", C.c_int32), ("dict_id", C.c_int64)]
+
+
+class HbmLayout(C.Structure):
+    _fields_ = [("batches", C.POINTER(HbmBatch)), ("n_batches", C.c_int32), ("n_nodes", C.c_int32),
+                ("nodes", C.POINTER(HbmNode)), ("spans", C.POINTER(BufferSpan)), ("windows", C.POINTER(C.c_int64)),
+                ("arena_bytes", C.c_int64), ("stream_bytes", C.c_int64), ("n_rows", C.c_int64),
+                ("device_stream", C.c_void_p), ("device_arena", C.c_void_p), ("n_tasks", C.c_int32), ("_pad", C.c_int32)]
 
 
 class SumProductResult(C.Structure):
@@ -94,13 +136,13 @@ class Vector(C.Structure):
 Vector._fields_ = [("data", C.c_void_p), ("validity", C.c_void_p), ("kind", C.c_int32), ("out_width", C.c_int32),
                    ("dictionary", C.c_void_p), ("dictionary_validity", C.c_void_p), ("dict_len", C.c_int64),
                    ("children", C.POINTER(Vector)), ("n_children", C.c_int32), ("validity_shift", C.c_int32),
-                   ("count", C.c_int64)]
+                   ("count", C.c_int64), ("heap", C.c_void_p), ("heap_size", C.c_int64)]
 
 
 class DataChunk(C.Structure):
     _fields_ = [("size", C.c_int64), ("n_columns", C.c_int32), ("file_index", C.c_int32),
                 ("batch_index", C.c_int64), ("chunk_offset", C.c_int64), ("columns", C.POINTER(Vector)),
-                ("sel", C.POINTER(C.c_uint32)), ("sel_count", C.c_int64)]
+                ("sel", C.POINTER(C.c_uint32)), ("sel_count", C.c_int64), ("source_rows", C.c_int64)]
 
 
 MAX_KV = 16
@@ -159,6 +201,20 @@ SIGNATURES = {
     "mi_scan_bind": (C.c_int, [P, C.POINTER(Field), C.c_int32, C.POINTER(C.c_int32)]),
     "mi_scan_init": (C.c_int, [P, C.POINTER(C.c_char_p), C.c_int32]),
     "mi_scan_set_filter_range": (C.c_int, [P, C.c_char_p, C.c_int64, C.c_int64]),
+    "mi_scan_set_filter": (C.c_int, [P, C.POINTER(FilterNode), C.c_int32, C.c_int32]),
+    "mi_scan_open_files_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_char_p), C.c_int32,
+                                           C.POINTER(ScanOptions), PP]),
+    "mi_hbm_open": (C.c_int, [P, P, C.c_int64, C.POINTER(HbmOptions), PP]),
+    "mi_hbm_close": (None, [P]),
+    "mi_hbm_set_arena": (C.c_int, [P, P, C.c_int64]),
+    "mi_hbm_layout_get": (C.c_int, [P, C.POINTER(HbmLayout)]),
+    "mi_hbm_launch": (C.c_int, [P, P]),
+    "mi_hbm_launch_timed": (C.c_int, [P, P, C.POINTER(C.c_float)]),
+    "mi_hbm_status": (C.c_int, [P, C.POINTER(C.c_uint32)]),
+    "mi_hbm_stats": (C.c_int, [P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "mi_hbm_class_stats": (C.c_int, [P, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                     C.POINTER(C.c_int64), C.POINTER(C.c_char_p)]),
+    "mi_hbm_fetch": (C.c_int, [P, C.c_int32, C.c_int64, C.c_int64, P]),
     "mi_scan_next": (C.c_int, [P, C.POINTER(DataChunk)]),
     "mi_scan_count": (C.c_int, [P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "mi_scan_sum_product": (C.c_int, [P, C.c_char_p, C.c_char_p, C.POINTER(RangeFilter), C.c_int32, C.POINTER(SumProductResult)]),
@@ -171,6 +227,10 @@ SIGNATURES = {
     "mi_writer_open": (C.c_int, [P, C.c_char_p, C.POINTER(Field), C.c_int32, C.POINTER(WriteOptions), PP]),
     "mi_writer_sink": (C.c_int, [P, C.POINTER(DataChunk)]),
     "mi_writer_sink_scan": (C.c_int, [P, P, C.POINTER(C.c_int64)]),
+    "mi_writer_local_create": (C.c_int, [P, PP]),
+    "mi_writer_local_sink": (C.c_int, [P, C.POINTER(DataChunk)]),
+    "mi_writer_local_combine": (C.c_int, [P]),
+    "mi_writer_local_destroy": (None, [P]),
     "mi_writer_finalize": (C.c_int, [P]),
     "mi_writer_close": (None, [P]),
     "mi_writer_row_groups": (C.c_int64, [P]),

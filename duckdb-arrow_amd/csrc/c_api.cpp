@@ -61,10 +61,17 @@ struct mi_plan {
   std::unique_ptr<Plan> plan;
 };
 
+// the dominant kernel of every class, as rocprofv3 prints it
+extern "C" const char* KernelNameOfClass(int32_t cls) {
+  static const char* names[device::kNumClasses] = {"transcode_copy", "transcode_dec128", "transcode_string", "transcode_misc_light",
+                                                  "encode_fixed", "encode_string_v5", "transcode_gather"};
+  return (cls >= 0 && cls < device::kNumClasses) ? names[cls] : "";
+}
+
 extern "C" {
 
 const char* mi_last_error(void) { return g_last_error.c_str(); }
-const char* mi_version(void) { return "mi_arrow_ipc 1 gfx950 0.7.0-SNAPSHOT"; }
+const char* mi_version(void) { return "mi_arrow_ipc 2 gfx950 0.7.0-SNAPSHOT"; }
 // nanoarrow_version() (src/nanoarrow_extension.cpp:20-31) returns the linked nanoarrow's version; the metadata
 // dialect implemented here is the one of apache/arrow-nanoarrow@4bf5a932 = "0.7.0-SNAPSHOT" (test/sql/nanoarrow.test:18).
 const char* mi_nanoarrow_version(void) { return "0.7.0-SNAPSHOT"; }
@@ -253,13 +260,11 @@ int mi_plan_class_stats(const mi_plan* plan, int32_t cls, int64_t* bytes_read, i
                         int64_t* tiles, const char** kernel_name) {
   return Wrap([&] {
     if (!plan || cls < 0 || cls >= device::kNumClasses) throw InvalidInputException("mi_plan_class_stats: bad argument");
-    static const char* names[device::kNumClasses] = {"transcode_copy", "transcode_dec128", "transcode_string", "transcode_misc",
-                                                    "encode_fixed", "encode_string"};
     if (bytes_read) *bytes_read = plan->plan->class_bytes_read[cls];
     if (bytes_written) *bytes_written = plan->plan->class_bytes_written[cls];
     if (rows) *rows = plan->plan->class_rows[cls];
     if (tiles) *tiles = plan->plan->class_tiles[cls];
-    if (kernel_name) *kernel_name = names[cls];
+    if (kernel_name) *kernel_name = KernelNameOfClass(cls);
   });
 }
 

@@ -17,6 +17,11 @@
 
 #include "kernels.hpp"
 
+// hipGetLastError() after a launch reports the thread's LAST error, whoever caused it (another library's probing call, a
+// failed call of an earlier request): launchers drop what is pending before they launch, so that what they return is
+// about their own kernel.
+#define MI_DROP_STALE_ERROR() (void)hipGetLastError()
+
 namespace miarrow {
 namespace device {
 namespace {
@@ -159,6 +164,38 @@ __device__ __forceinline__ void copy_bytes(gptr<const uint8_t> src, gptr<uint8_t
   for (; i < nvec; i += kBlockThreads) st16(d + i, ld16(s + i));
 #pragma clang loop unroll(disable) vectorize(disable)
   for (int j = nvec * 16 + threadIdx.x; j < bytes; j += kBlockThreads) dst[j] = src[j];
+}
+
+// Builds one string_t from payload bytes [a, a+len) of `data`.  The payload is fetched as aligned dwords and
+// realigned with v_alignbyte_b32 (IPC buffers are 8-byte aligned and padded to 8, so the aligned dword that holds
+// the last payload byte is always readable).  len <= 12: 12 inline bytes, zero padded.  Else 4-byte prefix + pointer.
+__device__ __forceinline__ u32x4 make_string_t(gptr<const uint8_t> data, int64_t a, uint32_t len, uint64_t ptr_base) {
+  const uint32_t take = len <= 12 ? len : 4;  // payload bytes that go into the struct
+  const uint32_t mis = static_cast<uint32_t>(a & 3);
+  gptr<const uint32_t> q = (gptr<const uint32_t>)(data + (a - mis));
+  const uint32_t nwords = take ? (mis + take + 3) >> 2 : 0;  // 0..4 aligned dwords cover the payload
+  const uint32_t w0 = nwords > 0 ? q[0] : 0;
+  const uint32_t w1 = nwords > 1 ? q[1] : 0;
+  const uint32_t w2 = nwords > 2 ? q[2] : 0;
+  const uint32_t w3 = nwords > 3 ? q[3] : 0;
+  const uint32_t o0 = __builtin_amdgcn_alignbyte(w1, w0, mis);
+  const uint32_t o1 = __builtin_amdgcn_alignbyte(w2, w1, mis);
+  const uint32_t o2 = __builtin_amdgcn_alignbyte(w3, w2, mis);
+  u32x4 s;
+  s.x = len;
+  if (len <= 12) {
+    // zero the bytes past len
+    const uint32_t k0 = len >= 4 ? 4 : len, k1 = len >= 8 ? 4 : (len > 4 ? len - 4 : 0), k2 = len > 8 ? len - 8 : 0;
+    s.y = k0 == 4 ? o0 : (o0 & ((1u << (8 * k0)) - 1u));
+    s.z = k1 == 4 ? o1 : (o1 & ((1u << (8 * k1)) - 1u));
+    s.w = k2 == 4 ? o2 : (o2 & ((1u << (8 * k2)) - 1u));
+  } else {
+    const uint64_t p = ptr_base + static_cast<uint64_t>(a);
+    s.y = o0;
+    s.z = static_cast<uint32_t>(p);
+    s.w = static_cast<uint32_t>(p >> 32);
+  }
+  return s;
 }
 
 // Inclusive wave64 scan on the DPP crossbar (no LDS traffic): row_shr 1/2/4/8 inside each 16-lane row, then

@@ -61,6 +61,12 @@ static void ValidateTask(const mi_col_task& t, size_t i) {
     throw InvalidInputException("task " + std::to_string(i) + ": " + what);
   };
   if (device::ClassOfKind(t.kind) < 0) fail("unknown kind " + std::to_string(t.kind));
+  if (t.sel != nullptr) {  // gather mode: decode only the rows a selection vector names, compacted per 2048-row window
+    if (!device::KindCanGather(t.kind)) fail("kind " + std::to_string(t.kind) + " cannot be decoded through a selection vector");
+    if (t.sel_count == nullptr) fail("gather tasks need sel_count (rows selected per 2048-row window)");
+    if (t.out_aux != nullptr || t.depth != 0) fail("gather tasks are top-level columns");
+    if (reinterpret_cast<uintptr_t>(t.sel) % 4 != 0 || reinterpret_cast<uintptr_t>(t.sel_count) % 4 != 0) fail("selection vector misaligned");
+  }
   if (t.nrows < 0) fail("negative row count");
   if (t.row_offset < 0) fail("negative row offset");
   if (t.depth < 0 || t.depth > 64) fail("bad nesting depth");
@@ -237,7 +243,7 @@ void Plan::Set(const mi_col_task* in_tasks, int32_t n_tasks, hipStream_t upload_
   for (int32_t i = 0; i < n_tasks; i++) {
     ValidateTask(in_tasks[i], static_cast<size_t>(i));
     mi_col_task t = in_tasks[i];
-    const int cls = device::ClassOfKind(t.kind);
+    const int cls = device::ClassOfTask(t);
     if (t.kind >= MI_K_ENC_COPY) {
       is_encode = true;
       t.depth = 0;
@@ -362,6 +368,9 @@ void Plan::LaunchSlice(const ClassSlice& cs, hipStream_t s) {
       MI_HIP_CHECK(device::LaunchEncodeStringTileSums(t, tb, tt, cs.n_tasks, cs.total_tiles, d_tile_sums, s));
       MI_HIP_CHECK(device::LaunchEncodeStringScan(t, tb, cs.n_tasks, d_tile_sums, d_status, s));
       MI_HIP_CHECK(device::LaunchEncodeString(t, tb, tt, cs.n_tasks, cs.total_tiles, d_tile_sums, d_null_counts, cs.misc_groups, s));
+      break;
+    case device::kClassGather:
+      MI_HIP_CHECK(device::LaunchGather(t, tb, tt, cs.n_tasks, cs.total_tiles, d_status, s));
       break;
     default:
       MI_HIP_CHECK(device::LaunchTranscode(cs.cls, t, tb, tt, cs.n_tasks, cs.total_tiles, d_status, cs.misc_groups, s));

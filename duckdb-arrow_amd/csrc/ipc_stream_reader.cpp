@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <deque>
 #include <exception>
 #include <mutex>
 #include <thread>
@@ -186,7 +187,9 @@ bool IPCStreamReader::GetNextBatch(DecodedBatch* out, bool accept_dictionaries, 
 }
 
 // Large bodies are read with several concurrent pread()s: one thread copies out of the page cache at ~10 GB/s, far below
-// what the H2D link takes, so the body is cut into slices read in parallel (MI_IO_THREADS, default 8).
+// what the H2D link takes, so the body is cut into slices read in parallel.  The pool is process wide (MI_IO_THREADS,
+// default 8, grown by multi-device scans to 8 per device) and serves any number of callers at once: a Run() is a batch of
+// tasks in one shared queue, the caller works on its own batch while it waits.
 namespace {
 class IoPool {
  public:
@@ -194,35 +197,55 @@ class IoPool {
     static IoPool pool;
     return pool;
   }
-  int Threads() const { return n_threads; }
+  int Threads() {
+    std::lock_guard<std::mutex> lk(mu);
+    return n_threads;
+  }
+  void Ensure(int n) {
+    std::lock_guard<std::mutex> lk(mu);
+    const int cap = std::max(1, static_cast<int>(std::thread::hardware_concurrency()));
+    n = std::min(n, std::max(cap, 8));
+    while (n_threads < n) {
+      workers.emplace_back([this] { Loop(); });
+      n_threads++;
+    }
+  }
   // runs fn(i) for i in [0, n) on the pool + the calling thread; rethrows the first failure
   void Run(int n, const std::function<void(int)>& fn) {
-    if (n <= 1 || n_threads <= 1) {
+    if (n <= 1 || Threads() <= 1) {
       for (int i = 0; i < n; i++) fn(i);
       return;
     }
-    std::lock_guard<std::mutex> one_job_at_a_time(run_mu);  // readers of different scans may call from different threads
-    std::unique_lock<std::mutex> lk(mu);
-    job = &fn;
-    job_n = n;
-    next = 0;
-    pending = n;
-    error = nullptr;
-    generation++;
+    Job job;
+    job.fn = &fn;
+    job.n = n;
+    job.pending = n;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      jobs.push_back(&job);
+    }
     cv.notify_all();
-    lk.unlock();
-    Work();
-    lk.lock();
-    done_cv.wait(lk, [&] { return pending == 0; });
-    job = nullptr;
-    if (error) std::rethrow_exception(error);
+    Work(&job);  // the caller takes tasks of its own batch
+    std::unique_lock<std::mutex> lk(mu);
+    job.done_cv.wait(lk, [&] { return job.pending == 0; });
+    if (job.error) std::rethrow_exception(job.error);
   }
 
  private:
+  struct Job {
+    const std::function<void(int)>* fn = nullptr;
+    int n = 0, next = 0, pending = 0;
+    std::exception_ptr error;
+    std::condition_variable done_cv;
+  };
   IoPool() {
     const char* v = std::getenv("MI_IO_THREADS");
-    n_threads = v ? std::max(1, std::atoi(v)) : 8;
-    for (int i = 1; i < n_threads; i++) workers.emplace_back([this] { Loop(); });
+    const int n = v ? std::max(1, std::atoi(v)) : 8;
+    n_threads = 1;  // the calling thread
+    for (int i = 1; i < n; i++) {
+      workers.emplace_back([this] { Loop(); });
+      n_threads++;
+    }
   }
   ~IoPool() {
     {
@@ -232,47 +255,54 @@ class IoPool {
     cv.notify_all();
     for (auto& t : workers) t.join();
   }
-  void Work() {
+  // takes tasks of `only` (or of the oldest batch with tasks left when NULL) until none is left
+  void Work(Job* only) {
     while (true) {
-      int i;
+      Job* job = nullptr;
+      int i = 0;
       {
         std::lock_guard<std::mutex> lk(mu);
-        if (!job || next >= job_n) return;
-        i = next++;
+        if (only) {
+          if (only->next < only->n) job = only;
+        } else {
+          for (Job* j : jobs)
+            if (j->next < j->n) { job = j; break; }
+        }
+        if (!job) return;
+        i = job->next++;
+        if (job->next >= job->n) jobs.erase(std::find(jobs.begin(), jobs.end(), job));  // nothing left to hand out
       }
+      std::exception_ptr err;
       try {
-        (*job)(i);
+        (*job->fn)(i);
       } catch (...) {
-        std::lock_guard<std::mutex> lk(mu);
-        if (!error) error = std::current_exception();
+        err = std::current_exception();
       }
       std::lock_guard<std::mutex> lk(mu);
-      if (--pending == 0) done_cv.notify_all();
+      if (err && !job->error) job->error = err;
+      if (--job->pending == 0) job->done_cv.notify_all();
     }
   }
   void Loop() {
-    uint64_t seen = 0;
     while (true) {
       {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return stop || generation != seen; });
+        cv.wait(lk, [&] { return stop || !jobs.empty(); });
         if (stop) return;
-        seen = generation;
       }
-      Work();
+      Work(nullptr);
     }
   }
-  std::mutex mu, run_mu;
-  std::condition_variable cv, done_cv;
+  std::mutex mu;
+  std::condition_variable cv;
   std::vector<std::thread> workers;
-  const std::function<void(int)>* job = nullptr;
-  int job_n = 0, next = 0, pending = 0, n_threads = 1;
-  uint64_t generation = 0;
+  std::deque<Job*> jobs;  // batches that still have tasks to hand out
+  int n_threads = 1;
   bool stop = false;
-  std::exception_ptr error;
 };
 }  // namespace
 
+void EnsureIoThreads(int n) { IoPool::Get().Ensure(n); }
 
 // ------------------------------------------------------------------------------------------------ compression
 // Body compression (Message.fbs BodyCompression, method BUFFER): every buffer is `int64 uncompressed_length` (-1 = the

@@ -20,9 +20,11 @@
 namespace miarrow {
 
 //! Runs fn(i), i in [0, n), on the process-wide I/O pool (MI_IO_THREADS, default 8) + the calling thread; rethrows the
-//! first failure.  One job at a time: callers on different threads queue up.
+//! first failure.  Callers on different threads share the pool.
 void ParallelFor(int n, const std::function<void(int)>& fn);
 int IoThreads();
+//! Grows the pool to at least n threads (bounded by the host's cores); multi-device scans ask for 8 per device
+void EnsureIoThreads(int n);
 
 
 

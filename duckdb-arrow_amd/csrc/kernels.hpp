@@ -23,8 +23,12 @@ constexpr int kDecTileRows = MI_DEC_TILE_ROWS;
 int TileRowsOfClass(int cls);
 
 // Kernel classes: a plan groups its tasks by class and launches one kernel per non-empty class.
-enum KernelClass { kClassCopy = 0, kClassDec128 = 1, kClassString = 2, kClassMisc = 3, kClassEncFixed = 4, kClassEncString = 5, kNumClasses = 6 };
+enum KernelClass { kClassCopy = 0, kClassDec128 = 1, kClassString = 2, kClassMisc = 3, kClassEncFixed = 4, kClassEncString = 5, kClassGather = 6,
+                   kNumClasses = 7 };
 int ClassOfKind(int32_t kind);  // -1 for an unknown kind
+//! class of a task: gather mode (mi_col_task.sel) has its own kernel; -1 when the kind is unknown or cannot be gathered
+int ClassOfTask(const mi_col_task& t);
+bool KindCanGather(int32_t kind);
 
 // One launch over a device-resident task table slice.  `tile_begin[i]` = first tile of task i within the slice,
 // tile_begin[n_tasks] = total_tiles.  `status` accumulates MI_ST_* bits.
@@ -34,7 +38,6 @@ hipError_t LaunchTranscode(int cls, const mi_col_task* d_tasks, const uint32_t* 
 // which transcode_misc kernel owns a kind of the misc class: 0 common flat kinds (one wave per tile), 1 nested, 2 rare flat
 int MiscGroupOfKind(int32_t kind);
 
-// K6: range filter -> selection vector, one workgroup per 2048-row window.
 //! Fused consumer: sum(a * b) over the rows that pass up to 4 conjunctive range filters, straight
 //! from the decoded vectors in HBM.  acc = {sum low 64 bits, sum high 64 bits (two's complement), rows selected}.
 struct AggSumProductArgs {
@@ -52,6 +55,36 @@ struct AggSumProductArgs {
 };
 hipError_t LaunchAggSumProduct(const AggSumProductArgs& args, unsigned long long* d_acc, int num_cus, hipStream_t stream);
 
+// Late materialisation: tasks with mi_col_task.sel decode only the selected rows, compacted per window (kernels_gather.hip)
+hipError_t LaunchGather(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task, int32_t n_tasks,
+                        uint32_t total_tiles, uint32_t* d_status, hipStream_t stream);
+
+// K6: pushed-down predicate -> one ascending selection vector per 2048-row window (kernels_filter.hip).  The predicate is
+// in conjunctive normal form: leaves in clause order, kLeafEndsClause on the last leaf of every clause (a clause is the
+// OR of its leaves, the filter the AND of its clauses).
+constexpr int kLeafRange = 1;       // lo <= v <= hi on the stored integer (negated with kLeafNegate)
+constexpr int kLeafIsNull = 2;
+constexpr int kLeafIsNotNull = 3;
+constexpr int kLeafIn = 4;          // v is one of in_values[0 .. n_in)
+constexpr int kLeafUnsigned = 1;    // flags: the column holds unsigned integers
+constexpr int kLeafNegate = 2;      //        NOT (range / in-list); NULL still fails
+constexpr int kLeafEndsClause = 4;
+constexpr int kLeafBias = 8;        //        uint64 column: values and constants are compared after x ^ 2^63
+constexpr int kMaxFilterLeaves = 24;
+struct FilterLeafDev {
+  const void* data;                 // decoded fixed-width vector (device), NULL for IS [NOT] NULL
+  const uint64_t* validity;         // validity words (device) or NULL = all valid
+  const int64_t* in_values;         // kLeafIn (device)
+  int64_t lo, hi;
+  int32_t op, width, flags, n_in;
+};
+struct FilterProgram {
+  int32_t n_leaves;
+  int32_t _pad;
+  FilterLeafDev leaves[kMaxFilterLeaves];
+};
+hipError_t LaunchFilterProgram(const FilterProgram& prog, int64_t nrows, mi_sel_t* sel_out, uint32_t* count_out, hipStream_t stream);
+// lo <= v < hi on one column (mi_filter_range)
 hipError_t LaunchFilterRange(const void* values, int32_t width, const void* validity, int64_t nrows, int64_t lo,
                              int64_t hi, mi_sel_t* sel_out, uint32_t* count_out, hipStream_t stream);
 

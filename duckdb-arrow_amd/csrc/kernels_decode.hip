@@ -70,38 +70,6 @@ __global__ __launch_bounds__(kBlockThreads) void transcode_dec128(const mi_col_t
 }
 
 // ---------------------------------------------------------------------------------------------------- K4
-// Builds one string_t from payload bytes [a, a+len) of `data`.  The payload is fetched as aligned dwords and
-// realigned with v_alignbyte_b32 (IPC buffers are 8-byte aligned and padded to 8, so the aligned dword that holds
-// the last payload byte is always readable).  len <= 12: 12 inline bytes, zero padded.  Else 4-byte prefix + pointer.
-__device__ __forceinline__ u32x4 make_string_t(gptr<const uint8_t> data, int64_t a, uint32_t len, uint64_t ptr_base) {
-  const uint32_t take = len <= 12 ? len : 4;  // payload bytes that go into the struct
-  const uint32_t mis = static_cast<uint32_t>(a & 3);
-  gptr<const uint32_t> q = (gptr<const uint32_t>)(data + (a - mis));
-  const uint32_t nwords = take ? (mis + take + 3) >> 2 : 0;  // 0..4 aligned dwords cover the payload
-  const uint32_t w0 = nwords > 0 ? q[0] : 0;
-  const uint32_t w1 = nwords > 1 ? q[1] : 0;
-  const uint32_t w2 = nwords > 2 ? q[2] : 0;
-  const uint32_t w3 = nwords > 3 ? q[3] : 0;
-  const uint32_t o0 = __builtin_amdgcn_alignbyte(w1, w0, mis);
-  const uint32_t o1 = __builtin_amdgcn_alignbyte(w2, w1, mis);
-  const uint32_t o2 = __builtin_amdgcn_alignbyte(w3, w2, mis);
-  u32x4 s;
-  s.x = len;
-  if (len <= 12) {
-    // zero the bytes past len
-    const uint32_t k0 = len >= 4 ? 4 : len, k1 = len >= 8 ? 4 : (len > 4 ? len - 4 : 0), k2 = len > 8 ? len - 8 : 0;
-    s.y = k0 == 4 ? o0 : (o0 & ((1u << (8 * k0)) - 1u));
-    s.z = k1 == 4 ? o1 : (o1 & ((1u << (8 * k1)) - 1u));
-    s.w = k2 == 4 ? o2 : (o2 & ((1u << (8 * k2)) - 1u));
-  } else {
-    const uint64_t p = ptr_base + static_cast<uint64_t>(a);
-    s.y = o0;
-    s.z = static_cast<uint32_t>(p);
-    s.w = static_cast<uint32_t>(p >> 32);
-  }
-  return s;
-}
-
 // utf8 / binary with int32 or int64 offsets -> string_t, offsets validated like NANOARROW_VALIDATION_LEVEL_FULL.
 // Every lane owns the 8 rows {tid + 256k} of the tile and issues all its loads before the first store (8 independent
 // offset loads, then up to 8 x 4 payload dwords), so one wave has 8 rows in flight (-8 % time against 2 in flight).
@@ -579,6 +547,11 @@ int ClassOfKind(int32_t kind) {
   }
 }
 
+int ClassOfTask(const mi_col_task& t) {
+  if (t.sel != nullptr) return KindCanGather(t.kind) ? kClassGather : -1;
+  return ClassOfKind(t.kind);
+}
+
 int MiscGroupOfKind(int32_t kind) {
   switch (kind) {
     case MI_K_BOOL: case MI_K_DICT: case MI_K_DATE64: case MI_K_MUL_I32: case MI_K_MUL_I64: case MI_K_DIV_I64: return 0;
@@ -589,6 +562,7 @@ int MiscGroupOfKind(int32_t kind) {
 
 hipError_t LaunchTranscode(int cls, const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
                            int32_t n_tasks, uint32_t total_tiles, uint32_t* d_status, uint32_t misc_groups, hipStream_t stream) {
+  MI_DROP_STALE_ERROR();
   if (total_tiles == 0) return hipSuccess;
   if (d_tile_task == nullptr) return hipErrorInvalidValue;
   const dim3 grid(total_tiles), block(kBlockThreads);  // one workgroup per tile

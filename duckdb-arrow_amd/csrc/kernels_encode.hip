@@ -505,6 +505,7 @@ __global__ __launch_bounds__(kBlockThreads) void encode_string_redo(const mi_col
 // the tile -> task table.
 hipError_t LaunchEncodeStringTileSums(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
                                       int32_t n_tasks, uint32_t total_tiles, int64_t* d_tile_sums, hipStream_t stream) {
+  MI_DROP_STALE_ERROR();
   if (total_tiles == 0) return hipSuccess;
   hipLaunchKernelGGL(encode_string_tile_sums, dim3(total_tiles), dim3(kBlockThreads), 0, stream, d_tasks, d_tile_begin, d_tile_task,
                      n_tasks, total_tiles, d_tile_sums);
@@ -513,6 +514,7 @@ hipError_t LaunchEncodeStringTileSums(const mi_col_task* d_tasks, const uint32_t
 
 hipError_t LaunchEncodeStringScan(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, int32_t n_tasks,
                                   int64_t* d_tile_sums, uint32_t* d_status, hipStream_t stream) {
+  MI_DROP_STALE_ERROR();
   if (n_tasks == 0) return hipSuccess;
   const uint32_t grid = n_tasks < 2048 ? static_cast<uint32_t>(n_tasks) : 2048u;
   hipLaunchKernelGGL(encode_string_scan, dim3(grid), dim3(kBlockThreads), 0, stream, d_tasks, d_tile_begin, n_tasks,
@@ -522,6 +524,7 @@ hipError_t LaunchEncodeStringScan(const mi_col_task* d_tasks, const uint32_t* d_
 
 hipError_t LaunchEncodeFixed(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
                              int32_t n_tasks, uint32_t total_tiles, int64_t* d_null_counts, hipStream_t stream) {
+  MI_DROP_STALE_ERROR();
   if (total_tiles == 0) return hipSuccess;
   hipLaunchKernelGGL(encode_fixed, dim3(total_tiles), dim3(kBlockThreads), 0, stream, d_tasks, d_tile_begin, d_tile_task, n_tasks,
                      total_tiles, d_null_counts);
@@ -531,6 +534,7 @@ hipError_t LaunchEncodeFixed(const mi_col_task* d_tasks, const uint32_t* d_tile_
 hipError_t LaunchEncodeString(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
                               int32_t n_tasks, uint32_t total_tiles, int64_t* d_tile_sums, int64_t* d_null_counts,
                               uint32_t groups, hipStream_t stream) {
+  MI_DROP_STALE_ERROR();
   if (total_tiles == 0) return hipSuccess;
   const dim3 grid(total_tiles), block(kBlockThreads);
   if (groups & 1u) {  // strings

@@ -2,6 +2,8 @@
 #include "device_common.hpp"
 
 #include <algorithm>
+#include <cstring>
+#include <type_traits>
 
 namespace miarrow {
 namespace device {
@@ -9,59 +11,124 @@ namespace device {
 namespace {
 
 // ---------------------------------------------------------------------------------------------------- K6
-// Range filter lo <= v < hi AND valid -> ascending window-relative indices, one selection vector per 2048-row window.
-// A workgroup takes kFilterWindows consecutive windows: lane i owns rows [8i, 8i+8) of each (16 to 64 contiguous bytes,
-// loaded as one vector), all windows' loads are issued before anything depends on them (a single 8 KB window per
-// workgroup left the kernel bound by the latency of that one round trip: 2.1 TB/s), then per window a DPP wave scan +
-// one LDS exchange of the 4 wave totals gives every lane its output position: the selection vector comes out sorted
-// without a second pass.
+// Pushed-down predicate -> ascending window-relative row indices, one selection vector per 2048-row window (the
+// reference sets filter_pushdown = false, src/scanner/read_arrow.cpp:47-48: these are the rows DuckDB's own filter above
+// the scan would keep; a comparison with NULL is false).  The predicate arrives in conjunctive normal form as a kernel
+// argument (FilterProgram, scalar loads): leaves are inclusive ranges on the stored integers (optionally negated),
+// IN-lists and IS [NOT] NULL over decoded fixed-width vectors of any projected column.
+// A workgroup takes kFilterWindows consecutive windows: lane i owns rows [8i, 8i+8) of each (8 to 64 contiguous bytes,
+// loaded as one vector), the loads of all windows of a leaf are issued before anything depends on them (a single 8 KB
+// window per workgroup left the kernel bound by the latency of that one round trip: 2.1 TB/s), then per window a DPP wave
+// scan + one LDS exchange of the 4 wave totals gives every lane its output position: the selection vector comes out
+// sorted without a second pass.
 constexpr int kFilterWindows = 4;
 
 template <typename T>
-__global__ __launch_bounds__(kBlockThreads) void filter_range(const T* __restrict__ values_p,
-                                                              const uint64_t* __restrict__ validity_p, int64_t nrows,
-                                                              int64_t lo, int64_t hi, mi_sel_t* __restrict__ sel_out_p,
-                                                              uint32_t* __restrict__ count_out_p) {
+__device__ __forceinline__ void leaf_compare(const FilterLeafDev& L, int64_t first_window, int64_t nrows, int r,
+                                             uint32_t (&m)[kFilterWindows]) {
   typedef T vec8 __attribute__((ext_vector_type(8)));
   typedef vec8 vec8_a4 __attribute__((aligned(4)));
-  __shared__ uint32_t wave_total[kFilterWindows][kBlockThreads / 64];
-  gptr<const T> values = GC<T>(values_p);
-  gptr<const uint64_t> validity = GC<uint64_t>(validity_p);
-  gptr<mi_sel_t> sel_out = GM<mi_sel_t>(sel_out_p);
-  gptr<uint32_t> count_out = GM<uint32_t>(count_out_p);
-  const int64_t first_window = static_cast<int64_t>(blockIdx.x) * kFilterWindows;
-  const int r = 8 * threadIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t mask[kFilterWindows];
+  gptr<const T> values = GC<T>(L.data);
+  const bool is_unsigned = (L.flags & kLeafUnsigned) != 0;
+  const int64_t bias = (L.flags & kLeafBias) ? static_cast<int64_t>(0x8000000000000000ull) : 0;  // uint64: order-preserving map to int64
+  int64_t x[kFilterWindows][8];
 #pragma unroll
   for (int w = 0; w < kFilterWindows; w++) {
     const int64_t row0 = (first_window + w) * kTileRows;
     const int64_t left = nrows - row0;
     const int n = left < kTileRows ? static_cast<int>(left < 0 ? 0 : left) : kTileRows;
-    uint32_t m = 0;
     if (r + 8 <= n) {
-      const uint32_t vbits = validity ? static_cast<uint32_t>((validity[(row0 + r) >> 6] >> ((row0 + r) & 63)) & 0xFF) : 0xFFu;
       const vec8 v = __builtin_nontemporal_load((gptr<const vec8_a4>)(values + row0 + r));
 #pragma unroll
       for (int k = 0; k < 8; k++) {
-        const int64_t x = static_cast<int64_t>(v[k]);
-        if (x >= lo && x < hi) m |= 1u << k;
+        typedef typename std::make_unsigned<T>::type UT;
+        x[w][k] = (is_unsigned ? static_cast<int64_t>(static_cast<uint64_t>(static_cast<UT>(v[k]))) : static_cast<int64_t>(v[k])) ^ bias;
       }
-      m &= vbits;
-    } else if (r < n) {  // the table's last, partial vector
-      const uint32_t vbits = validity ? static_cast<uint32_t>((validity[(row0 + r) >> 6] >> ((row0 + r) & 63)) & 0xFF) : 0xFFu;
-      for (int k = 0; r + k < n; k++) {
-        const int64_t x = static_cast<int64_t>(values[row0 + r + k]);
-        if (x >= lo && x < hi) m |= 1u << k;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        typedef typename std::make_unsigned<T>::type UT;
+        const T v = r + k < n ? values[row0 + r + k] : T(0);
+        x[w][k] = (is_unsigned ? static_cast<int64_t>(static_cast<uint64_t>(static_cast<UT>(v))) : static_cast<int64_t>(v)) ^ bias;
       }
-      m &= vbits;
     }
-    mask[w] = m;
+  }
+  if (L.op == kLeafRange) {
+#pragma unroll
+    for (int w = 0; w < kFilterWindows; w++) {
+      uint32_t mm = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) mm |= (x[w][k] >= L.lo && x[w][k] <= L.hi) ? (1u << k) : 0u;
+      m[w] = mm;
+    }
+  } else {  // kLeafIn: the list is small and uniform (scalar loads)
+#pragma unroll
+    for (int w = 0; w < kFilterWindows; w++) m[w] = 0;
+    for (int j = 0; j < L.n_in; j++) {
+      const int64_t c = L.in_values[j];
+#pragma unroll
+      for (int w = 0; w < kFilterWindows; w++)
+#pragma unroll
+        for (int k = 0; k < 8; k++) m[w] |= (x[w][k] == c) ? (1u << k) : 0u;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlockThreads) void filter_program(const FilterProgram prog, int64_t nrows,
+                                                                mi_sel_t* __restrict__ sel_out_p,
+                                                                uint32_t* __restrict__ count_out_p) {
+  __shared__ uint32_t wave_total[kFilterWindows][kBlockThreads / 64];
+  gptr<mi_sel_t> sel_out = GM<mi_sel_t>(sel_out_p);
+  gptr<uint32_t> count_out = GM<uint32_t>(count_out_p);
+  const int64_t first_window = static_cast<int64_t>(blockIdx.x) * kFilterWindows;
+  const int r = 8 * threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t acc[kFilterWindows], clause[kFilterWindows];
+#pragma unroll
+  for (int w = 0; w < kFilterWindows; w++) {
+    const int64_t left = nrows - (first_window + w) * kTileRows - r;  // rows of this lane's group that exist
+    acc[w] = left >= 8 ? 0xFFu : (left <= 0 ? 0u : ((1u << left) - 1u));
+    clause[w] = 0;
+  }
+#pragma clang loop unroll(disable)
+  for (int l = 0; l < prog.n_leaves; l++) {
+    const FilterLeafDev& L = prog.leaves[l];
+    uint32_t vb[kFilterWindows];
+#pragma unroll
+    for (int w = 0; w < kFilterWindows; w++) {
+      const int64_t row = (first_window + w) * kTileRows + r;  // multiple of 8: the 8 bits sit in one word
+      vb[w] = (L.validity != nullptr && row < nrows) ? static_cast<uint32_t>((GC<uint64_t>(L.validity)[row >> 6] >> (row & 63)) & 0xFF) : 0xFFu;
+    }
+    uint32_t m[kFilterWindows];
+    if (L.op == kLeafIsNull || L.op == kLeafIsNotNull) {
+#pragma unroll
+      for (int w = 0; w < kFilterWindows; w++) m[w] = L.op == kLeafIsNull ? (~vb[w] & 0xFFu) : vb[w];
+    } else {
+      switch (L.width) {
+        case 1: leaf_compare<int8_t>(L, first_window, nrows, r, m); break;
+        case 2: leaf_compare<int16_t>(L, first_window, nrows, r, m); break;
+        case 4: leaf_compare<int32_t>(L, first_window, nrows, r, m); break;
+        default: leaf_compare<int64_t>(L, first_window, nrows, r, m); break;
+      }
+#pragma unroll
+      for (int w = 0; w < kFilterWindows; w++) {
+        if (L.flags & kLeafNegate) m[w] = ~m[w] & 0xFFu;
+        m[w] &= vb[w];  // a comparison with NULL is not true
+      }
+    }
+#pragma unroll
+    for (int w = 0; w < kFilterWindows; w++) {
+      clause[w] |= m[w];
+      if (L.flags & kLeafEndsClause) {
+        acc[w] &= clause[w];
+        clause[w] = 0;
+      }
+    }
   }
   uint32_t incl[kFilterWindows];
 #pragma unroll
   for (int w = 0; w < kFilterWindows; w++) {
-    incl[w] = wave_inclusive_scan_u32(__builtin_popcount(mask[w]));
+    incl[w] = wave_inclusive_scan_u32(__builtin_popcount(acc[w]));
     if (lane == 63) wave_total[w][wave] = incl[w];
   }
   __syncthreads();
@@ -76,12 +143,12 @@ __global__ __launch_bounds__(kBlockThreads) void filter_range(const T* __restric
       if (i < wave) base += x;
       total += x;
     }
-    uint32_t pos = base + incl[w] - __builtin_popcount(mask[w]);
+    uint32_t pos = base + incl[w] - __builtin_popcount(acc[w]);
     gptr<mi_sel_t> out = sel_out + window * kTileRows;
-    uint32_t m = mask[w];
-    while (m) {  // ascending set bits
-      const int k = __builtin_ctz(m);
-      m &= m - 1;
+    uint32_t mm = acc[w];
+    while (mm) {  // ascending set bits
+      const int k = __builtin_ctz(mm);
+      mm &= mm - 1;
       out[pos++] = static_cast<mi_sel_t>(r + k);
     }
     if (threadIdx.x == 0) count_out[window] = total;
@@ -140,6 +207,7 @@ __global__ __launch_bounds__(kBlockThreads) void agg_sum_product(AggSumProductAr
 }  // namespace
 
 hipError_t LaunchAggSumProduct(const AggSumProductArgs& args, unsigned long long* d_acc, int num_cus, hipStream_t stream) {
+  MI_DROP_STALE_ERROR();
   if (args.nrows <= 0) return hipSuccess;
   const int64_t want = (args.nrows + kBlockThreads * 8 - 1) / (kBlockThreads * 8);   // ~8 rows per lane
   const uint32_t grid = static_cast<uint32_t>(std::min<int64_t>(want, static_cast<int64_t>(num_cus) * 16));
@@ -147,31 +215,34 @@ hipError_t LaunchAggSumProduct(const AggSumProductArgs& args, unsigned long long
   return hipGetLastError();
 }
 
-hipError_t LaunchFilterRange(const void* values, int32_t width, const void* validity, int64_t nrows, int64_t lo,
-                             int64_t hi, mi_sel_t* sel_out, uint32_t* count_out, hipStream_t stream) {
+hipError_t LaunchFilterProgram(const FilterProgram& prog, int64_t nrows, mi_sel_t* sel_out, uint32_t* count_out, hipStream_t stream) {
+  MI_DROP_STALE_ERROR();
   if (nrows <= 0) return hipSuccess;
+  if (prog.n_leaves < 0 || prog.n_leaves > kMaxFilterLeaves) return hipErrorInvalidValue;
   const int64_t windows = (nrows + kTileRows - 1) / kTileRows;
   const uint32_t grid = static_cast<uint32_t>((windows + kFilterWindows - 1) / kFilterWindows);
-  const uint64_t* v = static_cast<const uint64_t*>(validity);
-  switch (width) {
-    case 4:
-      hipLaunchKernelGGL(filter_range<int32_t>, dim3(grid), dim3(kBlockThreads), 0, stream,
-                         static_cast<const int32_t*>(values), v, nrows, lo, hi, sel_out, count_out);
-      break;
-    case 8:
-      hipLaunchKernelGGL(filter_range<int64_t>, dim3(grid), dim3(kBlockThreads), 0, stream,
-                         static_cast<const int64_t*>(values), v, nrows, lo, hi, sel_out, count_out);
-      break;
-    case 2:
-      hipLaunchKernelGGL(filter_range<int16_t>, dim3(grid), dim3(kBlockThreads), 0, stream,
-                         static_cast<const int16_t*>(values), v, nrows, lo, hi, sel_out, count_out);
-      break;
-    default:
-      return hipErrorInvalidValue;
-  }
+  hipLaunchKernelGGL(filter_program, dim3(grid), dim3(kBlockThreads), 0, stream, prog, nrows, sel_out, count_out);
   return hipGetLastError();
 }
 
+hipError_t LaunchFilterRange(const void* values, int32_t width, const void* validity, int64_t nrows, int64_t lo,
+                             int64_t hi, mi_sel_t* sel_out, uint32_t* count_out, hipStream_t stream) {
+  MI_DROP_STALE_ERROR();
+  if (width != 1 && width != 2 && width != 4 && width != 8) return hipErrorInvalidValue;
+  FilterProgram prog;
+  memset(&prog, 0, sizeof(prog));
+  prog.n_leaves = 1;
+  FilterLeafDev& L = prog.leaves[0];
+  L.data = values;
+  L.validity = static_cast<const uint64_t*>(validity);
+  L.op = kLeafRange;
+  L.width = width;
+  L.flags = kLeafEndsClause;
+  L.lo = lo;
+  L.hi = hi == INT64_MIN ? hi : hi - 1;  // lo <= v < hi as an inclusive range
+  if (hi == INT64_MIN) { L.lo = 1; L.hi = 0; }  // nothing is < INT64_MIN
+  return LaunchFilterProgram(prog, nrows, sel_out, count_out, stream);
+}
 
 }  // namespace device
 }  // namespace miarrow

@@ -10,7 +10,7 @@
 namespace miarrow {
 
 int WrapC(const std::function<void()>& f);  // c_api.cpp
-struct mi_ctx_fwd;
+void EnsureIoThreads(int n);                // ipc_stream_reader.cpp
 
 namespace {
 constexpr size_t kAlign = 256;
@@ -43,6 +43,8 @@ mi_string_t MakeHostString(const std::string& s) {
   }
   return r;
 }
+
+int PipelineDepth(const mi_scan_options& o) { return std::max(2, std::min(16, o.pipeline_depth > 0 ? o.pipeline_depth : 3)); }
 }  // namespace
 
 ArrowScan::ArrowScan(Context* ctx_p, std::vector<std::string> paths, const mi_scan_options& o) : ctx(ctx_p), opts(o) {
@@ -52,12 +54,16 @@ ArrowScan::ArrowScan(Context* ctx_p, std::vector<std::string> paths, const mi_sc
     s.path = p;
     sources.push_back(std::move(s));
   }
+  slots.resize(static_cast<size_t>(PipelineDepth(opts)));
+  staging.resize(slots.size() + kReadAhead + 1);
 }
 
 ArrowScan::ArrowScan(Context* ctx_p, std::vector<ArrowIPCBuffer> buffers_p, const mi_scan_options& o)
     : ctx(ctx_p), opts(o), buffers(std::move(buffers_p)), is_buffers(true) {
   Source s;
   sources.push_back(std::move(s));
+  slots.resize(static_cast<size_t>(PipelineDepth(opts)));
+  staging.resize(slots.size() + kReadAhead + 1);
 }
 
 ArrowScan::~ArrowScan() {
@@ -71,16 +77,22 @@ ArrowScan::~ArrowScan() {
   (void)hipStreamSynchronize(ctx->d2h_stream);
   for (auto& s : slots) {
     s.batch = DecodedBatch();  // returns the staging lease
+    s.plan.reset();
+    s.gather_plan.reset();
     if (s.d_in) (void)hipFree(s.d_in);
     if (s.d_out) (void)hipFree(s.d_out);
     if (s.h_out) (void)hipHostFree(s.h_out);
     if (s.h_status) (void)hipHostFree(s.h_status);
+    if (s.h_counts) (void)hipHostFree(s.h_counts);
     if (s.h_aux) (void)hipHostFree(s.h_aux);
     if (s.d_aux) (void)hipFree(s.d_aux);
     if (s.h2d_done) (void)hipEventDestroy(s.h2d_done);
     if (s.compute_done) (void)hipEventDestroy(s.compute_done);
     if (s.d2h_done) (void)hipEventDestroy(s.d2h_done);
+    if (s.filter_done) (void)hipEventDestroy(s.filter_done);
   }
+  for (void* p : d_in_lists)
+    if (p) (void)hipFree(p);
   dicts.clear();
   fetched.clear();
   for (auto& st : staging)
@@ -160,9 +172,24 @@ const std::vector<ScanColumn>& ArrowScan::Bind() {
   return all_columns;
 }
 
+void ArrowScan::SetFilter(FilterCnf cnf) {
+  if (initialized) throw InvalidInputException("set the filter before mi_scan_init");
+  if (has_filter) {  // a second filter is ANDed with the first
+    filter.insert(filter.end(), cnf.begin(), cnf.end());
+  } else {
+    filter = std::move(cnf);
+  }
+  size_t leaves = 0;
+  for (auto& c : filter) leaves += c.size();
+  if (leaves > static_cast<size_t>(device::kMaxFilterLeaves))
+    throw NotImplementedException("filter needs more than " + std::to_string(device::kMaxFilterLeaves) + " leaves");
+  has_filter = true;
+}
+
 void ArrowScan::Init(const std::vector<std::string>& projected) {
   Bind();
   out_columns.clear();
+  filter_only_columns.clear();
   if (projected.empty()) {
     out_columns = all_columns;
   } else {
@@ -184,41 +211,104 @@ void ArrowScan::Init(const std::vector<std::string>& projected) {
     }
   }
   all_valid.assign(MI_VECTOR_SIZE / 64, ~0ull);
-  const_vectors.assign(out_columns.size(), {});
-  chunk_vectors.assign(out_columns.size(), mi_vector{});
-  if (has_filter) {
-    filter_out_col = -1;
-    for (size_t i = 0; i < out_columns.size(); i++)
-      if (out_columns[i].name == filter_column) filter_out_col = static_cast<int>(i);
-    if (filter_out_col < 0) throw InvalidInputException("filter column '" + filter_column + "' is not in the projection");
-    int32_t kind, w, nb;
-    int64_t param;
-    out_columns[static_cast<size_t>(filter_out_col)].field.Plan(&kind, &param, &w, &nb);
-    if ((kind != MI_K_COPY && kind != MI_K_DEC128 && kind != MI_K_DATE64) || (w != 2 && w != 4 && w != 8) ||
-        out_columns[static_cast<size_t>(filter_out_col)].field.type == MI_AT_FLOAT) {
-      throw NotImplementedException("range filter pushdown needs an integer / date / decimal(<=18) column");
-    }
-  }
   ctx->Bind();
-  for (auto& s : slots) {
-    if (!s.h2d_done) {
-      MI_HIP_CHECK(hipEventCreateWithFlags(&s.h2d_done, hipEventDisableTiming));
-      MI_HIP_CHECK(hipEventCreateWithFlags(&s.compute_done, hipEventDisableTiming));
-      MI_HIP_CHECK(hipEventCreateWithFlags(&s.d2h_done, hipEventDisableTiming));
-      s.plan = std::make_unique<Plan>(ctx);
-      MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.h_status), 64, hipHostMallocDefault));
-      *s.h_status = 0;
+  compact = false;
+  if (has_filter) {
+    // resolve the leaves: a filter column is either projected (its decoded vector is reused) or decoded for the filter alone
+    filter_columns.clear();
+    std::vector<std::string> filter_names;
+    for (auto& clause : filter) {
+      for (auto& leaf : clause) {
+        auto known = std::find(filter_names.begin(), filter_names.end(), leaf.column);
+        if (known == filter_names.end()) {
+          int32_t where = -1;
+          for (size_t i = 0; i < out_columns.size(); i++)
+            if (out_columns[i].name == leaf.column) where = static_cast<int32_t>(i);
+          if (where < 0) {
+            auto it = std::find_if(all_columns.begin(), all_columns.end(), [&](const ScanColumn& sc) { return sc.name == leaf.column; });
+            if (it == all_columns.end()) throw InvalidInputException("filter column '" + leaf.column + "' does not exist in IPC file schema");
+            filter_only_columns.push_back(*it);
+            where = ~static_cast<int32_t>(filter_only_columns.size() - 1);
+          }
+          filter_names.push_back(leaf.column);
+          filter_columns.push_back(where);
+          known = filter_names.end() - 1;
+        }
+        leaf.out_col = static_cast<int32_t>(known - filter_names.begin());
+        const int32_t where = filter_columns[static_cast<size_t>(leaf.out_col)];
+        const ScanColumn& sc = where >= 0 ? out_columns[static_cast<size_t>(where)] : filter_only_columns[static_cast<size_t>(~where)];
+        if (sc.is_filename || sc.is_hive) throw NotImplementedException("filter on the constant column '" + sc.name + "' is not pushed into the scan");
+        if (leaf.op == device::kLeafIsNull || leaf.op == device::kLeafIsNotNull) {
+          std::string why;
+          if (!sc.field.Supported(&why)) throw NotImplementedException("Column '" + sc.name + "': " + why + " is not decoded by the MI355X scan path yet");
+          continue;
+        }
+        int32_t kind, w, nb;
+        int64_t param;
+        const bool ok = sc.field.Plan(&kind, &param, &w, &nb) && !sc.field.has_dictionary &&
+                        (kind == MI_K_COPY || kind == MI_K_DEC128 || kind == MI_K_DATE64 || kind == MI_K_MUL_I32 || kind == MI_K_MUL_I64 ||
+                         kind == MI_K_DIV_I64 || kind == MI_K_NARROW || kind == MI_K_BOOL) &&
+                        (w == 1 || w == 2 || w == 4 || w == 8) && sc.field.type != MI_AT_FLOAT;
+        if (!ok)
+          throw NotImplementedException("filter pushdown on column '" + sc.name + "' (" + sc.field.DuckType() +
+                                        ") needs an integer / boolean / date / time / timestamp / decimal(<=18) column");
+      }
+    }
+    // IN-lists live in HBM for the lifetime of the scan
+    for (void* p : d_in_lists)
+      if (p) (void)hipFree(p);
+    d_in_lists.clear();
+    for (auto& clause : filter)
+      for (auto& leaf : clause) {
+        void* p = nullptr;
+        if (leaf.op == device::kLeafIn) {
+          MI_HIP_CHECK(hipMalloc(&p, leaf.in_values.size() * 8));
+          MI_HIP_CHECK(hipMemcpy(p, leaf.in_values.data(), leaf.in_values.size() * 8, hipMemcpyHostToDevice));
+        }
+        d_in_lists.push_back(p);
+      }
+    if (opts.filter_compact) {
+      for (auto& c : out_columns) {
+        if (c.is_filename || c.is_hive) continue;
+        int32_t kind, w, nb;
+        int64_t param;
+        c.field.Plan(&kind, &param, &w, &nb);
+        if (!device::KindCanGather(kind) || !c.field.children.empty())
+          throw NotImplementedException("filter_compact needs flat projected columns: '" + c.name + "' (" + c.field.DuckType() +
+                                        ") is decoded window by window, use the selection vector instead");
+      }
+      compact = true;
     }
   }
+  for (auto& s : slots) InitSlot(s);
   initialized = true;
 }
 
-void ArrowScan::SetFilterRange(const std::string& column, int64_t lo, int64_t hi) {
-  if (initialized) throw InvalidInputException("set the filter before mi_scan_init");
-  has_filter = true;
-  filter_column = column;
-  filter_lo = lo;
-  filter_hi = hi;
+void ArrowScan::InitSlot(Slot& s) {
+  if (s.h2d_done) return;
+  ctx->Bind();
+  MI_HIP_CHECK(hipEventCreateWithFlags(&s.h2d_done, hipEventDisableTiming));
+  MI_HIP_CHECK(hipEventCreateWithFlags(&s.compute_done, hipEventDisableTiming));
+  MI_HIP_CHECK(hipEventCreateWithFlags(&s.d2h_done, hipEventDisableTiming));
+  MI_HIP_CHECK(hipEventCreateWithFlags(&s.filter_done, hipEventDisableTiming));
+  s.plan = std::make_unique<Plan>(ctx);
+  s.gather_plan = std::make_unique<Plan>(ctx);
+  MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.h_status), 64, hipHostMallocDefault));
+  s.h_status[0] = s.h_status[1] = 0;
+}
+
+// More record batches in flight / held by the caller at once (the COPY pump hands whole batches to several sink threads).
+// Only before the first batch has been requested: the read-ahead thread sizes its staging ring from the slot count.
+void ArrowScan::EnsurePipelineDepth(int depth) {
+  depth = std::min(depth, 16);
+  if (static_cast<int>(slots.size()) >= depth) return;
+  if (producer_started || !inflight.empty()) throw InvalidInputException("the pipeline depth can only grow before the scan has started");
+  std::vector<Slot> bigger(static_cast<size_t>(depth));
+  for (size_t i = 0; i < slots.size(); i++) bigger[i] = std::move(slots[i]);
+  slots = std::move(bigger);
+  staging.resize(slots.size() + kReadAhead + 1);
+  if (initialized)
+    for (auto& s : slots) InitSlot(s);
 }
 
 void ArrowScan::EnsureSlotBuffers(Slot& s, size_t in_bytes, size_t out_bytes) {
@@ -236,12 +326,15 @@ void ArrowScan::EnsureSlotBuffers(Slot& s, size_t in_bytes, size_t out_bytes) {
     s.d_out_cap = RoundUp(grow(out_bytes, s.d_out_cap), 1 << 16);
     MI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s.d_out), s.d_out_cap));
   }
-  if (!opts.device_resident && out_bytes > s.h_out_cap) {
-    if (s.h_out) MI_HIP_CHECK(hipHostFree(s.h_out));
-    s.h_out = nullptr;
-    s.h_out_cap = RoundUp(grow(out_bytes, s.h_out_cap), 1 << 16);
-    MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.h_out), s.h_out_cap, hipHostMallocDefault));
-  }
+}
+
+void ArrowScan::EnsureHostOut(Slot& s, size_t bytes) {
+  if (opts.device_resident || bytes <= s.h_out_cap) return;
+  ctx->Bind();
+  if (s.h_out) MI_HIP_CHECK(hipHostFree(s.h_out));
+  s.h_out = nullptr;
+  s.h_out_cap = RoundUp(std::max(bytes, s.h_out_cap + s.h_out_cap / 2), 1 << 16);
+  MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.h_out), s.h_out_cap, hipHostMallocDefault));
 }
 
 ArrowScan::Slot* ArrowScan::FreeSlot() {
@@ -252,6 +345,7 @@ ArrowScan::Slot* ArrowScan::FreeSlot() {
 
 void ArrowScan::DecodeDictionary(Source& src, const DecodedBatch& b) {
   ctx->Bind();
+  (void)src;
   if (b.column_node.empty() || b.nodes.empty()) throw InternalException("DictionaryBatch without a value node");
   const ArrowField& f = *b.nodes[static_cast<size_t>(b.column_node[0])].field;  // the field that carries the id (any depth)
   int32_t kind, w, nb;
@@ -353,253 +447,233 @@ void ArrowScan::DecodeDictionary(Source& src, const DecodedBatch& b) {
   dicts[b.dict_id] = d;
 }
 
-// One field node (and, recursively, its children) of a record batch: output slots + the transcode task.
-// `win` = first row of every top-level 2048-row chunk window in this node's row space (+ the end): top-level columns and
-// struct children of them have win[k] = 2048k (the tiles themselves); the child of a list starts its window k at
-// offsets[win[k]], the child of a fixed_size_list at size * win[k].
-int32_t ArrowScan::AddNode(Slot& s, const DecodedBatch& b, int32_t ni, std::vector<int64_t> win, bool win_is_tiles,
-                           int64_t parent_valid_off, int32_t parent_div, size_t* off, std::vector<mi_col_task>* tasks,
-                           std::vector<uint64_t>* aux, std::vector<std::pair<size_t, size_t>>* aux_fixups) {
-  const DecodedNode& nd = b.nodes[static_cast<size_t>(ni)];
-  int32_t kind, w, nb;
-  int64_t param;
-  if (!nd.field->Plan(&kind, &param, &w, &nb, nd.value_only))
-    throw NotImplementedException("Arrow type " + nd.field->Format() + " of field '" + nd.field->name + "' is not decoded by the MI355X scan path");
-  const int64_t n = nd.length;
-  const int32_t idx = static_cast<int32_t>(s.node_out.size());
-  s.node_out.emplace_back();
-  {
-    Slot::NodeOut& o = s.node_out.back();
-    o.kind = kind;
-    o.width = w;
-    o.param = param;
-    o.nrows = n;
-    o.arrow_type = nd.field->type;
-    o.win = win;
-    // reference behaviour for plain fixed-width columns: the vector aliases the Arrow buffer (DirectConversion) and an
-    // array without NULLs leaves the ValidityMask unset
-    if (opts.zero_copy_direct && !agg.on && kind == MI_K_COPY && nd.null_count == 0 && parent_valid_off < 0 && nd.spans.size() > 1 &&
-        !(has_filter && nd.depth == 0 && ni == filter_node)) {
-      o.alias = (opts.device_resident ? s.d_in : b.body) + nd.spans[1].offset;
-      if (opts.device_resident) s.upload.emplace_back(nd.spans[1].offset, nd.spans[1].length);
-      return idx;
-    }
-    o.data_off = *off;
-    *off += RoundUp(static_cast<size_t>(n) * static_cast<size_t>(std::max(w, 1)) + 16);
-    o.valid_off = *off;
-    *off += RoundUp(static_cast<size_t>((n + 63) / 64) * 8 + 8);
+// Tables the tasks read from HBM (list windows, string-view buffers) travel in a pinned aux buffer beside the body.
+void ArrowScan::UploadAux(Slot& s, const std::vector<uint64_t>& aux) {
+  const size_t aux_bytes = aux.size() * 8;
+  if (!aux_bytes) return;
+  if (aux_bytes > s.h_aux_cap) {
+    if (s.h_aux) MI_HIP_CHECK(hipHostFree(s.h_aux));
+    if (s.d_aux) MI_HIP_CHECK(hipFree(s.d_aux));
+    s.h_aux_cap = s.d_aux_cap = RoundUp(aux_bytes * 2, 4096);
+    MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.h_aux), s.h_aux_cap, hipHostMallocDefault));
+    MI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s.d_aux), s.d_aux_cap));
   }
-  for (const auto& sp : nd.spans)
-    if (sp.length > 0) s.upload.emplace_back(sp.offset, sp.length);
-  const size_t data_off = s.node_out[static_cast<size_t>(idx)].data_off, valid_off = s.node_out[static_cast<size_t>(idx)].valid_off;
-  auto span = [&](size_t k) { return k < nd.spans.size() ? nd.spans[k] : mi_buffer_span{0, 0}; };
-  auto consumer_addr = [&](int64_t body_offset) {
-    return opts.device_resident ? reinterpret_cast<uint64_t>(s.d_in) + static_cast<uint64_t>(body_offset)
-                                : reinterpret_cast<uint64_t>(b.body) + static_cast<uint64_t>(body_offset);
-  };
-  mi_col_task t;
-  std::memset(&t, 0, sizeof(t));
-  // out_data / out_validity / out_aux hold OFFSETS until the slot's buffers are final (EnqueueBatch rebases them)
-  t.out_data = reinterpret_cast<void*>(data_off);
-  t.out_validity = reinterpret_cast<void*>(valid_off);
-  t.out_aux = reinterpret_cast<void*>(parent_valid_off >= 0 ? static_cast<size_t>(parent_valid_off) + 1 : 0);  // +1: 0 means none
-  t.flags = parent_div;
-  t.depth = nd.depth;
-  t.validity = span(0).length ? s.d_in + span(0).offset : nullptr;
-  t.buf1 = nd.spans.size() > 1 ? s.d_in + span(1).offset : s.d_in;
-  t.nrows = n;
-  t.null_count = nd.null_count;
-  t.kind = kind;
-  t.param = param;
-  std::vector<int64_t> child_win;
-  switch (kind) {
-    case MI_K_STR32: case MI_K_STR64:
-      t.buf2 = s.d_in + span(2).offset;
-      t.buf2_len = span(2).length;
-      t.ptr_base = consumer_addr(span(2).offset);
-      break;
-    case MI_K_FIXED_BINARY:
-      t.ptr_base = consumer_addr(span(1).offset);
-      break;
-    case MI_K_STRVIEW: {
-      const size_t at = aux->size();
-      for (size_t k = 2; k < nd.spans.size(); k++) {
-        aux->push_back(consumer_addr(nd.spans[k].offset));
-        aux->push_back(static_cast<uint64_t>(nd.spans[k].length));
-      }
-      if (nd.spans.size() <= 2) { aux->push_back(0); aux->push_back(0); }
-      t.buf2_len = static_cast<int64_t>(nd.spans.size() > 2 ? nd.spans.size() - 2 : 0);
-      if (n > 0) aux_fixups->emplace_back(tasks->size(), at);  // an empty node gets no task (below): nothing to patch
-      break;
-    }
-    case MI_K_DICT: {
-      auto it = dicts.find(nd.field->dict_id);
-      if (it == dicts.end()) throw IOException("RecordBatch uses dictionary id " + std::to_string(nd.field->dict_id) + " before its DictionaryBatch");
-      s.node_out[static_cast<size_t>(idx)].dict = it->second;
-      t.param2 = it->second->dict_len;
-      break;
-    }
-    case MI_K_LIST32: case MI_K_LIST64: {
-      if (nd.children.size() != 1) throw InternalException("list field without exactly one child");
-      t.param = b.nodes[static_cast<size_t>(nd.children[0])].length;
-      if (!win_is_tiles) {
-        const size_t at = aux->size();
-        for (int64_t r : win) aux->push_back(static_cast<uint64_t>(r));
-        t.buf2_len = static_cast<int64_t>(win.size());
-        if (n > 0) aux_fixups->emplace_back(tasks->size(), at);
-      }
-      // the child's windows start at offsets[win[k]] (read from the host copy of the body)
-      const uint8_t* offs = b.body + span(1).offset;
-      child_win.reserve(win.size());
-      int64_t prev = 0;
-      for (int64_t r : win) {
-        int64_t v = 0;
-        if (n > 0) {
-          if (r < 0 || r > n) throw InternalException("Arrow IPC validation failed: list window outside the column");
-          if (kind == MI_K_LIST32) { int32_t x; std::memcpy(&x, offs + 4 * r, 4); v = x; }
-          else std::memcpy(&v, offs + 8 * r, 8);
-          // the offsets sampled here place the child vectors of every chunk: they are checked on the host (the device
-          // checks all of them, but only flags) so that no window ever points outside the child column
-          if (v < prev || v > t.param)
-            throw InternalException("Arrow IPC validation failed: offsets buffer is not monotonically non-decreasing or exceeds the data buffer");
-          prev = v;
-        }
-        child_win.push_back(v);
-      }
-      break;
-    }
-    default: break;
-  }
-  if (n > 0) tasks->push_back(t);
-  if (kind == MI_K_LIST32 || kind == MI_K_LIST64) {
-    const int32_t c = AddNode(s, b, nd.children[0], child_win, false, -1, 0, off, tasks, aux, aux_fixups);
-    s.node_out[static_cast<size_t>(idx)].children.push_back(c);
-  } else if (kind == MI_K_STRUCT && !nd.children.empty()) {
-    const bool fixed = nd.field->type == MI_AT_FIXED_LIST;
-    const int64_t size = fixed ? param : 1;
-    std::vector<int64_t> cw;
-    for (int64_t r : win) cw.push_back(r * size);
-    for (int32_t cn : nd.children) {
-      const int32_t c = AddNode(s, b, cn, cw, win_is_tiles && !fixed, static_cast<int64_t>(valid_off), static_cast<int32_t>(fixed ? size : 1),
-                                off, tasks, aux, aux_fixups);
-      s.node_out[static_cast<size_t>(idx)].children.push_back(c);
-    }
-  }
-  return idx;
+  std::memcpy(s.h_aux, aux.data(), aux_bytes);
+  MI_HIP_CHECK(hipMemcpyAsync(s.d_aux, s.h_aux, aux_bytes, hipMemcpyHostToDevice, ctx->h2d_stream));
 }
 
+// Stage A of a record batch: H2D of the body, the full-width decode tasks (every projected column; with compaction only
+// the filter columns), the filter, the fused aggregate and -- unless the batch is compacted, which needs the selected row
+// count on the host first (stage B) -- the copy back.
 void ArrowScan::EnqueueBatch(Slot& s) {
   ctx->Bind();
   const DecodedBatch& b = s.batch;
   Source& src = sources[static_cast<size_t>(s.source)];
   const int64_t n = b.length;
   s.nrows = n;
-  std::vector<int64_t> top_win;
-  for (int64_t r = 0; r < n; r += MI_VECTOR_SIZE) top_win.push_back(r);
-  top_win.push_back(n);
-  if (n == 0) top_win.push_back(0);
-  // output layout + tasks (offsets first, rebased once the slot buffers are sized)
-  size_t off = 0;
-  s.node_out.clear();
-  s.col_root.assign(out_columns.size(), -1);
-  s.col_data_off.assign(out_columns.size(), 0);
-  s.col_valid_off.assign(out_columns.size(), 0);
-  std::vector<int32_t> widths(out_columns.size(), 0);
-  std::vector<mi_col_task> tasks;
-  std::vector<uint64_t> aux;
-  std::vector<std::pair<size_t, size_t>> aux_fixups;  // (task index, first aux word)
-  s.upload.clear();
-  filter_node = -1;
-  if (has_filter && src.out_to_file_column[static_cast<size_t>(filter_out_col)] >= 0)
-    filter_node = b.column_node[static_cast<size_t>(src.out_to_file_column[static_cast<size_t>(filter_out_col)])];
+  s.compact = compact && n > 0;
+  s.needs_stage_b = false;
+  const int64_t n_windows = (n + MI_VECTOR_SIZE - 1) / MI_VECTOR_SIZE;
   // d_in must be final before tasks take addresses inside it
   EnsureSlotBuffers(s, static_cast<size_t>(b.body_size) + 64, 0);
-  for (size_t c = 0; c < out_columns.size(); c++) {
-    if (out_columns[c].is_filename || out_columns[c].is_hive) continue;
-    const int32_t fc = src.out_to_file_column[c];
-    int32_t kind, nb;
-    int64_t param;
-    out_columns[c].field.Plan(&kind, &param, &widths[c], &nb);
-    if (fc < 0) {  // column absent in this file (union_by_name): an all-NULL vector
-      s.col_data_off[c] = off;
-      off += RoundUp(static_cast<size_t>(n) * static_cast<size_t>(std::max(widths[c], 1)) + 16);
-      s.col_valid_off[c] = off;
-      off += RoundUp(static_cast<size_t>((n + 63) / 64) * 8 + 8);
-      continue;
+
+  PlannerOptions po;
+  po.array_align = kAlign;
+  const bool zero_copy = opts.zero_copy_direct > 0 || (opts.zero_copy_direct == 0 && opts.device_resident);
+  po.zero_copy_direct = zero_copy && !agg.on && !s.compact;
+  po.unset_all_valid = opts.unset_all_valid != 0;
+  s.planner.opts = po;
+  s.planner.Clear();
+  s.col_root.assign(out_columns.size(), -1);
+  s.absent.assign(out_columns.size(), {0, 0});
+  s.filter_root.assign(filter_columns.size(), -1);
+  s.node_dict.clear();
+
+  BatchPlacement where;
+  where.batch = &b;
+  where.in_base = s.d_in;
+  where.consumer_base = opts.device_resident ? reinterpret_cast<uint64_t>(s.d_in) : reinterpret_cast<uint64_t>(b.body);
+  where.dict_len = [&](int64_t id) -> int64_t {
+    auto it = dicts.find(id);
+    if (it == dicts.end()) throw IOException("RecordBatch uses dictionary id " + std::to_string(id) + " before its DictionaryBatch");
+    return it->second->dict_len;
+  };
+  // filter columns read their decoded vectors from HBM: never aliased into a body that may not even be uploaded
+  std::vector<char> no_alias(b.nodes.size(), 0);
+  if (has_filter) {
+    for (size_t k = 0; k < filter_columns.size(); k++) {
+      const int32_t wc = filter_columns[k];
+      const int32_t fc = wc >= 0 ? src.out_to_file_column[static_cast<size_t>(wc)] : src.filter_to_file_column[static_cast<size_t>(~wc)];
+      if (fc >= 0) no_alias[static_cast<size_t>(b.column_node[static_cast<size_t>(fc)])] = 1;
     }
-    s.col_root[c] = AddNode(s, b, b.column_node[static_cast<size_t>(fc)], top_win, true, -1, 0, &off, &tasks, &aux, &aux_fixups);
-    s.col_data_off[c] = s.node_out[static_cast<size_t>(s.col_root[c])].data_off;
-    s.col_valid_off[c] = s.node_out[static_cast<size_t>(s.col_root[c])].valid_off;
+    where.no_alias = &no_alias;
+  }
+  std::vector<int32_t> widths(out_columns.size(), 0);
+  auto width_of = [](const ScanColumn& c) {
+    int32_t kind, w, nb;
+    int64_t param;
+    c.field.Plan(&kind, &param, &w, &nb);
+    return w;
+  };
+  // ---- layout.  Full decode: [projected columns | sel | counts] travel back, then the filter-only columns.
+  //      Compaction (stage A): only the filter columns + sel + counts; the projected columns are planned in stage B.
+  if (!s.compact) {
+    for (size_t c = 0; c < out_columns.size(); c++) {
+      if (out_columns[c].is_filename || out_columns[c].is_hive) continue;
+      widths[c] = width_of(out_columns[c]);
+      const int32_t fc = src.out_to_file_column[c];
+      if (fc < 0) {  // column absent in this file (union_by_name): an all-NULL vector
+        s.absent[c] = s.planner.AddAbsentColumn(n, widths[c]);
+        continue;
+      }
+      s.col_root[c] = s.planner.AddColumn(where, b.column_node[static_cast<size_t>(fc)]);
+    }
   }
   if (has_filter) {
-    s.sel_off = off;
-    off += RoundUp(static_cast<size_t>(n) * 4 + 16);
-    s.sel_count_off = off;
-    off += RoundUp(static_cast<size_t>((n + MI_VECTOR_SIZE - 1) / MI_VECTOR_SIZE) * 4 + 16);
+    s.sel_off = s.planner.Reserve(static_cast<size_t>(n) * 4 + 16);
+    s.sel_count_off = s.planner.Reserve(static_cast<size_t>(n_windows) * 4 + 16);
   }
-  EnsureSlotBuffers(s, static_cast<size_t>(b.body_size) + 64, off + 64);
-  // small tables (list windows, string-view buffers) ride in a pinned aux buffer
-  const size_t aux_bytes = aux.size() * 8;
-  if (aux_bytes) {
-    if (aux_bytes > s.h_aux_cap) {
-      if (s.h_aux) MI_HIP_CHECK(hipHostFree(s.h_aux));
-      if (s.d_aux) MI_HIP_CHECK(hipFree(s.d_aux));
-      s.h_aux_cap = s.d_aux_cap = RoundUp(aux_bytes * 2, 4096);
-      MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.h_aux), s.h_aux_cap, hipHostMallocDefault));
-      MI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s.d_aux), s.d_aux_cap));
+  s.d2h_bytes = s.compact ? 0 : s.planner.arena_bytes;
+  if (has_filter) {
+    for (size_t k = 0; k < filter_columns.size(); k++) {
+      const int32_t wc = filter_columns[k];
+      if (wc >= 0 && !s.compact) {
+        s.filter_root[k] = s.col_root[static_cast<size_t>(wc)];
+        continue;
+      }
+      const int32_t fc = wc >= 0 ? src.out_to_file_column[static_cast<size_t>(wc)] : src.filter_to_file_column[static_cast<size_t>(~wc)];
+      if (fc >= 0) s.filter_root[k] = s.planner.AddColumn(where, b.column_node[static_cast<size_t>(fc)]);
     }
-    std::memcpy(s.h_aux, aux.data(), aux_bytes);
   }
-  for (auto& t : tasks) {
-    t.out_data = s.d_out + reinterpret_cast<size_t>(t.out_data);
-    t.out_validity = s.d_out + reinterpret_cast<size_t>(t.out_validity);
-    const size_t pv = reinterpret_cast<size_t>(t.out_aux);
-    t.out_aux = pv ? s.d_out + (pv - 1) : nullptr;
+  s.stage_a_bytes = s.planner.arena_bytes;
+  s.node_dict.resize(s.planner.nodes.size());
+  for (size_t i = 0; i < s.planner.nodes.size(); i++)
+    if (s.planner.nodes[i].dict_id >= 0) s.node_dict[i] = dicts[s.planner.nodes[i].dict_id];
+  // worst case for stage B: every row selected
+  size_t stage_b_worst = 0;
+  if (s.compact) {
+    stage_b_worst = 4096;
+    for (auto& c : out_columns)
+      if (!c.is_filename && !c.is_hive)
+        stage_b_worst += RoundUp(static_cast<size_t>(n) * static_cast<size_t>(std::max(width_of(c), 1)) + 16) + RoundUp(static_cast<size_t>((n + 63) / 64) * 8 + 8);
   }
-  for (auto& fx : aux_fixups) tasks[fx.first].buf2 = s.d_aux + fx.second * 8;
-  // H2D of the body (+ tables) on the copy stream
+  EnsureSlotBuffers(s, static_cast<size_t>(b.body_size) + 64, s.stage_a_bytes + stage_b_worst + 64);
+  EnsureHostOut(s, s.d2h_bytes + 64);
+  if (static_cast<size_t>(n_windows + 1) * 4 > s.h_counts_cap) {
+    if (s.h_counts) MI_HIP_CHECK(hipHostFree(s.h_counts));
+    s.h_counts_cap = RoundUp(static_cast<size_t>(n_windows + 1) * 8, 4096);
+    MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.h_counts), s.h_counts_cap, hipHostMallocDefault));
+  }
+  UploadAux(s, s.planner.aux);
+  s.planner.Rebase(0, s.d_out, s.d_aux);
+
+  // ---- H2D of the body on the copy stream: only what the kernels read (projected columns; with zero_copy_direct not even
+  // all of those): merge the buffer ranges, gaps below 64 KiB are cheaper to copy than to split.  A full scan is one copy.
+  std::vector<std::pair<int64_t, int64_t>> upload = s.planner.upload;
+  if (opts.device_resident)  // aliased vectors of a GPU consumer point into the HBM copy of the body
+    for (auto& nd : s.planner.nodes)
+      if (nd.alias_body_off >= 0) upload.emplace_back(nd.alias_body_off, nd.nrows * nd.width);
+  if (s.compact) {  // stage B reads every projected column
+    for (size_t c = 0; c < out_columns.size(); c++) {
+      const int32_t fc = (out_columns[c].is_filename || out_columns[c].is_hive) ? -1 : src.out_to_file_column[c];
+      if (fc < 0) continue;
+      for (const auto& sp : b.nodes[static_cast<size_t>(b.column_node[static_cast<size_t>(fc)])].spans)
+        if (sp.length > 0) upload.emplace_back(sp.offset, sp.length);
+    }
+  }
   if (b.body_size > 0) {
-    {
-      // only what the kernels read (projected columns; with zero_copy_direct not even all of those): merge the buffer
-      // ranges, gaps below 64 KiB are cheaper to copy than to split.  A full scan is one copy of the whole body.
-      std::sort(s.upload.begin(), s.upload.end());
-      int64_t lo = -1, hi = -1;
-      auto flush = [&]() {
-        if (lo < 0) return;
-        hi = std::min<int64_t>((hi + 63) & ~int64_t(63), b.body_size);
-        MI_HIP_CHECK(hipMemcpyAsync(s.d_in + lo, b.body + lo, static_cast<size_t>(hi - lo), hipMemcpyHostToDevice, ctx->h2d_stream));
-      };
-      for (const auto& r : s.upload) {
-        if (lo >= 0 && r.first <= hi + (64 << 10)) {
-          hi = std::max(hi, r.first + r.second);
-          continue;
-        }
-        flush();
-        lo = r.first & ~int64_t(63);
-        hi = r.first + r.second;
+    std::sort(upload.begin(), upload.end());
+    int64_t lo = -1, hi = -1;
+    auto flush = [&]() {
+      if (lo < 0) return;
+      hi = std::min<int64_t>((hi + 63) & ~int64_t(63), b.body_size);
+      MI_HIP_CHECK(hipMemcpyAsync(s.d_in + lo, b.body + lo, static_cast<size_t>(hi - lo), hipMemcpyHostToDevice, ctx->h2d_stream));
+    };
+    for (const auto& r : upload) {
+      if (lo >= 0 && r.first <= hi + (64 << 10)) {
+        hi = std::max(hi, r.first + r.second);
+        continue;
       }
       flush();
+      lo = r.first & ~int64_t(63);
+      hi = r.first + r.second;
     }
+    flush();
   }
-  if (aux_bytes) MI_HIP_CHECK(hipMemcpyAsync(s.d_aux, s.h_aux, aux_bytes, hipMemcpyHostToDevice, ctx->h2d_stream));
   MI_HIP_CHECK(hipEventRecord(s.h2d_done, ctx->h2d_stream));
   MI_HIP_CHECK(hipStreamWaitEvent(ctx->stream, s.h2d_done, 0));
   // absent columns: all-NULL vectors (data 0, validity 0)
-  for (size_t c = 0; c < out_columns.size(); c++) {
-    if (out_columns[c].is_filename || out_columns[c].is_hive) continue;
-    if (src.out_to_file_column[c] < 0 && n > 0) {
-      MI_HIP_CHECK(hipMemsetAsync(s.d_out + s.col_data_off[c], 0, static_cast<size_t>(n) * static_cast<size_t>(std::max(widths[c], 1)), ctx->stream));
-      MI_HIP_CHECK(hipMemsetAsync(s.d_out + s.col_valid_off[c], 0, static_cast<size_t>((n + 63) / 64) * 8, ctx->stream));
+  if (!s.compact) {
+    for (size_t c = 0; c < out_columns.size(); c++) {
+      if (out_columns[c].is_filename || out_columns[c].is_hive) continue;
+      if (src.out_to_file_column[c] < 0 && n > 0) {
+        MI_HIP_CHECK(hipMemsetAsync(s.d_out + s.absent[c].first, 0, static_cast<size_t>(n) * static_cast<size_t>(std::max(widths[c], 1)), ctx->stream));
+        MI_HIP_CHECK(hipMemsetAsync(s.d_out + s.absent[c].second, 0, static_cast<size_t>((n + 63) / 64) * 8, ctx->stream));
+      }
     }
   }
-  s.plan->Set(tasks.data(), static_cast<int32_t>(tasks.size()), ctx->stream);
+  s.plan->Set(s.planner.tasks.data(), static_cast<int32_t>(s.planner.tasks.size()), ctx->stream);
   MI_HIP_CHECK(hipMemsetAsync(s.plan->d_status, 0, sizeof(uint32_t), ctx->stream));
   s.plan->Launch(ctx->stream);
   if (has_filter && n > 0) {
-    const size_t fc = static_cast<size_t>(filter_out_col);
-    MI_HIP_CHECK(device::LaunchFilterRange(s.d_out + s.col_data_off[fc], widths[fc], s.d_out + s.col_valid_off[fc], n, filter_lo,
-                                           filter_hi, reinterpret_cast<mi_sel_t*>(s.d_out + s.sel_off),
-                                           reinterpret_cast<uint32_t*>(s.d_out + s.sel_count_off), ctx->stream));
+    device::FilterProgram prog;
+    std::memset(&prog, 0, sizeof(prog));
+    size_t li = 0;
+    for (auto& clause : filter) {
+      for (size_t j = 0; j < clause.size(); j++, li++) {
+        const FilterLeaf& leaf = clause[j];
+        device::FilterLeafDev& L = prog.leaves[prog.n_leaves++];
+        const int32_t wc = filter_columns[static_cast<size_t>(leaf.out_col)];
+        const ScanColumn& sc = wc >= 0 ? out_columns[static_cast<size_t>(wc)] : filter_only_columns[static_cast<size_t>(~wc)];
+        const int32_t root = s.filter_root[static_cast<size_t>(leaf.out_col)];
+        L.op = leaf.op;
+        L.flags = (j + 1 == clause.size() ? device::kLeafEndsClause : 0) | (leaf.negate ? device::kLeafNegate : 0);
+        L.lo = leaf.lo;
+        L.hi = leaf.hi;
+        L.in_values = static_cast<const int64_t*>(d_in_lists[li]);
+        L.n_in = static_cast<int32_t>(leaf.in_values.size());
+        L.width = 1;
+        if (root < 0) {
+          // the column is absent from this file (union_by_name): every row is NULL -- IS NULL keeps every row, everything
+          // else keeps none (an empty, non-negated range over any readable bytes: the selection buffer itself)
+          L.validity = nullptr;
+          L.flags &= ~device::kLeafNegate;
+          if (leaf.op == device::kLeafIsNull) {
+            L.op = device::kLeafIsNotNull;
+          } else {
+            L.op = device::kLeafRange;
+            L.lo = 1;
+            L.hi = 0;
+            L.data = s.d_out + s.sel_off;
+          }
+          continue;
+        }
+        const PlannedNode& pn = s.planner.nodes[static_cast<size_t>(root)];
+        L.data = pn.alias_body_off >= 0 ? static_cast<const void*>(s.d_in + pn.alias_body_off) : static_cast<const void*>(s.d_out + pn.data_off);
+        L.validity = pn.valid_off >= 0 ? reinterpret_cast<const uint64_t*>(s.d_out + pn.valid_off) : nullptr;
+        L.width = std::max(pn.width, 1);
+        if (sc.field.type == MI_AT_INT && !sc.field.is_signed) {
+          L.flags |= device::kLeafUnsigned;
+          if (pn.width == 8 && leaf.op != device::kLeafIsNull && leaf.op != device::kLeafIsNotNull) {
+            // uint64: compared through the order-preserving map x ^ 2^63 on both sides.  Constants arrive as int64, a
+            // negative one is below every value of the column.
+            L.flags |= device::kLeafBias;
+            const int64_t bias = static_cast<int64_t>(0x8000000000000000ull);
+            if (leaf.op == device::kLeafRange) {
+              if (!leaf.hi_open && leaf.hi < 0) { L.lo = 1; L.hi = 0; }   // empty (its negation keeps every valid row, as it must)
+              else {
+                L.lo = (leaf.lo_open || leaf.lo < 0) ? bias : (leaf.lo ^ bias);            // bias = the image of 0
+                L.hi = leaf.hi_open ? static_cast<int64_t>(0x7FFFFFFFFFFFFFFFull) : (leaf.hi ^ bias);   // image of UINT64_MAX
+              }
+            }
+            // IN-lists of uint64 columns are uploaded unbiased: compare them unbiased too
+            if (leaf.op == device::kLeafIn) L.flags &= ~device::kLeafBias;
+          }
+        }
+      }
+    }
+    MI_HIP_CHECK(device::LaunchFilterProgram(prog, n, reinterpret_cast<mi_sel_t*>(s.d_out + s.sel_off),
+                                             reinterpret_cast<uint32_t*>(s.d_out + s.sel_count_off), ctx->stream));
   }
   if (agg.on && n > 0) {
     // fused consumer: the decoded vectors are read once more by the aggregate kernel and never leave HBM
@@ -607,9 +681,9 @@ void ArrowScan::EnqueueBatch(Slot& s) {
     std::memset(&a, 0, sizeof(a));
     auto column = [&](int32_t c, const void** data, const uint64_t** valid, int32_t* width) {
       if (s.col_root[static_cast<size_t>(c)] < 0) throw InvalidInputException("aggregate column '" + out_columns[static_cast<size_t>(c)].name + "' is absent from a file of the scan");
-      const Slot::NodeOut& o = s.node_out[static_cast<size_t>(s.col_root[static_cast<size_t>(c)])];
+      const PlannedNode& o = s.planner.nodes[static_cast<size_t>(s.col_root[static_cast<size_t>(c)])];
       *data = s.d_out + o.data_off;
-      *valid = reinterpret_cast<const uint64_t*>(s.d_out + o.valid_off);
+      *valid = o.valid_off >= 0 ? reinterpret_cast<const uint64_t*>(s.d_out + o.valid_off) : nullptr;
       *width = o.width;
     };
     a.n_filters = static_cast<int32_t>(agg.filter_cols.size());
@@ -626,39 +700,136 @@ void ArrowScan::EnqueueBatch(Slot& s) {
   }
   MI_HIP_CHECK(hipEventRecord(s.compute_done, ctx->stream));
   MI_HIP_CHECK(hipStreamWaitEvent(ctx->d2h_stream, s.compute_done, 0));
-  if (!opts.device_resident && !agg.on && off > 0)
-    MI_HIP_CHECK(hipMemcpyAsync(s.h_out, s.d_out, off, hipMemcpyDeviceToHost, ctx->d2h_stream));
+  if (has_filter && n > 0)  // the per-window counts always come back (tiny): chunk sizes, Count(), the stage-B layout
+    MI_HIP_CHECK(hipMemcpyAsync(s.h_counts, s.d_out + s.sel_count_off, static_cast<size_t>(n_windows) * 4, hipMemcpyDeviceToHost, ctx->d2h_stream));
+  if (s.compact) {
+    MI_HIP_CHECK(hipEventRecord(s.filter_done, ctx->d2h_stream));
+    s.needs_stage_b = true;
+    return;
+  }
+  if (!opts.device_resident && !agg.on && s.d2h_bytes > 0)
+    MI_HIP_CHECK(hipMemcpyAsync(s.h_out, s.d_out, s.d2h_bytes, hipMemcpyDeviceToHost, ctx->d2h_stream));
   // the device status word travels with the results instead of costing a stream-wide synchronisation
-  MI_HIP_CHECK(hipMemcpyAsync(s.h_status, s.plan->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->d2h_stream));
+  MI_HIP_CHECK(hipMemcpyAsync(&s.h_status[0], s.plan->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->d2h_stream));
+  s.h_status[1] = 0;
   MI_HIP_CHECK(hipEventRecord(s.d2h_done, ctx->d2h_stream));
 }
 
-// The vector of node `node` for chunk window `window` (rows win[window] .. win[window + 1] of the node), children included.
-void ArrowScan::BuildVector(Slot& s, int32_t node, size_t window, uint8_t* base, mi_vector* v) {
-  const Slot::NodeOut& o = s.node_out[static_cast<size_t>(node)];
+// Stage B of a compacted batch: the filter's counts are on the host, so the projected columns get a dense layout sized
+// for the rows that survived; the gather kernel decodes exactly those and only they travel back.
+void ArrowScan::EnqueueStageB(Slot& s) {
+  ctx->Bind();
+  MI_HIP_CHECK(hipEventSynchronize(s.filter_done));
+  const DecodedBatch& b = s.batch;
+  Source& src = sources[static_cast<size_t>(s.source)];
+  const int64_t n = b.length;
+  const int64_t n_windows = (n + MI_VECTOR_SIZE - 1) / MI_VECTOR_SIZE;
+  int64_t total = 0;
+  for (int64_t w = 0; w < n_windows; w++) total += s.h_counts[w];
+  s.needs_stage_b = false;
+  // a fresh planner pass for the projected columns: arena offsets relative to the compact region behind stage A's arrays
+  BatchPlanner cp(s.planner.opts);
+  cp.opts.zero_copy_direct = false;
+  BatchPlacement where;
+  where.batch = &b;
+  where.in_base = s.d_in;
+  where.consumer_base = opts.device_resident ? reinterpret_cast<uint64_t>(s.d_in) : reinterpret_cast<uint64_t>(b.body);
+  where.alloc_rows = total;
+  where.dict_len = [&](int64_t id) -> int64_t {
+    auto it = dicts.find(id);
+    if (it == dicts.end()) throw IOException("RecordBatch uses dictionary id " + std::to_string(id) + " before its DictionaryBatch");
+    return it->second->dict_len;
+  };
+  s.col_root.assign(out_columns.size(), -1);
+  std::vector<int32_t> widths(out_columns.size(), 0);
+  for (size_t c = 0; c < out_columns.size(); c++) {
+    if (out_columns[c].is_filename || out_columns[c].is_hive) continue;
+    int32_t kind, nb;
+    int64_t param;
+    out_columns[c].field.Plan(&kind, &param, &widths[c], &nb);
+    const int32_t fc = src.out_to_file_column[c];
+    if (fc < 0) {
+      s.absent[c] = cp.AddAbsentColumn(total, widths[c]);
+      continue;
+    }
+    s.col_root[c] = cp.AddColumn(where, b.column_node[static_cast<size_t>(fc)]);
+  }
+  s.d2h_bytes = cp.arena_bytes;
+  const size_t region_off = RoundUp(s.stage_a_bytes, 4096);
+  if (region_off + cp.arena_bytes + 64 > s.d_out_cap) throw InternalException("compact region exceeds the slot");
+  uint8_t* region = s.d_out + region_off;
+  EnsureHostOut(s, s.d2h_bytes + 64);
+  cp.Rebase(0, region, nullptr);
+  for (auto& t : cp.tasks) {
+    t.sel = s.d_out + s.sel_off;
+    t.sel_count = s.d_out + s.sel_count_off;
+  }
+  hipStream_t st = ctx->stream;
+  // validity words start as all ones (the gather kernel clears the NULLs); absent columns are all NULL
+  for (size_t c = 0; c < out_columns.size(); c++) {
+    if (out_columns[c].is_filename || out_columns[c].is_hive || total == 0) continue;
+    if (s.col_root[c] < 0) {
+      MI_HIP_CHECK(hipMemsetAsync(region + s.absent[c].first, 0, static_cast<size_t>(total) * static_cast<size_t>(std::max(widths[c], 1)), st));
+      MI_HIP_CHECK(hipMemsetAsync(region + s.absent[c].second, 0, static_cast<size_t>((total + 63) / 64) * 8, st));
+      continue;
+    }
+    const PlannedNode& pn = cp.nodes[static_cast<size_t>(s.col_root[c])];
+    if (pn.valid_off >= 0) MI_HIP_CHECK(hipMemsetAsync(region + pn.valid_off, 0xFF, static_cast<size_t>((total + 63) / 64) * 8 + 8, st));
+  }
+  s.gather_plan->Set(cp.tasks.data(), static_cast<int32_t>(total > 0 ? cp.tasks.size() : 0), st);
+  MI_HIP_CHECK(hipMemsetAsync(s.gather_plan->d_status, 0, sizeof(uint32_t), st));
+  if (total > 0) s.gather_plan->Launch(st);
+  MI_HIP_CHECK(hipEventRecord(s.compute_done, st));
+  MI_HIP_CHECK(hipStreamWaitEvent(ctx->d2h_stream, s.compute_done, 0));
+  if (!opts.device_resident && s.d2h_bytes > 0 && total > 0)
+    MI_HIP_CHECK(hipMemcpyAsync(s.h_out, region, s.d2h_bytes, hipMemcpyDeviceToHost, ctx->d2h_stream));
+  MI_HIP_CHECK(hipMemcpyAsync(&s.h_status[0], s.plan->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->d2h_stream));
+  MI_HIP_CHECK(hipMemcpyAsync(&s.h_status[1], s.gather_plan->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->d2h_stream));
+  MI_HIP_CHECK(hipEventRecord(s.d2h_done, ctx->d2h_stream));
+  // the chunk builder reads the compact layout from here on
+  s.node_dict.assign(cp.nodes.size(), nullptr);
+  for (size_t i = 0; i < cp.nodes.size(); i++)
+    if (cp.nodes[i].dict_id >= 0) s.node_dict[i] = dicts[cp.nodes[i].dict_id];
+  s.compact_region = region;
+  s.planner.nodes = std::move(cp.nodes);
+}
+
+// The vector of node `node` for chunk window `window`, children included.  Full layout: rows win[window] .. win[window + 1]
+// of the node; compacted batches: rows [2048 window, 2048 window + compact_rows) of the dense arrays.
+void ArrowScan::BuildVector(const Slot& s, int32_t node, size_t window, int64_t compact_rows, uint8_t* base, ChunkStorage* st, mi_vector* v) {
+  const PlannedNode& o = s.planner.nodes[static_cast<size_t>(node)];
   std::memset(v, 0, sizeof(*v));
-  const int64_t r0 = o.win[window], r1 = o.win[window + 1];
-  if (o.alias) {
-    v->data = const_cast<uint8_t*>(o.alias) + static_cast<size_t>(r0) * static_cast<size_t>(o.width);
+  const int64_t r0 = compact_rows >= 0 ? static_cast<int64_t>(window) * MI_VECTOR_SIZE : o.win[window];
+  const int64_t r1 = compact_rows >= 0 ? r0 + compact_rows : o.win[window + 1];
+  if (o.alias_body_off >= 0) {
+    const uint8_t* body = opts.device_resident ? s.d_in : s.batch.body;
+    v->data = const_cast<uint8_t*>(body) + o.alias_body_off + static_cast<size_t>(r0) * static_cast<size_t>(o.width);
     v->validity = nullptr;  // all valid
   } else {
     v->data = base + o.data_off + static_cast<size_t>(r0) * static_cast<size_t>(o.width);
-    v->validity = reinterpret_cast<mi_validity_t*>(base + o.valid_off) + r0 / 64;
-    v->validity_shift = static_cast<int32_t>(r0 % 64);
+    if (o.valid_off >= 0) {
+      v->validity = reinterpret_cast<mi_validity_t*>(base + o.valid_off) + r0 / 64;
+      v->validity_shift = static_cast<int32_t>(r0 % 64);
+    }
   }
   v->kind = o.kind;
   v->out_width = o.width;
   v->count = r1 - r0;
-  if (o.kind == MI_K_DICT && o.dict) {
-    v->dictionary = opts.device_resident ? o.dict->d_data : o.dict->h_data;
-    v->dictionary_validity = static_cast<const mi_validity_t*>(opts.device_resident ? o.dict->d_validity : o.dict->h_validity);
-    v->dict_len = o.dict->dict_len;
+  if (o.kind == MI_K_STR32 || o.kind == MI_K_STR64 || o.kind == MI_K_FIXED_BINARY) {
+    v->heap = reinterpret_cast<const void*>(o.ptr_base);
+    v->heap_size = o.heap_size;
+  }
+  if (o.kind == MI_K_DICT && s.node_dict[static_cast<size_t>(node)]) {
+    const DictState& d = *s.node_dict[static_cast<size_t>(node)];
+    v->dictionary = opts.device_resident ? d.d_data : d.h_data;
+    v->dictionary_validity = static_cast<const mi_validity_t*>(opts.device_resident ? d.d_validity : d.h_validity);
+    v->dict_len = d.dict_len;
   }
   if (!o.children.empty()) {
-    if (child_pool_used + o.children.size() > child_pool.size()) throw InternalException("nested vector pool exhausted");
-    mi_vector* kids = child_pool.data() + child_pool_used;
-    child_pool_used += o.children.size();
-    for (size_t k = 0; k < o.children.size(); k++) BuildVector(s, o.children[k], window, base, &kids[k]);
+    if (st->child_pool_used + o.children.size() > st->child_pool.size()) throw InternalException("nested vector pool exhausted");
+    mi_vector* kids = st->child_pool.data() + st->child_pool_used;
+    st->child_pool_used += o.children.size();
+    for (size_t k = 0; k < o.children.size(); k++) BuildVector(s, o.children[k], window, -1, base, st, &kids[k]);
     v->children = kids;
     v->n_children = static_cast<int32_t>(o.children.size());
   }
@@ -668,34 +839,41 @@ void ArrowScan::BuildVector(Slot& s, int32_t node, size_t window, uint8_t* base,
 void ArrowScan::PrepareSource(size_t si) {
   OpenSource(si);
   Source& src = sources[si];
-  if (!src.out_to_file_column.empty()) return;
+  if (src.prepared) return;
   const ArrowSchemaModel& schema = src.reader->GetBaseSchema();
   std::vector<std::string> names;
   for (auto& f : schema.fields) names.push_back(f.name);
   DeduplicateColumns(names);
   std::vector<std::string> wanted;
+  auto map_column = [&](const ScanColumn& col) -> int32_t {
+    auto it = std::find(names.begin(), names.end(), col.name);
+    if (it == names.end()) {
+      if (!opts.union_by_name) {
+        throw InvalidInputException("Failed to read file \"" + src.path + "\": schema mismatch: column \"" + col.name +
+                                    "\" is missing. If you are trying to read files with different schemas, try setting union_by_name=True");
+      }
+      return -1;
+    }
+    const ArrowField& ff = schema.fields[static_cast<size_t>(it - names.begin())];
+    if (ff.Format() != col.field.Format()) {
+      throw NotImplementedException("Column \"" + col.name + "\" has type " + ff.DuckType() + " in file \"" + src.path +
+                                    "\" but " + col.field.DuckType() +
+                                    " in the first file; cross-file casts are done by DuckDB's MultiFileReader above this path");
+    }
+    auto dup = std::find(wanted.begin(), wanted.end(), *it);
+    if (dup != wanted.end()) return static_cast<int32_t>(dup - wanted.begin());
+    wanted.push_back(*it);
+    return static_cast<int32_t>(wanted.size() - 1);
+  };
   src.out_to_file_column.assign(out_columns.size(), -1);
   for (size_t c = 0; c < out_columns.size(); c++) {
     if (out_columns[c].is_filename || out_columns[c].is_hive) continue;
-    auto it = std::find(names.begin(), names.end(), out_columns[c].name);
-    if (it == names.end()) {
-      if (!opts.union_by_name) {
-        throw InvalidInputException("Failed to read file \"" + src.path + "\": schema mismatch: column \"" + out_columns[c].name +
-                                    "\" is missing. If you are trying to read files with different schemas, try setting union_by_name=True");
-      }
-      continue;
-    }
-    const ArrowField& ff = schema.fields[static_cast<size_t>(it - names.begin())];
-    if (ff.Format() != out_columns[c].field.Format()) {
-      throw NotImplementedException("Column \"" + out_columns[c].name + "\" has type " + ff.DuckType() + " in file \"" + src.path +
-                                    "\" but " + out_columns[c].field.DuckType() +
-                                    " in the first file; cross-file casts are done by DuckDB's MultiFileReader above this path");
-    }
-    src.out_to_file_column[c] = static_cast<int32_t>(wanted.size());
-    wanted.push_back(*it);
+    src.out_to_file_column[c] = map_column(out_columns[c]);
   }
+  src.filter_to_file_column.assign(filter_only_columns.size(), -1);
+  for (size_t c = 0; c < filter_only_columns.size(); c++) src.filter_to_file_column[c] = map_column(filter_only_columns[c]);
   if (!wanted.empty()) src.reader->SetColumnProjection(wanted);
-  else src.out_to_file_column.assign(out_columns.size(), -1);
+  src.prepared = true;
 }
 
 // A pinned staging buffer for one record-batch body; the returned handle gives it back when the batch is released.
@@ -842,63 +1020,90 @@ bool ArrowScan::SubmitNextBatch(bool may_block) {
     s.source = f.source;
     s.batch_index = f.ordinal;
     s.busy = true;
-    EnqueueBatch(s);
-    inflight.push_back(static_cast<int>(&s - slots));
+    try {
+      EnqueueBatch(s);
+    } catch (...) {
+      s.busy = false;
+      s.batch = DecodedBatch();
+      throw;
+    }
+    inflight.push_back(static_cast<int>(&s - slots.data()));
     return true;
   }
   return false;
 }
 
-void ArrowScan::Next(mi_data_chunk* out) {
+bool ArrowScan::AcquireBatch(BatchRef* out) {
   if (!initialized) Init({});
   ctx->Bind();
-  std::memset(out, 0, sizeof(*out));
-  while (true) {
-    // release the slot the previous chunk came from once it is fully consumed
-    if (cur_slot >= 0 && cur_row >= slots[cur_slot].nrows) {
-      slots[cur_slot].busy = false;
-      slots[cur_slot].batch.owner.reset();
-      inflight.erase(inflight.begin());
-      cur_slot = -1;
-      cur_row = 0;
-    }
-    // keep the pipeline full
-    while (inflight.size() < static_cast<size_t>(kSlots) && SubmitNextBatch(/*may_block*/ inflight.empty())) {
-    }
-    if (cur_slot < 0) {
-      if (inflight.empty()) {
-        out->size = 0;
-        out->n_columns = static_cast<int32_t>(out_columns.size());
-        return;  // exhausted
-      }
-      cur_slot = inflight.front();
-      cur_row = 0;
-      Slot& s = slots[cur_slot];
-      MI_HIP_CHECK(hipEventSynchronize(s.d2h_done));
-      ThrowForStatus(*s.h_status);
-      if (s.nrows == 0) continue;  // empty record batch: nothing to emit
-    }
-    break;
+  // keep the pipeline full (blocks for input only when nothing is in flight: the batch the caller needs next)
+  while (FreeSlot() != nullptr && SubmitNextBatch(/*may_block*/ inflight.empty())) {
   }
-  Slot& s = slots[cur_slot];
-  const int64_t n = std::min<int64_t>(MI_VECTOR_SIZE, s.nrows - cur_row);
-  uint8_t* base = opts.device_resident ? s.d_out : s.h_out;
-  if (child_pool.size() < s.node_out.size() + 1) child_pool.resize(s.node_out.size() + 1);
-  child_pool_used = 0;
-  Source& src = sources[static_cast<size_t>(s.source)];
+  // compacted batches whose selected-row counts have arrived get their second stage, in batch order
+  for (size_t k = 0; k < inflight.size(); k++) {
+    Slot& s = slots[static_cast<size_t>(inflight[k])];
+    if (!s.needs_stage_b) continue;
+    if (k == 0 || hipEventQuery(s.filter_done) == hipSuccess) EnqueueStageB(s);
+    else break;
+  }
+  if (inflight.empty()) return false;  // exhausted
+  const int si = inflight.front();
+  Slot& s = slots[static_cast<size_t>(si)];
+  MI_HIP_CHECK(hipEventSynchronize(s.d2h_done));
+  inflight.pop_front();
+  try {
+    ThrowForStatus(s.h_status[0] | s.h_status[1]);
+  } catch (...) {
+    s.busy = false;
+    s.batch.owner.reset();
+    throw;
+  }
+  out->slot = si;
+  out->batch_index = s.batch_index;
+  out->nrows = s.nrows;
+  out->source = s.source;
+  out->selected = s.nrows;
+  if (has_filter) {
+    out->selected = 0;
+    const int64_t n_windows = (s.nrows + MI_VECTOR_SIZE - 1) / MI_VECTOR_SIZE;
+    for (int64_t w = 0; w < n_windows; w++) out->selected += s.h_counts[w];
+  }
+  out->chunk_rows = s.compact ? out->selected : s.nrows;
+  out->n_windows = static_cast<int32_t>((out->chunk_rows + MI_VECTOR_SIZE - 1) / MI_VECTOR_SIZE);
+  return true;
+}
+
+void ArrowScan::ReleaseBatch(const BatchRef& ref) {
+  Slot& s = slots[static_cast<size_t>(ref.slot)];
+  s.busy = false;
+  s.batch.owner.reset();
+}
+
+void ArrowScan::BuildChunk(const BatchRef& ref, int32_t window, ChunkStorage* st, mi_data_chunk* out) {
+  const Slot& s = slots[static_cast<size_t>(ref.slot)];
+  std::memset(out, 0, sizeof(*out));
+  const int64_t chunk_rows = s.compact ? ref.selected : s.nrows;
+  const int64_t row0 = static_cast<int64_t>(window) * MI_VECTOR_SIZE;
+  const int64_t n = std::min<int64_t>(MI_VECTOR_SIZE, chunk_rows - row0);
+  if (window < 0 || n <= 0) throw InvalidInputException("chunk window outside the record batch");
+  uint8_t* base = opts.device_resident ? (s.compact ? s.compact_region : s.d_out) : s.h_out;
+  st->vectors.assign(out_columns.size(), mi_vector{});
+  if (st->child_pool.size() < s.planner.nodes.size() + 1) st->child_pool.resize(s.planner.nodes.size() + 1);
+  st->child_pool_used = 0;
+  const Source& src = sources[static_cast<size_t>(s.source)];
   for (size_t c = 0; c < out_columns.size(); c++) {
-    mi_vector& v = chunk_vectors[c];
-    std::memset(&v, 0, sizeof(v));
+    mi_vector& v = st->vectors[c];
     if (out_columns[c].is_filename || out_columns[c].is_hive) {
-      auto& cv = const_vectors[c];
-      // strings are kept alive in the source (path / hive map), the vector points at them
-      const std::string& stable = out_columns[c].is_filename ? src.path : src.hive[out_columns[c].hive_key];
-      if (cv.size() != MI_VECTOR_SIZE || cv[0].value.inlined.length != stable.size() ||
-          (stable.size() > 12 && cv[0].value.pointer.ptr != reinterpret_cast<uint64_t>(stable.data())) ||
-          (stable.size() <= 12 && std::memcmp(cv[0].value.inlined.inlined, stable.data(), stable.size()) != 0)) {
-        cv.assign(MI_VECTOR_SIZE, MakeHostString(stable));
+      // strings are kept alive in the source (path / hive map), one vector of 2048 copies per (file, column)
+      const std::string& stable = out_columns[c].is_filename ? src.path : src.hive.at(out_columns[c].hive_key);
+      const mi_string_t* cv;
+      {
+        std::lock_guard<std::mutex> lk(const_mu);
+        auto& vec = const_vectors[{s.source, c}];
+        if (vec.empty()) vec.assign(MI_VECTOR_SIZE, MakeHostString(stable));
+        cv = vec.data();
       }
-      v.data = cv.data();
+      v.data = const_cast<mi_string_t*>(cv);
       v.validity = all_valid.data();
       v.kind = MI_K_STR32;
       v.out_width = 16;
@@ -906,13 +1111,13 @@ void ArrowScan::Next(mi_data_chunk* out) {
       continue;
     }
     if (s.col_root[c] >= 0) {
-      BuildVector(s, s.col_root[c], static_cast<size_t>(cur_row / MI_VECTOR_SIZE), base, &v);
+      BuildVector(s, s.col_root[c], static_cast<size_t>(window), s.compact ? n : -1, base, st, &v);
     } else {  // absent in this file: all NULL
       int32_t kind, w, nb;
       int64_t param;
       out_columns[c].field.Plan(&kind, &param, &w, &nb);
-      v.data = base + s.col_data_off[c] + static_cast<size_t>(cur_row) * static_cast<size_t>(std::max(w, 1));
-      v.validity = reinterpret_cast<mi_validity_t*>(base + s.col_valid_off[c]) + cur_row / 64;
+      v.data = base + s.absent[c].first + static_cast<size_t>(row0) * static_cast<size_t>(std::max(w, 1));
+      v.validity = reinterpret_cast<mi_validity_t*>(base + s.absent[c].second) + row0 / 64;
       v.kind = kind;
       v.out_width = w;
       v.count = n;
@@ -922,27 +1127,68 @@ void ArrowScan::Next(mi_data_chunk* out) {
   out->n_columns = static_cast<int32_t>(out_columns.size());
   out->file_index = s.source;
   out->batch_index = s.batch_index;
-  out->chunk_offset = cur_row;
-  out->columns = chunk_vectors.data();
+  out->chunk_offset = row0;
+  out->columns = st->vectors.data();
   out->sel_count = n;
-  if (has_filter) {
-    out->sel = reinterpret_cast<const mi_sel_t*>(base + s.sel_off) + cur_row;
-    if (opts.device_resident) {
-      uint32_t cnt = 0;
-      MI_HIP_CHECK(hipMemcpy(&cnt, s.d_out + s.sel_count_off + static_cast<size_t>(cur_row / MI_VECTOR_SIZE) * 4, 4, hipMemcpyDeviceToHost));
-      out->sel_count = cnt;
-    } else {
-      out->sel_count = reinterpret_cast<const uint32_t*>(base + s.sel_count_off)[cur_row / MI_VECTOR_SIZE];
-    }
+  out->source_rows = s.compact ? (window == 0 ? s.nrows : 0) : n;
+  if (has_filter && !s.compact) {
+    out->sel = reinterpret_cast<const mi_sel_t*>(base + s.sel_off) + row0;
+    out->sel_count = s.h_counts[window];
   }
-  cur_row += n;
 }
 
-void ArrowScan::SumProduct(const std::string& a, const std::string& b, const std::vector<std::string>& filter_columns,
+void ArrowScan::Next(mi_data_chunk* out) {
+  if (!initialized) Init({});
+  std::memset(out, 0, sizeof(*out));
+  while (true) {
+    if (have_cur && cur_window >= cur_ref.n_windows) {  // the previous chunk was the batch's last: recycle its slot
+      ReleaseBatch(cur_ref);
+      have_cur = false;
+    }
+    if (have_cur) break;
+    if (!AcquireBatch(&cur_ref)) {
+      out->size = 0;
+      out->n_columns = static_cast<int32_t>(out_columns.size());
+      return;  // exhausted
+    }
+    have_cur = true;
+    cur_window = 0;  // an empty (or, when compacting, fully filtered) batch has no windows: the loop moves on
+  }
+  BuildChunk(cur_ref, cur_window, &next_storage, out);
+  cur_window++;
+}
+
+void ArrowScan::Count(int64_t* rows, int64_t* selected, int64_t* chunks) {
+  if (!initialized) Init({});
+  int64_t r = 0, sel = 0, n = 0;
+  if (have_cur) {  // mid-batch after mi_scan_next: the rest of the current batch counts chunk by chunk
+    mi_data_chunk ch;
+    while (cur_window < cur_ref.n_windows) {
+      BuildChunk(cur_ref, cur_window++, &next_storage, &ch);
+      r += ch.source_rows;
+      sel += ch.sel ? ch.sel_count : ch.size;
+      n++;
+    }
+    ReleaseBatch(cur_ref);
+    have_cur = false;
+  }
+  BatchRef ref;
+  while (AcquireBatch(&ref)) {   // whole batches: no chunk is materialised for a count
+    r += ref.nrows;
+    sel += ref.selected;
+    n += ref.n_windows;
+    ReleaseBatch(ref);
+  }
+  if (rows) *rows = r;
+  if (selected) *selected = sel;
+  if (chunks) *chunks = n;
+}
+
+void ArrowScan::SumProduct(const std::string& a, const std::string& b, const std::vector<std::string>& filter_columns_p,
                            const std::vector<int64_t>& lo, const std::vector<int64_t>& hi, mi_sum_product_result* out) {
   if (initialized) throw InvalidInputException("mi_scan_sum_product replaces mi_scan_init / mi_scan_next: call it right after bind");
-  if (filter_columns.size() > 4) throw InvalidInputException("at most 4 range filters");
-  if (has_filter) throw InvalidInputException("give the filters to mi_scan_sum_product instead of mi_scan_set_filter_range");
+  if (filter_columns_p.size() > 4) throw InvalidInputException("at most 4 range filters");
+  if (has_filter) throw InvalidInputException("give the filters to mi_scan_sum_product instead of mi_scan_set_filter");
   ctx->Bind();
   // project exactly the columns the aggregate reads
   std::vector<std::string> proj;
@@ -954,7 +1200,8 @@ void ArrowScan::SumProduct(const std::string& a, const std::string& b, const std
   };
   agg.col_a = slot_of(a);
   agg.col_b = slot_of(b);
-  for (auto& f : filter_columns) agg.filter_cols.push_back(slot_of(f));
+  agg.filter_cols.clear();
+  for (auto& f : filter_columns_p) agg.filter_cols.push_back(slot_of(f));
   agg.lo = lo;
   agg.hi = hi;
   Init(proj);
@@ -972,13 +1219,9 @@ void ArrowScan::SumProduct(const std::string& a, const std::string& b, const std
   MI_HIP_CHECK(hipMemsetAsync(agg.d_acc, 0, 4 * sizeof(unsigned long long), ctx->stream));
   agg.on = true;
   agg.rows_scanned = 0;
-  mi_data_chunk ch;
   try {
-    while (true) {   // the pull loop only recycles slots: nothing is copied back
-      Next(&ch);
-      if (ch.size == 0) break;
-      cur_row = slots[cur_slot].nrows;  // the whole batch is consumed on the device
-    }
+    BatchRef ref;
+    while (AcquireBatch(&ref)) ReleaseBatch(ref);   // the pull loop only recycles slots: nothing is copied back
     unsigned long long acc[4] = {0, 0, 0, 0};
     MI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     MI_HIP_CHECK(hipMemcpy(acc, agg.d_acc, sizeof(acc), hipMemcpyDeviceToHost));
@@ -1004,6 +1247,118 @@ double ArrowScan::Progress() {
   return std::min(100.0, 100.0 * done / static_cast<double>(sources.size()));
 }
 
+// ------------------------------------------------------------------------------------------------ multi-device
+MultiDeviceScan::MultiDeviceScan(const std::vector<Context*>& ctxs, std::vector<std::string> paths, const mi_scan_options& o) {
+  if (ctxs.empty()) throw InvalidInputException("mi_scan_open_files_multi needs at least one context");
+  const int32_t n = static_cast<int32_t>(ctxs.size());
+  const int32_t outer_world = o.world > 1 ? o.world : 1, outer_rank = o.world > 1 ? o.rank : 0;
+  if (outer_rank < 0 || outer_rank >= outer_world) throw InvalidInputException("rank outside [0, world)");
+  for (int32_t i = 0; i < n; i++) {
+    if (!ctxs[static_cast<size_t>(i)]) throw InvalidInputException("mi_scan_open_files_multi: NULL context");
+    mi_scan_options so = o;
+    // batch k of the file list belongs to this scan when k mod world == rank; its j-th batch goes to context j mod n:
+    // k = rank + world * j  =>  sub-scan i takes the batches with k mod (world * n) == rank + world * i
+    so.world = outer_world * n;
+    so.rank = outer_rank + outer_world * i;
+    subs.push_back(std::make_unique<ArrowScan>(ctxs[static_cast<size_t>(i)], paths, so));
+  }
+  EnsureIoThreads(8 * n);  // every device reads its own record batches out of the page cache
+  pending.resize(subs.size());
+  have.assign(subs.size(), 0);
+  done.assign(subs.size(), 0);
+}
+
+const std::vector<ScanColumn>& MultiDeviceScan::Bind() {
+  for (size_t i = 1; i < subs.size(); i++) subs[i]->Bind();
+  return subs[0]->Bind();
+}
+
+void MultiDeviceScan::Init(const std::vector<std::string>& projected) {
+  for (auto& s : subs) s->Init(projected);
+}
+
+void MultiDeviceScan::SetFilter(FilterCnf cnf) {
+  for (auto& s : subs) s->SetFilter(cnf);
+}
+
+void MultiDeviceScan::ForEachParallel(const std::function<void(size_t)>& fn) {
+  std::vector<std::thread> threads;
+  std::vector<std::exception_ptr> errors(subs.size());
+  for (size_t i = 0; i < subs.size(); i++)
+    threads.emplace_back([&, i] {
+      try {
+        fn(i);
+      } catch (...) {
+        errors[i] = std::current_exception();
+      }
+    });
+  for (auto& t : threads) t.join();
+  for (auto& e : errors)
+    if (e) std::rethrow_exception(e);
+}
+
+// k-way merge on the record-batch ordinal: every sub-scan yields its own batches in ascending order, so the chunk to emit
+// is the pending one with the smallest batch_index.  A pending chunk stays valid until its sub-scan is pulled again, which
+// happens only after the consumer has come back for the next chunk.
+void MultiDeviceScan::Next(mi_data_chunk* out) {
+  if (last_emitted >= 0) {
+    have[static_cast<size_t>(last_emitted)] = 0;
+    last_emitted = -1;
+  }
+  int best = -1;
+  for (size_t i = 0; i < subs.size(); i++) {
+    if (!have[i] && !done[i]) {
+      subs[i]->Next(&pending[i]);
+      if (pending[i].size == 0) done[i] = 1;
+      else have[i] = 1;
+    }
+    if (have[i] && (best < 0 || pending[i].batch_index < pending[static_cast<size_t>(best)].batch_index)) best = static_cast<int>(i);
+  }
+  if (best < 0) {
+    std::memset(out, 0, sizeof(*out));
+    out->n_columns = static_cast<int32_t>(subs[0]->NumOutputColumns());
+    return;
+  }
+  *out = pending[static_cast<size_t>(best)];
+  last_emitted = best;
+}
+
+void MultiDeviceScan::Count(int64_t* rows, int64_t* selected, int64_t* chunks) {
+  std::vector<int64_t> r(subs.size(), 0), s(subs.size(), 0), c(subs.size(), 0);
+  ForEachParallel([&](size_t i) { subs[i]->Count(&r[i], &s[i], &c[i]); });
+  int64_t tr = 0, ts = 0, tc = 0;
+  for (size_t i = 0; i < subs.size(); i++) {
+    tr += r[i];
+    ts += s[i];
+    tc += c[i];
+  }
+  if (rows) *rows = tr;
+  if (selected) *selected = ts;
+  if (chunks) *chunks = tc;
+}
+
+void MultiDeviceScan::SumProduct(const std::string& a, const std::string& b, const std::vector<std::string>& filter_columns,
+                                 const std::vector<int64_t>& lo, const std::vector<int64_t>& hi, mi_sum_product_result* out) {
+  std::vector<mi_sum_product_result> parts(subs.size());
+  for (auto& p : parts) std::memset(&p, 0, sizeof(p));
+  ForEachParallel([&](size_t i) { subs[i]->SumProduct(a, b, filter_columns, lo, hi, &parts[i]); });
+  unsigned __int128 sum = 0;
+  std::memset(out, 0, sizeof(*out));
+  for (auto& p : parts) {
+    sum += (static_cast<unsigned __int128>(static_cast<uint64_t>(p.sum_hi)) << 64) | p.sum_lo;  // two's complement: wraps like the device
+    out->rows_scanned += p.rows_scanned;
+    out->rows_selected += p.rows_selected;
+  }
+  out->sum_lo = static_cast<uint64_t>(sum);
+  out->sum_hi = static_cast<int64_t>(static_cast<uint64_t>(sum >> 64));
+}
+
+double MultiDeviceScan::Progress() {
+  double p = 0;
+  for (auto& s : subs) p += s->Progress();
+  return p / static_cast<double>(subs.size());
+}
+
 }  // namespace miarrow
 
 // ------------------------------------------------------------------------------------------------ C ABI
@@ -1014,8 +1369,13 @@ Context* ContextOf(mi_ctx* c);
 }
 
 struct mi_scan {
-  std::unique_ptr<ArrowScan> scan;
+  std::unique_ptr<ScanBase> scan;
+  ArrowScan* single = nullptr;  // the scan when it is not a multi-device one (the COPY pump pulls whole batches from it)
 };
+
+namespace miarrow {
+ArrowScan* SingleScanOf(mi_scan* s) { return s ? s->single : nullptr; }
+}  // namespace miarrow
 
 extern "C" {
 
@@ -1028,7 +1388,26 @@ int mi_scan_open_files(mi_ctx* ctx, const char* const* paths, int32_t n_paths, c
     std::vector<std::string> v;
     for (int32_t i = 0; i < n_paths; i++) v.emplace_back(paths[i]);
     auto s = std::make_unique<mi_scan>();
-    s->scan = std::make_unique<ArrowScan>(ContextOf(ctx), std::move(v), o);
+    auto scan = std::make_unique<ArrowScan>(ContextOf(ctx), std::move(v), o);
+    s->single = scan.get();
+    s->scan = std::move(scan);
+    *out = s.release();
+  });
+}
+
+int mi_scan_open_files_multi(mi_ctx* const* ctxs, int32_t n_ctxs, const char* const* paths, int32_t n_paths,
+                             const mi_scan_options* opts, mi_scan** out) {
+  return WrapC([&] {
+    if (!ctxs || n_ctxs <= 0 || !paths || n_paths <= 0 || !out) throw InvalidInputException("mi_scan_open_files_multi: bad argument");
+    mi_scan_options o;
+    std::memset(&o, 0, sizeof(o));
+    if (opts) o = *opts;
+    std::vector<std::string> v;
+    for (int32_t i = 0; i < n_paths; i++) v.emplace_back(paths[i]);
+    std::vector<Context*> cs;
+    for (int32_t i = 0; i < n_ctxs; i++) cs.push_back(ContextOf(ctxs[i]));
+    auto s = std::make_unique<mi_scan>();
+    s->scan = std::make_unique<MultiDeviceScan>(cs, std::move(v), o);
     *out = s.release();
   });
 }
@@ -1042,7 +1421,9 @@ int mi_scan_open_buffers(mi_ctx* ctx, const mi_ipc_buffer* buffers, int32_t n_bu
     std::vector<ArrowIPCBuffer> v;
     for (int32_t i = 0; i < n_buffers; i++) v.emplace_back(buffers[i].ptr, buffers[i].size);
     auto s = std::make_unique<mi_scan>();
-    s->scan = std::make_unique<ArrowScan>(ContextOf(ctx), std::move(v), o);
+    auto scan = std::make_unique<ArrowScan>(ContextOf(ctx), std::move(v), o);
+    s->single = scan.get();
+    s->scan = std::move(scan);
     *out = s.release();
   });
 }
@@ -1070,10 +1451,28 @@ int mi_scan_init(mi_scan* s, const char* const* projected_names, int32_t n_proje
   });
 }
 
+int mi_scan_set_filter(mi_scan* s, const mi_filter_node* nodes, int32_t n_nodes, int32_t root) {
+  return WrapC([&] {
+    if (!s || !nodes) throw InvalidInputException("mi_scan_set_filter: NULL argument");
+    s->scan->SetFilter(NormaliseFilter(nodes, n_nodes, root));
+  });
+}
+
 int mi_scan_set_filter_range(mi_scan* s, const char* column, int64_t lo, int64_t hi) {
   return WrapC([&] {
     if (!s || !column) throw InvalidInputException("mi_scan_set_filter_range: NULL argument");
-    s->scan->SetFilterRange(column, lo, hi);
+    mi_filter_node nodes[3];
+    std::memset(nodes, 0, sizeof(nodes));
+    nodes[0].op = MI_F_AND;
+    nodes[0].first_child = 1;
+    nodes[0].n_children = 2;
+    nodes[1].op = MI_F_GE;
+    nodes[1].column = column;
+    nodes[1].value = lo;
+    nodes[2].op = MI_F_LT;
+    nodes[2].column = column;
+    nodes[2].value = hi;
+    s->scan->SetFilter(NormaliseFilter(nodes, 3, 0));
   });
 }
 
@@ -1087,18 +1486,7 @@ int mi_scan_next(mi_scan* s, mi_data_chunk* out) {
 int mi_scan_count(mi_scan* s, int64_t* rows, int64_t* selected, int64_t* chunks) {
   return WrapC([&] {
     if (!s) throw InvalidInputException("mi_scan_count: NULL argument");
-    int64_t r = 0, sel = 0, n = 0;
-    mi_data_chunk ch;
-    while (true) {
-      s->scan->Next(&ch);
-      if (ch.size == 0) break;
-      r += ch.size;
-      sel += ch.sel ? ch.sel_count : ch.size;
-      n++;
-    }
-    if (rows) *rows = r;
-    if (selected) *selected = sel;
-    if (chunks) *chunks = n;
+    s->scan->Count(rows, selected, chunks);
   });
 }
 

@@ -1,6 +1,6 @@
 // scan_operator.hpp -- the scan TableFunction body: read_arrow / scan_arrow_ipc on the MI355X path.
 //
-// Mirrors, for this path, what the reference wires together from DuckDB pieces:
+// Takes the place of what the reference wires together from DuckDB pieces:
 //   bind      ArrowFileScan::ArrowFileScan            src/file_scanner/arrow_file_scan.cpp:9-23
 //             ScanArrowIPCFunction::ScanArrowIPCBind   src/scanner/scan_arrow_ipc.cpp:20-48
 //             ArrowMultiFileInfo::BindReader           src/file_scanner/arrow_multi_file_info.cpp:54-70
@@ -24,6 +24,7 @@
 #include <string>
 #include <vector>
 
+#include "batch_planner.hpp"
 #include "engine.hpp"
 #include "ipc_stream_reader.hpp"
 
@@ -39,29 +40,97 @@ struct ScanColumn {
   std::string hive_key;
 };
 
-class ArrowScan {
+//! One leaf of a pushed-down predicate after normalisation (scan_filter.cpp): every comparison on an integer-like column
+//! is an inclusive range (optionally negated), plus IS [NOT] NULL and IN-lists.
+struct FilterLeaf {
+  std::string column;
+  int32_t op = 0;                 // device::kLeaf*
+  int64_t lo = 0, hi = 0;         // kLeafRange: lo <= v <= hi ...
+  bool lo_open = true, hi_open = true;  // ... where an open end has no bound at all (uint64 columns reach past INT64_MAX)
+  bool negate = false;
+  std::vector<int64_t> in_values;
+  int32_t out_col = -1;           // resolved at Init: index into the scan's filter columns
+};
+//! Conjunctive normal form: every clause is an OR of leaves, the filter is the AND of its clauses.
+using FilterCnf = std::vector<std::vector<FilterLeaf>>;
+FilterCnf NormaliseFilter(const mi_filter_node* nodes, int32_t n_nodes, int32_t root);  // scan_filter.cpp
+
+//! Vectors of one DataChunk (the storage behind mi_data_chunk.columns)
+struct ChunkStorage {
+  std::vector<mi_vector> vectors;
+  std::vector<mi_vector> child_pool;
+  size_t child_pool_used = 0;
+};
+
+//! A record batch whose decoded vectors are complete and held for the caller (ArrowScan::AcquireBatch)
+struct BatchRef {
+  int slot = -1;
+  int64_t batch_index = 0;
+  int64_t nrows = 0;
+  int32_t source = 0;
+  int32_t n_windows = 0;     // chunks BuildChunk can produce (compacted batches: of the rows that survived the filter)
+  int64_t selected = 0;      // rows passing the pushed-down filter (== nrows without one)
+  int64_t chunk_rows = 0;    // rows its chunks hold together: nrows, or `selected` when the batch was compacted
+};
+
+class ScanBase {
+ public:
+  virtual ~ScanBase() = default;
+  virtual const std::vector<ScanColumn>& Bind() = 0;
+  virtual void Init(const std::vector<std::string>& projected) = 0;
+  virtual void SetFilter(FilterCnf cnf) = 0;
+  virtual void Next(mi_data_chunk* out) = 0;
+  virtual void Count(int64_t* rows, int64_t* selected, int64_t* chunks) = 0;
+  virtual void SumProduct(const std::string& a, const std::string& b, const std::vector<std::string>& filter_columns,
+                          const std::vector<int64_t>& lo, const std::vector<int64_t>& hi, mi_sum_product_result* out) = 0;
+  virtual double Progress() = 0;
+};
+
+class ArrowScan : public ScanBase {
  public:
   ArrowScan(Context* ctx, std::vector<std::string> paths, const mi_scan_options& opts);
   ArrowScan(Context* ctx, std::vector<ArrowIPCBuffer> buffers, const mi_scan_options& opts);
-  ~ArrowScan();
+  ~ArrowScan() override;
 
   //! Bind: schema of the scan (names deduplicated) -- "Provided table/dataframe must have at least one column"
-  const std::vector<ScanColumn>& Bind();
+  const std::vector<ScanColumn>& Bind() override;
   //! Init: projection pushdown (column names, output order)
-  void Init(const std::vector<std::string>& projected);
-  //! Range filter pushed into the scan (K6; the reference leaves filters to DuckDB: read_arrow.cpp:47-48)
-  void SetFilterRange(const std::string& column, int64_t lo, int64_t hi);
+  void Init(const std::vector<std::string>& projected) override;
+  //! Predicate pushed into the scan (K6; the reference leaves filters to DuckDB: read_arrow.cpp:47-48)
+  void SetFilter(FilterCnf cnf) override;
   //! One DataChunk (<= 2048 rows); size 0 when exhausted
-  void Next(mi_data_chunk* out);
-  double Progress();
+  void Next(mi_data_chunk* out) override;
+  void Count(int64_t* rows, int64_t* selected, int64_t* chunks) override;
+  double Progress() override;
+  //! sum(a * b) over rows passing the range filters, all on the GPU; drains the scan (mi_scan_sum_product)
+  void SumProduct(const std::string& a, const std::string& b, const std::vector<std::string>& filter_columns,
+                  const std::vector<int64_t>& lo, const std::vector<int64_t>& hi, mi_sum_product_result* out) override;
+
+  // ---- batch-level pull (what Next() is built on; the COPY pump and the multi-device scan use it directly) ----
+  //! Waits for the next record batch in order; false when the scan is exhausted.  The batch stays valid (its slot is
+  //! not recycled) until ReleaseBatch; at most pipeline_depth - 1 batches may be held at once.
+  bool AcquireBatch(BatchRef* out);
+  //! Chunk `window` (rows [2048 w, 2048 (w+1)) of the batch; fewer when compacted) -> out, vectors in `storage`.
+  //! Thread-safe for different batches.
+  void BuildChunk(const BatchRef& ref, int32_t window, ChunkStorage* storage, mi_data_chunk* out);
+  void ReleaseBatch(const BatchRef& ref);
+  //! true once every source is read and no batch is in flight (AcquireBatch returns false both then and when every slot is
+  //! held by the caller: release one and ask again)
+  bool Exhausted() const { return exhausted && inflight.empty(); }
+  void EnsurePipelineDepth(int depth);
+  bool HostConsumer() const { return !opts.device_resident; }
+  size_t NumOutputColumns() const { return out_columns.size(); }
+  const std::vector<ScanColumn>& OutputColumns() const { return out_columns; }
+  bool Initialized() const { return initialized; }
 
  private:
   struct Source {
     std::string path;                          // empty for buffers
     std::unique_ptr<IPCStreamReader> reader;
     std::vector<int32_t> out_to_file_column;   // per output column: index in this file's projected batch, -1 = absent
+    std::vector<int32_t> filter_to_file_column;  // per filter-only column (not in the projection)
     std::map<std::string, std::string> hive;   // key -> value parsed from the path
-    bool opened = false;
+    bool opened = false, prepared = false;
   };
   //! One immutable version of a decoded dictionary (dict_len + 1 entries, the last one NULL).  Record batches keep the
   //! version they were enqueued with, so a later replacement / delta never changes what an in-flight batch sees.
@@ -81,37 +150,32 @@ class ArrowScan {
     uint8_t* d_in = nullptr;   size_t d_in_cap = 0;    // body in HBM
     uint8_t* d_out = nullptr;  size_t d_out_cap = 0;   // decoded vectors in HBM
     uint8_t* h_out = nullptr;  size_t h_out_cap = 0;   // decoded vectors, pinned
-    std::unique_ptr<Plan> plan;
-    uint32_t* h_status = nullptr;                      // pinned copy of the plan's device status word
-    hipEvent_t h2d_done = nullptr, compute_done = nullptr, d2h_done = nullptr;
+    std::unique_ptr<Plan> plan;                        // full-width decode (all columns, or the filter columns when compacting)
+    std::unique_ptr<Plan> gather_plan;                 // compaction: every projected column through the selection vector
+    uint32_t* h_status = nullptr;                      // pinned copy of the plans' device status words
+    hipEvent_t h2d_done = nullptr, compute_done = nullptr, d2h_done = nullptr, filter_done = nullptr;
     bool busy = false;
     DecodedBatch batch;
     int32_t source = 0;
     int64_t batch_index = 0;
     int64_t nrows = 0;
-    std::vector<size_t> col_data_off, col_valid_off;   // per output column, offsets into d_out / h_out
-    //! decoded field nodes of the batch (nested columns have children); col_root[c] = node of output column c (-1: absent)
-    struct NodeOut {
-      size_t data_off = 0, valid_off = 0;
-      int32_t kind = 0, width = 0, arrow_type = 0;
-      int64_t param = 0, nrows = 0;
-      std::vector<int64_t> win;       // first row (in this node's row space) of every top-level 2048-row window, + end
-      std::vector<int32_t> children;
-      std::shared_ptr<DictState> dict;
-      const uint8_t* alias = nullptr;  // zero_copy_direct: the values live in the record-batch body, validity = all valid
-    };
-    std::vector<std::pair<int64_t, int64_t>> upload;   // body byte ranges the kernels read (everything unless aliasing)
-    std::vector<NodeOut> node_out;
-    std::vector<int32_t> col_root;
-    uint8_t* h_aux = nullptr;  size_t h_aux_cap = 0;   // pinned: list window tables, string-view buffer tables
+    BatchPlanner planner{PlannerOptions{}};            // layout + tasks of the projected columns
+    std::vector<int32_t> col_root;                     // per output column: planner node (-1: absent in this file)
+    std::vector<std::pair<size_t, size_t>> absent;     // per output column absent in this file: {data_off, valid_off}
+    std::vector<std::shared_ptr<DictState>> node_dict; // per planner node: the dictionary version this batch uses
+    uint8_t* h_aux = nullptr;  size_t h_aux_cap = 0;   // pinned: list window tables, string-view buffer tables, filter program
     uint8_t* d_aux = nullptr;  size_t d_aux_cap = 0;
-    size_t sel_off = 0, sel_count_off = 0;             // filter outputs
-    std::shared_ptr<void> external_body;               // buffer sources: nothing to own, body is caller memory
-    std::vector<std::shared_ptr<DictState>> col_dict;  // per output column: the dictionary version this batch uses
+    size_t sel_off = 0, sel_count_off = 0;             // filter outputs (arena offsets)
+    std::vector<int32_t> filter_root;                  // per filter column: planner node of its full-width decoded vector
+    uint32_t* h_counts = nullptr; size_t h_counts_cap = 0;  // pinned: rows selected per 2048-row window
+    size_t d2h_bytes = 0;                              // bytes that travel back to the host
+    size_t stage_a_bytes = 0;                          // arena bytes of the full-width arrays (+ sel, counts)
+    bool compact = false;                              // chunks hold only the selected rows (dense arrays behind stage A's)
+    bool needs_stage_b = false;                        // compaction: the gather + copy back wait for the counts
+    uint8_t* compact_region = nullptr;                 // device address of the dense arrays
   };
 
   void OpenSource(size_t i);
-  void BuildOutputSchema();
   //! takes the next fetched record batch and enqueues its GPU work; false when nothing could be submitted (no free
   //! slot, nothing fetched yet while `may_block` is false, or every source is exhausted)
   bool SubmitNextBatch(bool may_block);
@@ -133,28 +197,23 @@ class ArrowScan {
   void StartProducer();
   void StopProducer();
   void ProducerLoop();
-  void PrepareSource(size_t si);      // per-file column mapping + reader projection (was inline in SubmitNextBatch)
+  void PrepareSource(size_t si);      // per-file column mapping + reader projection
   std::shared_ptr<void> LeaseStaging(size_t bytes, uint8_t** ptr);
   static constexpr int kReadAhead = 3;              // fetched batches waiting for a slot
-  static constexpr int kStaging = 3 + kReadAhead + 1;  // in flight on the GPU + waiting + the one being read
   std::thread producer;
   std::mutex q_mu;
   std::condition_variable q_cv;
   std::deque<Fetched> fetched;
-  Staging staging[kStaging];
+  std::vector<Staging> staging;                     // in flight on the GPU + waiting + the one being read
   bool producer_started = false, producer_stop = false;
+  void InitSlot(Slot& s);
   void EnqueueBatch(Slot& s);
- public:
-  //! sum(a * b) over rows passing the range filters, all on the GPU; drains the scan (mi_scan_sum_product)
-  void SumProduct(const std::string& a, const std::string& b, const std::vector<std::string>& filter_columns,
-                  const std::vector<int64_t>& lo, const std::vector<int64_t>& hi, mi_sum_product_result* out);
- private:
-  int32_t AddNode(Slot& s, const DecodedBatch& b, int32_t ni, std::vector<int64_t> win, bool win_is_tiles, int64_t parent_valid_off,
-                  int32_t parent_div, size_t* off, std::vector<mi_col_task>* tasks, std::vector<uint64_t>* aux,
-                  std::vector<std::pair<size_t, size_t>>* aux_fixups);
-  void BuildVector(Slot& s, int32_t node, size_t window, uint8_t* base, mi_vector* out);
+  void EnqueueStageB(Slot& s);
+  void UploadAux(Slot& s, const std::vector<uint64_t>& aux);
+  void BuildVector(const Slot& s, int32_t node, size_t window, int64_t compact_rows, uint8_t* base, ChunkStorage* st, mi_vector* out);
   void DecodeDictionary(Source& src, const DecodedBatch& b);
   void EnsureSlotBuffers(Slot& s, size_t in_bytes, size_t out_bytes);
+  void EnsureHostOut(Slot& s, size_t bytes);
   Slot* FreeSlot();
 
   Context* ctx;
@@ -165,22 +224,19 @@ class ArrowScan {
   bool bound = false, initialized = false;
   std::vector<ScanColumn> all_columns;   // bind result
   std::vector<ScanColumn> out_columns;   // after projection
+  std::vector<ScanColumn> filter_only_columns;  // filter columns outside the projection: decoded, never emitted
   std::vector<std::string> projected_names;
 
   // pipeline
-  static constexpr int kSlots = 3;
-  Slot slots[kSlots];
-  std::vector<int> inflight;             // slot indices in submission order
+  std::vector<Slot> slots;
+  std::deque<int> inflight;              // slot indices in submission order (not yet acquired)
   size_t cur_source = 0;
-  int64_t next_batch_ordinal = 0;        // global record-batch ordinal (sharding + order)
   bool exhausted = false;
-  // consumer cursor
-  int cur_slot = -1;
-  int64_t cur_row = 0;
-  std::vector<mi_vector> chunk_vectors;
-  std::vector<mi_vector> child_pool;     // children of nested vectors of the current chunk
-  size_t child_pool_used = 0;
-  int32_t filter_node = -1;              // field node of the filter column in the batch being enqueued
+  // consumer cursor of Next()
+  BatchRef cur_ref;
+  bool have_cur = false;
+  int32_t cur_window = 0;
+  ChunkStorage next_storage;
   // fused aggregate (mi_scan_sum_product): output columns the kernel reads, bounds, device accumulator
   struct Aggregate {
     bool on = false;
@@ -190,18 +246,43 @@ class ArrowScan {
     unsigned long long* d_acc = nullptr;   // {sum lo, sum hi, rows selected}
     int64_t rows_scanned = 0;
   } agg;
-  // constant columns (filename / hive): 2048 string_t each, host
-  std::vector<std::vector<mi_string_t>> const_vectors;
+  // constant columns (filename / hive): 2048 string_t each per source, host
+  std::map<std::pair<int32_t, size_t>, std::vector<mi_string_t>> const_vectors;
+  std::mutex const_mu;
   std::vector<mi_validity_t> all_valid;
   // dictionaries by id
   std::map<int64_t, std::shared_ptr<DictState>> dicts;
   // filter
   bool has_filter = false;
-  std::string filter_column;
-  int filter_out_col = -1;
-  int64_t filter_lo = 0, filter_hi = 0;
-  // progress
-  int64_t total_bytes = 0, consumed_bytes = 0;
+  FilterCnf filter;
+  //! filter column k -> output column (>= 0) or ~index into filter_only_columns (< 0)
+  std::vector<int32_t> filter_columns;
+  std::vector<void*> d_in_lists;         // per leaf (clause order): its IN-list in HBM, or NULL
+  bool compact = false;
+};
+
+//! read_arrow over several GPUs of one process: one ArrowScan per context, record batch k of the file list
+//! goes to sub-scan k mod N, chunks come back in record-batch order (k-way merge on batch_index).  Draining calls
+//! (Count, SumProduct) run every sub-scan on its own thread.
+class MultiDeviceScan : public ScanBase {
+ public:
+  MultiDeviceScan(const std::vector<Context*>& ctxs, std::vector<std::string> paths, const mi_scan_options& opts);
+  const std::vector<ScanColumn>& Bind() override;
+  void Init(const std::vector<std::string>& projected) override;
+  void SetFilter(FilterCnf cnf) override;
+  void Next(mi_data_chunk* out) override;
+  void Count(int64_t* rows, int64_t* selected, int64_t* chunks) override;
+  void SumProduct(const std::string& a, const std::string& b, const std::vector<std::string>& filter_columns,
+                  const std::vector<int64_t>& lo, const std::vector<int64_t>& hi, mi_sum_product_result* out) override;
+  double Progress() override;
+
+ private:
+  void ForEachParallel(const std::function<void(size_t)>& fn);
+  std::vector<std::unique_ptr<ArrowScan>> subs;
+  std::vector<mi_data_chunk> pending;   // one chunk per sub-scan, valid until that sub-scan's next Next()
+  std::vector<char> have, done;
+  int last_emitted = -1;
+  bool started = false;
 };
 
 }  // namespace miarrow

@@ -1,6 +1,7 @@
 // writer.cpp -- see writer.hpp.
 #include "writer.hpp"
 #include "ipc_stream_reader.hpp"
+#include "scan_operator.hpp"
 
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
@@ -176,43 +177,32 @@ void ChunkCollection::AppendNode(int32_t ni, const mi_vector& v, int64_t start, 
   }
   // strings: one pass over the rows decides how the long-string payloads of this slice are staged
   int64_t extra_heap = 0, payload = 0;
-  bool grow_run = false;
-  uint64_t slice_hi = 0;
+  bool one_copy = false;
+  uint64_t region_lo = 0, region_hi = 0;
   if (columns[static_cast<size_t>(ni)].enc_kind == MI_K_ENC_STR32) {
-    Column& sc = columns[static_cast<size_t>(ni)];
     const mi_string_t* s = static_cast<const mi_string_t*>(v.data) + start;
-    bool contiguous = sc.run_open;
-    uint64_t expect = sc.run_end;           // where the next long string may start at the earliest
-    int64_t since = sc.rows_since_long;
+    const uint64_t heap_lo = reinterpret_cast<uint64_t>(v.heap), heap_hi = heap_lo + static_cast<uint64_t>(v.heap_size > 0 ? v.heap_size : 0);
+    bool ascending_inside = v.heap != nullptr;
     int64_t long_bytes = 0;
-    uint64_t first_long = 0;
+    uint64_t prev_end = 0;
     for (int64_t i = 0; i < n; i++) {
-      if (!BitAt(v.validity, vbit + i)) { since++; continue; }
+      if (!BitAt(v.validity, vbit + i)) continue;
       const uint32_t len = s[i].value.inlined.length;
       payload += len;
-      if (len <= 12) { since++; continue; }
+      if (len <= 12) continue;
       const uint64_t p = s[i].value.pointer.ptr;
       long_bytes += len;
-      if (first_long == 0) first_long = p;
-      if (contiguous && expect != 0 && (p < expect || p - expect > static_cast<uint64_t>(12 * since))) contiguous = false;
-      expect = p + len;
-      since = 0;
+      if (region_lo == 0) region_lo = p;
+      if (p < prev_end || p < heap_lo || p > heap_hi || len > heap_hi - p) ascending_inside = false;
+      prev_end = p + len;
     }
+    region_hi = prev_end;
     if (long_bytes > 0) {
-      if (contiguous) {  // [run_end (or the first long string), expect) continues the run
-        grow_run = true;
-        slice_hi = expect;
-        const uint64_t from = sc.run_end ? sc.run_end : first_long;
-        extra_heap = static_cast<int64_t>(slice_hi - from);
-        if (sc.run_end == 0) {
-          sc.ptr_base = first_long - static_cast<uint64_t>(sc.heap_used);  // heap_used is 0 here: a run starts a row group
-          sc.run_end = first_long;
-        }
-      } else {
-        extra_heap = long_bytes;
-      }
+      // one copy of [first long string, end of the last) when that range is known to be one allocation and is not much
+      // larger than what it is needed for (short and NULL rows in between own at most 12 bytes each there)
+      one_copy = ascending_inside && region_hi - region_lo <= static_cast<uint64_t>(long_bytes) + 16ull * static_cast<uint64_t>(n);
+      extra_heap = one_copy ? static_cast<int64_t>(region_hi - region_lo) : long_bytes;
     }
-    sc.rows_since_long = since;
   }
   Reserve(columns[static_cast<size_t>(ni)], columns[static_cast<size_t>(ni)].count + n, extra_heap);
   Column& c = columns[static_cast<size_t>(ni)];  // (children are appended after this block: `columns` never grows here)
@@ -261,24 +251,24 @@ void ChunkCollection::AppendNode(int32_t ni, const mi_vector& v, int64_t start, 
               static_cast<size_t>(n) * static_cast<size_t>(c.width));
   if (c.enc_kind == MI_K_ENC_STR32) {
     c.payload_bytes += payload;
-    if (grow_run) {
-      // the string_t rows stay as they are; the new source bytes extend the staged run
-      std::memcpy(c.heap + (c.run_end - c.ptr_base), reinterpret_cast<const void*>(static_cast<uintptr_t>(c.run_end)),
-                  static_cast<size_t>(slice_hi - c.run_end));
-      c.run_end = slice_hi;
-      c.heap_used = static_cast<int64_t>(c.run_end - c.ptr_base);
-    } else if (extra_heap > 0) {
-      // not laid out back to back: gather string by string; the pointer becomes ptr_base + heap offset
-      c.run_open = false;
+    if (extra_heap > 0) {
       mi_string_t* dst = reinterpret_cast<mi_string_t*>(c.data) + c.count;
-      for (int64_t i = 0; i < n; i++) {
+      if (one_copy) std::memcpy(c.heap + c.heap_used, reinterpret_cast<const void*>(static_cast<uintptr_t>(region_lo)), static_cast<size_t>(extra_heap));
+      int64_t at = c.heap_used;
+      for (int64_t i = 0; i < n; i++) {   // the staged rows point at heap offsets
         if (!BitAt(v.validity, vbit + i)) continue;
         const uint32_t len = dst[i].value.inlined.length;
         if (len <= 12) continue;
-        std::memcpy(c.heap + c.heap_used, reinterpret_cast<const void*>(static_cast<uintptr_t>(dst[i].value.pointer.ptr)), len);
-        dst[i].value.pointer.ptr = c.ptr_base + static_cast<uint64_t>(c.heap_used);
-        c.heap_used += len;
+        const uint64_t p = dst[i].value.pointer.ptr;
+        if (one_copy) {
+          dst[i].value.pointer.ptr = static_cast<uint64_t>(c.heap_used) + (p - region_lo);
+        } else {
+          std::memcpy(c.heap + at, reinterpret_cast<const void*>(static_cast<uintptr_t>(p)), len);
+          dst[i].value.pointer.ptr = static_cast<uint64_t>(at);
+          at += len;
+        }
       }
+      c.heap_used += extra_heap;
     }
     size_in_bytes += extra_heap;
   }
@@ -291,9 +281,6 @@ void ChunkCollection::Reset() {
     c.count = 0;
     c.heap_used = 0;
     c.ptr_base = 0;
-    c.run_end = 0;
-    c.run_open = true;
-    c.rows_since_long = 0;
     c.payload_bytes = 0;
     c.has_nulls = false;
     if (c.validity) std::memset(c.validity, 0xFF, c.validity_cap);
@@ -303,14 +290,23 @@ void ChunkCollection::Reset() {
 }
 
 // ------------------------------------------------------------------------------------------------ serializer
-ColumnDataCollectionSerializer::ColumnDataCollectionSerializer(Context* ctx_p) : ctx(ctx_p) {}
+ColumnDataCollectionSerializer::ColumnDataCollectionSerializer(Context* ctx_p, bool own_stream) : ctx(ctx_p) {
+  stream = ctx->stream;
+  if (own_stream) {
+    ctx->Bind();
+    MI_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    owns_stream = true;
+  }
+}
 
 ColumnDataCollectionSerializer::~ColumnDataCollectionSerializer() {
   h_bodies[cur_body] = h_body;
   for (auto* b : h_bodies)
     if (b) (void)hipHostFree(b);
+  plan.reset();
   if (d_body) (void)hipFree(d_body);
   if (d_in) (void)hipFree(d_in);
+  if (owns_stream && stream) (void)hipStreamDestroy(stream);
 }
 
 void ColumnDataCollectionSerializer::Init(const ArrowSchemaModel* schema_p) { schema = schema_p; }
@@ -380,7 +376,7 @@ idx_t ColumnDataCollectionSerializer::Serialize(ChunkCollection& buffer) {
   GrowDevice(&d_body, &d_body_cap, body_off + 256);
   { size_t zero = 0; GrowPinned(&h_body, &h_body_cap, body_off + 256, zero); }
 
-  hipStream_t s = ctx->stream;
+  hipStream_t s = stream;
   MI_HIP_CHECK(hipMemsetAsync(d_body, 0, body_off, s));  // the padding bytes of every buffer are zero
   std::vector<mi_col_task> tasks;
   std::vector<int32_t> validity_task(n_nodes, -1);  // task whose NULL counter belongs to node ci
@@ -473,11 +469,11 @@ void ArrowStreamWriter::InitOutputFile(const std::string& file_path) {
   if (fd < 0) throw IOException("Cannot open file \"" + file_path + "\": " + std::strerror(errno));
 }
 
-void ArrowStreamWriter::WriteData(const uint8_t* p, size_t n) {
+void ArrowStreamWriter::WriteAt(int64_t offset, const uint8_t* p, size_t n) {
   ScopedTimer timer(&Timers().write);
   size_t done = 0;
   while (done < n) {
-    ssize_t w = ::write(fd, p + done, n - done);
+    ssize_t w = ::pwrite(fd, p + done, n - done, static_cast<off_t>(offset + static_cast<int64_t>(done)));
     if (w < 0) {
       if (errno == EINTR) continue;
       throw IOException("Could not write to file \"" + file_name + "\": " + std::strerror(errno));
@@ -486,10 +482,27 @@ void ArrowStreamWriter::WriteData(const uint8_t* p, size_t n) {
   }
 }
 
+int64_t ArrowStreamWriter::ReserveRowGroup(size_t bytes) {
+  std::lock_guard<std::mutex> lk(io_mu);
+  const int64_t at = static_cast<int64_t>(total_written);
+  total_written += bytes;
+  ++row_group_count;
+  return at;
+}
+
+void ArrowStreamWriter::WriteData(const uint8_t* p, size_t n) {
+  int64_t at;
+  {
+    std::lock_guard<std::mutex> lk(io_mu);
+    at = static_cast<int64_t>(total_written);
+    total_written += n;
+  }
+  WriteAt(at, p, n);
+}
+
 void ArrowStreamWriter::WriteSchema() {
   serializer.SerializeSchema();
   WriteData(serializer.GetHeader().data(), serializer.GetHeader().size());
-  total_written += serializer.GetHeader().size();
 }
 
 void ArrowStreamWriter::IoLoop() {
@@ -504,8 +517,8 @@ void ArrowStreamWriter::IoLoop() {
     }
     try {
       if (!io_error) {
-        WriteData(job.header.data(), job.header.size());
-        WriteData(job.body, job.body_size);
+        WriteAt(job.offset, job.header.data(), job.header.size());
+        WriteAt(job.offset + static_cast<int64_t>(job.header.size()), job.body, job.body_size);
       }
     } catch (...) {
       std::lock_guard<std::mutex> lk(io_mu);
@@ -536,7 +549,7 @@ void ArrowStreamWriter::Flush(ChunkCollection& buffer) {
   WaitBufferFree(serializer.CurrentBody());
   if (serializer.Serialize(buffer) == 0) {
     buffer.Reset();
-    ++row_group_count;  // the reference counts the flush even when the collection was empty (arrow_stream_writer.cpp:66-71)
+    CountEmptyFlush();  // the reference counts the flush even when the collection was empty (arrow_stream_writer.cpp:66-71)
     return;
   }
   buffer.Reset();
@@ -544,7 +557,7 @@ void ArrowStreamWriter::Flush(ChunkCollection& buffer) {
   job.header = serializer.GetHeader();
   job.body = serializer.GetBody();
   job.body_size = static_cast<size_t>(serializer.GetBodySize());
-  total_written += job.header.size() + job.body_size;
+  job.offset = ReserveRowGroup(job.header.size() + job.body_size);
   {
     std::lock_guard<std::mutex> lk(io_mu);
     job.buffer = serializer.SwapBody();
@@ -553,7 +566,6 @@ void ArrowStreamWriter::Flush(ChunkCollection& buffer) {
     if (!io_thread.joinable()) io_thread = std::thread([this] { IoLoop(); });
   }
   io_cv.notify_all();
-  ++row_group_count;
 }
 
 void ArrowStreamWriter::Finalize() {
@@ -561,7 +573,6 @@ void ArrowStreamWriter::Finalize() {
   DrainIo();
   const uint8_t end_of_stream[] = {0xFF, 0xFF, 0xFF, 0xFF, 0x00, 0x00, 0x00, 0x00};
   WriteData(end_of_stream, sizeof(end_of_stream));
-  total_written += sizeof(end_of_stream);
   ::close(fd);
   fd = -1;
   finalized = true;
@@ -577,6 +588,10 @@ using namespace miarrow;
 
 namespace miarrow {
 Context* ContextOf(mi_ctx* c);
+}
+
+namespace miarrow {
+ArrowScan* SingleScanOf(mi_scan* s);  // scan_operator.cpp
 }
 
 struct mi_writer {
@@ -758,7 +773,256 @@ int mi_writer_sink(mi_writer* w, const mi_data_chunk* chunk) {
   });
 }
 
+// ---- per-thread sink state (ArrowWriteInitializeLocal / Sink / Combine, write_arrow_stream.cpp:141-174): every sink
+// thread buffers its own chunks AND serializes its own row groups (H2D + K7 + D2H on a stream of its own), so staging,
+// encoding and writing of different row groups overlap; only the claim of the file range is serialised.
+}  // extern "C"
+
+struct mi_writer_local {
+  mi_writer* w = nullptr;
+  std::unique_ptr<ChunkCollection> buffer;
+  std::unique_ptr<ColumnDataCollectionSerializer> serializer;
+  //! serializes the buffered rows as one record batch and writes it at the next free position of the file
+  void FlushRowGroup(const std::function<void()>& before_claim = nullptr, const std::function<void()>& after_claim = nullptr) {
+    ArrowStreamWriter& out = *w->writer;
+    if (serializer->Serialize(*buffer) == 0) {
+      buffer->Reset();
+      if (before_claim) before_claim();
+      out.CountEmptyFlush();
+      if (after_claim) after_claim();
+      return;
+    }
+    buffer->Reset();
+    const auto& header = serializer->GetHeader();
+    const size_t body = static_cast<size_t>(serializer->GetBodySize());
+    if (before_claim) before_claim();   // ordered sinks wait for their turn here
+    const int64_t at = out.ReserveRowGroup(header.size() + body);
+    if (after_claim) after_claim();
+    out.WriteAt(at, header.data(), header.size());
+    out.WriteAt(at + static_cast<int64_t>(header.size()), serializer->GetBody(), body);
+  }
+};
+
+namespace {
+std::unique_ptr<mi_writer_local> MakeLocal(mi_writer* w) {
+  auto l = std::make_unique<mi_writer_local>();
+  l->w = w;
+  l->buffer = std::make_unique<ChunkCollection>(w->ctx, w->fields);
+  l->serializer = std::make_unique<ColumnDataCollectionSerializer>(w->ctx, /*own_stream*/ true);
+  l->serializer->Init(&w->writer->Schema());
+  return l;
+}
+
+int SinkThreads() {
+  const char* v = std::getenv("MI_WRITER_THREADS");
+  if (v) return std::max(1, std::min(16, std::atoi(v)));
+  const int hw = static_cast<int>(std::thread::hardware_concurrency());
+  return std::max(1, std::min(6, hw / 3));
+}
+
+// COPY (FROM read_arrow(...)) TO 'file': the pump DuckDB's executor is between a scan and a copy sink, with the batch
+// copy's re-partitioning (PhysicalBatchCopyToFile hands prepare_batch collections of desired_batch_size = row_group_size
+// rows, write_arrow_stream.cpp:225-245).  The pump thread pulls whole record batches from the scan and cuts the stream of
+// their 2048-row chunks into row groups exactly where the one-thread sink would flush (after the chunk that reaches
+// row_group_size rows / row_group_size_bytes); each row group goes to one of T sink threads which appends its chunks,
+// encodes it and writes it -- claims of the file range happen in row-group order, so the file equals the one-thread file.
+void PumpScanParallel(mi_writer* w, ArrowScan* scan, int threads, int64_t* rows_out) {
+  struct Piece { int batch; int32_t w0, w1; };        // windows [w0, w1) of held batch `batch`
+  struct Job { std::vector<Piece> pieces; int64_t seq = 0; };
+  struct Held { BatchRef ref; int pieces_open = 0; bool fully_cut = false; };
+  scan->EnsurePipelineDepth(threads + 4);
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<Job> jobs;
+  std::vector<Held> held;             // index = batch token
+  std::deque<int> to_release;         // tokens whose last piece was appended (released by the pump thread: it owns the scan)
+  int64_t next_claim = 0;             // sequence number of the row group that may claim its file range next
+  bool done = false;
+  std::exception_ptr error;
+  std::vector<std::thread> workers;
+  auto fail = [&](std::exception_ptr e) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!error) error = e;
+    cv.notify_all();
+  };
+  for (int t = 0; t < threads; t++) {
+    workers.emplace_back([&] {
+      try {
+        auto local = MakeLocal(w);
+        ChunkStorage storage;
+        mi_data_chunk chunk;
+        while (true) {
+          Job job;
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return error || done || !jobs.empty(); });
+            if (error) return;
+            if (jobs.empty()) return;  // done
+            job = std::move(jobs.front());
+            jobs.pop_front();
+          }
+          for (const Piece& pc : job.pieces) {
+            BatchRef ref;
+            {
+              std::lock_guard<std::mutex> lk(mu);
+              ref = held[static_cast<size_t>(pc.batch)].ref;
+            }
+            for (int32_t wi = pc.w0; wi < pc.w1; wi++) {
+              scan->BuildChunk(ref, wi, &storage, &chunk);
+              local->buffer->Append(chunk);
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            Held& h = held[static_cast<size_t>(pc.batch)];
+            if (--h.pieces_open == 0 && h.fully_cut) {
+              to_release.push_back(pc.batch);
+              cv.notify_all();
+            }
+          }
+          local->FlushRowGroup(
+              [&] {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return error || next_claim == job.seq; });
+              },
+              [&] {
+                std::lock_guard<std::mutex> lk(mu);
+                next_claim = job.seq + 1;
+                cv.notify_all();
+              });
+        }
+      } catch (...) {
+        fail(std::current_exception());
+      }
+    });
+  }
+  int64_t rows = 0, seq = 0;
+  try {
+    Job cur;
+    int64_t cur_rows = 0, cur_bytes = 0;
+    const int64_t row_bytes = std::max<int64_t>(1, [&] {   // staged bytes per row, for row_group_size_bytes
+      int64_t b = 0;
+      for (auto& c : scan->OutputColumns()) {
+        int32_t kind, wd, nb;
+        int64_t param;
+        if (!c.is_filename && !c.is_hive && c.field.Plan(&kind, &param, &wd, &nb)) b += wd; else b += 16;
+      }
+      return b;
+    }());
+    auto dispatch = [&] {
+      if (cur.pieces.empty()) return;
+      cur.seq = seq++;
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        jobs.push_back(std::move(cur));
+      }
+      cv.notify_all();
+      cur = Job();
+      cur_rows = cur_bytes = 0;
+    };
+    auto release_ready = [&](bool wait) {
+      std::unique_lock<std::mutex> lk(mu);
+      if (wait) cv.wait(lk, [&] { return error || !to_release.empty(); });
+      if (error) std::rethrow_exception(error);
+      while (!to_release.empty()) {
+        const int tok = to_release.front();
+        to_release.pop_front();
+        const BatchRef ref = held[static_cast<size_t>(tok)].ref;
+        lk.unlock();
+        scan->ReleaseBatch(ref);
+        lk.lock();
+      }
+    };
+    while (true) {
+      release_ready(false);
+      BatchRef ref;
+      if (!scan->AcquireBatch(&ref)) {
+        if (scan->Exhausted()) break;
+        release_ready(true);   // every slot is held by a sink thread: wait for one to come back
+        continue;
+      }
+      rows += ref.chunk_rows;
+      int tok;
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        held.push_back(Held{ref, 0, false});
+        tok = static_cast<int>(held.size() - 1);
+      }
+      if (ref.n_windows == 0) {
+        std::lock_guard<std::mutex> lk(mu);
+        held[static_cast<size_t>(tok)].fully_cut = true;
+        to_release.push_back(tok);
+        continue;
+      }
+      int32_t w0 = 0;
+      for (int32_t wi = 0; wi < ref.n_windows; wi++) {
+        const int64_t n = std::min<int64_t>(MI_VECTOR_SIZE, ref.chunk_rows - static_cast<int64_t>(wi) * MI_VECTOR_SIZE);
+        cur_rows += n;
+        cur_bytes += n * row_bytes;
+        const bool full = cur_rows >= w->opts.row_group_size || cur_bytes >= w->opts.row_group_size_bytes;
+        if (full || wi + 1 == ref.n_windows) {
+          {
+            std::lock_guard<std::mutex> lk(mu);
+            held[static_cast<size_t>(tok)].pieces_open++;
+            if (wi + 1 == ref.n_windows) held[static_cast<size_t>(tok)].fully_cut = true;
+          }
+          cur.pieces.push_back(Piece{tok, w0, wi + 1});
+          w0 = wi + 1;
+          if (full) dispatch();
+        }
+      }
+    }
+    dispatch();   // the tail row group (ArrowWriteCombine)
+  } catch (...) {
+    fail(std::current_exception());
+  }
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    done = true;
+  }
+  cv.notify_all();
+  for (auto& t : workers) t.join();
+  // give every batch back before reporting
+  for (int tok : to_release) scan->ReleaseBatch(held[static_cast<size_t>(tok)].ref);
+  if (error) std::rethrow_exception(error);
+  if (rows_out) *rows_out = rows;
+}
+}  // namespace
+
+extern "C" {
+
+int mi_writer_local_create(mi_writer* w, mi_writer_local** out) {
+  return WrapC([&] {
+    if (!w || !w->writer || !out) throw InvalidInputException("mi_writer_local_create: bad argument");
+    *out = MakeLocal(w).release();
+  });
+}
+
+int mi_writer_local_sink(mi_writer_local* l, const mi_data_chunk* chunk) {
+  return WrapC([&] {
+    if (!l || !chunk) throw InvalidInputException("mi_writer_local_sink: bad argument");
+    l->buffer->Append(*chunk);
+    if (l->buffer->Count() >= l->w->opts.row_group_size || l->buffer->SizeInBytes() >= l->w->opts.row_group_size_bytes) l->FlushRowGroup();
+  });
+}
+
+int mi_writer_local_combine(mi_writer_local* l) {
+  return WrapC([&] {
+    if (!l) throw InvalidInputException("mi_writer_local_combine: NULL");
+    if (l->buffer->Count() > 0) l->FlushRowGroup();
+  });
+}
+
+void mi_writer_local_destroy(mi_writer_local* l) { delete l; }
+
 int mi_writer_sink_scan(mi_writer* w, mi_scan* scan, int64_t* rows) {
+  if (!w || !w->writer || !scan) return WrapC([] { throw InvalidInputException("mi_writer_sink_scan: bad argument"); });
+  ArrowScan* single = SingleScanOf(scan);
+  const int threads = SinkThreads();
+  if (single && single->HostConsumer() && threads > 1 && w->buffer->Count() == 0) {
+    return WrapC([&] {
+      if (!single->Initialized()) single->Init({});
+      PumpScanParallel(w, single, threads, rows);
+    });
+  }
   int64_t n = 0;
   mi_data_chunk ch;
   while (true) {

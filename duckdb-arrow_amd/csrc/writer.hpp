@@ -57,13 +57,11 @@ class ChunkCollection {
     int64_t payload_bytes = 0;    // sum of valid string lengths = size of the Arrow data buffer (list: child rows gathered)
     bool has_nulls = false;
     bool large_offsets = false;   // int64 Arrow offsets (arrow_large_buffer_size)
-    // long-string payloads: while the incoming strings lie back to back in row order (Arrow data buffers, DuckDB string
-    // heaps filled in order) the source bytes are staged as ONE growing run and the string_t rows keep their pointers
-    // (heap offset = pointer - ptr_base); anything else is gathered string by string behind the run
-    uint64_t ptr_base = 0;        // pointer value of heap[0]
-    uint64_t run_end = 0;         // source address one past the staged run (0: no run)
-    bool run_open = true;         // the run can still grow (nothing has been gathered behind it yet)
-    int64_t rows_since_long = 0;  // rows appended since the last long string (each may own <= 12 inline bytes in between)
+    // long-string payloads are staged in `heap` and the staged string_t rows point at heap offsets (ptr_base 0).  When the
+    // source vector declares the allocation its long strings live in (mi_vector.heap: the Arrow data buffer of a scanned
+    // record batch) and they ascend inside it, the bytes from the first to the last long string of an appended slice are
+    // staged with ONE copy; otherwise string by string.  Nothing outside a declared allocation or a string is ever read.
+    uint64_t ptr_base = 0;        // pointer value of heap[0] as the staged string_t rows see it (always 0)
     std::vector<int32_t> children;
     bool IsList() const { return arrow_type == MI_AT_LIST || arrow_type == MI_AT_LARGE_LIST || arrow_type == MI_AT_MAP; }
     bool IsGroup() const { return arrow_type == MI_AT_STRUCT || arrow_type == MI_AT_FIXED_LIST; }
@@ -82,7 +80,8 @@ class ChunkCollection {
 
 class ColumnDataCollectionSerializer {
  public:
-  explicit ColumnDataCollectionSerializer(Context* ctx);
+  //! own_stream: the encode runs on a stream of its own (one serializer per sink thread: their H2D / K7 / D2H overlap)
+  explicit ColumnDataCollectionSerializer(Context* ctx, bool own_stream = false);
   ~ColumnDataCollectionSerializer();
   void Init(const ArrowSchemaModel* schema);
   void SerializeSchema();
@@ -117,6 +116,8 @@ class ColumnDataCollectionSerializer {
   uint8_t* d_in = nullptr;    size_t d_in_cap = 0;
   int64_t body_size = 0;
   std::unique_ptr<Plan> plan;
+  hipStream_t stream = nullptr;
+  bool owns_stream = false;
 };
 
 class ArrowStreamWriter {
@@ -127,6 +128,14 @@ class ArrowStreamWriter {
   void WriteSchema();
   void Flush(ChunkCollection& buffer);
   void Finalize();
+  // ---- thread-safe half, for sink threads that serialize their own row groups (write_arrow_stream.cpp:141-159: every
+  // DuckDB thread has a local state; here each also owns a serializer) ----
+  //! Claims the next `bytes` of the file for one record-batch message and counts the row group
+  int64_t ReserveRowGroup(size_t bytes);
+  //! pwrite of a claimed range (any thread, no lock)
+  void WriteAt(int64_t offset, const uint8_t* p, size_t n);
+  void CountEmptyFlush() { std::lock_guard<std::mutex> lk(io_mu); ++row_group_count; }
+  Context* GetContext() const { return ctx; }
   idx_t NumberOfRowGroups() const { return row_group_count; }
   idx_t FileSize() const { return total_written; }
   const ArrowSchemaModel& Schema() const { return schema; }
@@ -134,7 +143,7 @@ class ArrowStreamWriter {
  private:
   void InitSchema(const std::vector<ArrowField>& fields, const std::vector<std::pair<std::string, std::string>>& metadata);
   void InitOutputFile(const std::string& file_path);
-  void WriteData(const uint8_t* p, size_t n);
+  void WriteData(const uint8_t* p, size_t n);   // appends at the end of what has been claimed so far
 
   // record-batch messages are written by an I/O thread while the sink stages the next row group; two body buffers
   // alternate (the reference writes synchronously inside Flush, arrow_stream_writer.cpp:66-77)
@@ -143,6 +152,7 @@ class ArrowStreamWriter {
     const uint8_t* body = nullptr;
     size_t body_size = 0;
     int buffer = -1;
+    int64_t offset = 0;   // claimed position of the message in the file
   };
   void IoLoop();
   void WaitBufferFree(int buffer);

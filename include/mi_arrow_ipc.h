@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 1
+#define MI_ABI_VERSION 2
 
 /* ---------------------------------------------------------------------------------------------------------
  * Status codes.  Same errno values the reference maps its exceptions to at the Arrow C stream boundary
@@ -289,6 +289,11 @@ typedef struct mi_col_task {
   int32_t flags;          /* decode with out_aux: parent row = row / flags (0 or 1: same row; n: fixed_size_list of n) */
   int32_t depth;          /* nesting depth: tasks run depth by depth so a child sees its parent's finished validity */
   int32_t _reserved;
+  /* Gather mode (late materialisation through a pushed-down filter's selection vector): when `sel` is set, only the rows
+   * sel[2048 w + i], i < sel_count[w], of every 2048-row window w are decoded; they land compacted at the start of the
+   * window's vector slot (out_data + 2048 w * width, validity word 32 w).  Top-level flat kinds only. */
+  const void* sel;        /* mi_sel_t[nrows]: ascending window-relative row indices per window (device) */
+  const void* sel_count;  /* uint32_t[ceil(nrows / 2048)] (device) */
 } mi_col_task;
 
 /* Error bits a plan accumulates on the device (polled by mi_plan_status). */
@@ -310,8 +315,8 @@ int mi_plan_launch(mi_plan* plan, void* stream);
 int mi_plan_status(mi_plan* plan, uint32_t* status_bits);
 /* Algorithmic bytes of one launch: Arrow buffer bytes consumed + DuckDB vector bytes produced, and tiles. */
 int mi_plan_stats(const mi_plan* plan, int64_t* bytes_read, int64_t* bytes_written, int64_t* rows, int64_t* tiles);
-/* Kernel classes of a plan (one launch each): 0 copy, 1 dec128, 2 string, 3 misc, 4 encode-fixed, 5 encode-string. */
-#define MI_NUM_KERNEL_CLASSES 6
+/* Kernel classes of a plan: 0 copy, 1 dec128, 2 string, 3 misc, 4 encode-fixed, 5 encode-string, 6 gather (tasks with `sel`). */
+#define MI_NUM_KERNEL_CLASSES 7
 /* Per-class share of mi_plan_stats (0 for classes the plan does not use) + the kernel's name as rocprof prints it. */
 int mi_plan_class_stats(const mi_plan* plan, int32_t kernel_class, int64_t* bytes_read, int64_t* bytes_written,
                         int64_t* rows, int64_t* tiles, const char** kernel_name);
@@ -323,9 +328,101 @@ int mi_plan_null_counts(mi_plan* plan, int64_t* out, int32_t n_tasks);
 /* Maps a status word to the errno + message the reference would raise. Returns MI_OK for 0. */
 int mi_status_to_error(uint32_t status_bits);
 
-/* K6 (extension: the reference sets filter_pushdown=false, read_arrow.cpp:47-48): range predicate
- * lo <= v < hi on a decoded fixed-width vector + validity -> per-2048-row-window selection vectors.
- * sel_out[window*2048 ...] holds ascending window-relative row indices, count_out[window] their number. */
+/* ---------------------------------------------------------------------------------------------------------
+ * HBM-resident streams (the mode the roofline is measured in).  A whole Arrow IPC stream is uploaded
+ * once; mi_hbm_open parses every message on the host, lays out one DuckDB vector array per (record batch, field node) in
+ * one output arena and builds ONE plan over all of them: a launch is a handful of kernels however many record batches
+ * the stream holds.  The layout is the scan operator's own planner (one planner for both modes).
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct mi_hbm mi_hbm;
+
+enum mi_hbm_pointer_mode {
+  MI_HBM_PTR_DEVICE = 0,         /* string_t long pointers are device addresses inside the resident stream (GPU consumers) */
+  MI_HBM_PTR_STREAM_OFFSET = 1,  /* ... are byte positions inside the stream (position-independent; what the parity tests compare) */
+  MI_HBM_PTR_HOST = 2            /* ... are host addresses inside `host_stream` (host consumers after a D2H of the vectors) */
+};
+
+typedef struct mi_hbm_options {
+  const char* const* columns;    /* projection by name (IPCStreamReader::SetColumnProjection), NULL = all columns */
+  int32_t n_columns;
+  int32_t accept_dictionaries;   /* decode DictionaryBatch messages + dictionary-encoded columns (last batch per id; no deltas) */
+  int32_t zero_copy_direct;      /* plain fixed-width columns without NULLs get no task: their vector IS the Arrow buffer in
+                                  * HBM (mi_hbm_node.alias_off), like the reference's DirectConversion */
+  int32_t unset_all_valid;       /* columns with null_count == 0 get no validity words (mi_hbm_node.valid_off = -1), like
+                                  * the reference, which leaves the ValidityMask of such a vector unset */
+  int32_t pointer_mode;          /* enum mi_hbm_pointer_mode */
+  int32_t defer_arena;           /* 1: do not allocate the output arena; the caller binds one with mi_hbm_set_arena */
+  int64_t array_align;           /* alignment of every output array inside the arena, power of two; 0 = 65536 */
+  void* device_stream;           /* optional: the stream already resident in HBM (caller-owned, >= size + 64 bytes readable);
+                                  * NULL = the library uploads `host_stream` into its own allocation */
+  void* device_arena;            /* optional: caller-owned output arena of device_arena_bytes (see mi_hbm_layout.arena_bytes) */
+  int64_t device_arena_bytes;
+} mi_hbm_options;
+
+/* One field node of one message (depth first; nodes of a batch are consecutive; children name their parent). */
+typedef struct mi_hbm_node {
+  char name[64];
+  int32_t kind;                  /* enum mi_kind */
+  int32_t out_width;
+  int32_t arrow_type;            /* enum mi_arrow_type */
+  int32_t depth;
+  int32_t parent;                /* global node index, -1 = a top-level column */
+  int32_t batch;                 /* index into mi_hbm_layout.batches */
+  int64_t param, nrows, null_count;
+  int64_t dict_id;               /* MI_K_DICT: the dictionary its sel_t values index, else -1 */
+  int64_t data_off;              /* arena offset of the vector data; -1 when aliased */
+  int64_t valid_off;             /* arena offset of the validity words; -1 = not materialised: every row valid */
+  int64_t alias_off;             /* >= 0: zero-copy, the values are the stream bytes at this position */
+  uint64_t ptr_base;             /* string kinds: string_t long pointers = ptr_base + offset inside the Arrow data buffer */
+  int32_t first_span, n_spans;   /* mi_hbm_layout.spans: the node's Arrow buffers as {position in the stream, length} */
+  int32_t first_window, n_windows; /* mi_hbm_layout.windows: first row (this node's row space) of every 2048-row chunk + end */
+} mi_hbm_node;
+
+typedef struct mi_hbm_batch {
+  int64_t nrows;
+  int64_t body_off, body_len;    /* the message body inside the stream */
+  int64_t arena_begin, arena_end;/* this message's part of the arena */
+  int32_t first_node, n_nodes;
+  int32_t n_columns;             /* its top-level columns = the nodes with parent -1, in order */
+  int32_t is_dictionary;         /* 1: the decoded values of dictionary dict_id (nrows entries + one NULL slot) */
+  int64_t dict_id;
+} mi_hbm_batch;
+
+typedef struct mi_hbm_layout {
+  const mi_hbm_batch* batches;   /* dictionaries first, then the record batches in stream order */
+  int32_t n_batches;
+  int32_t n_nodes;
+  const mi_hbm_node* nodes;
+  const mi_buffer_span* spans;
+  const int64_t* windows;
+  int64_t arena_bytes;
+  int64_t stream_bytes;
+  int64_t n_rows;                /* rows of all record batches */
+  void* device_stream;           /* the stream in HBM */
+  void* device_arena;            /* NULL until an arena is bound */
+  int32_t n_tasks;               /* tasks of the plan */
+  int32_t _pad;
+} mi_hbm_layout;
+
+int mi_hbm_open(mi_ctx* ctx, const void* host_stream, int64_t size, const mi_hbm_options* opts, mi_hbm** out);
+void mi_hbm_close(mi_hbm* h);
+int mi_hbm_set_arena(mi_hbm* h, void* device_arena, int64_t bytes);
+/* Pointers stay valid until mi_hbm_close. */
+int mi_hbm_layout_get(mi_hbm* h, mi_hbm_layout* out);
+/* One pass of the hot path over the whole stream; asynchronous on `stream` (a hipStream_t, NULL = the context's own). */
+int mi_hbm_launch(mi_hbm* h, void* stream);
+/* Like mi_plan_launch_timed / _status / _stats / _class_stats, for the stream's plan. */
+int mi_hbm_launch_timed(mi_hbm* h, void* stream, float* ms_per_class /* [MI_NUM_KERNEL_CLASSES] */);
+int mi_hbm_status(mi_hbm* h, uint32_t* status_bits);
+int mi_hbm_stats(mi_hbm* h, int64_t* bytes_read, int64_t* bytes_written, int64_t* rows, int64_t* tiles);
+int mi_hbm_class_stats(mi_hbm* h, int32_t kernel_class, int64_t* bytes_read, int64_t* bytes_written, int64_t* rows,
+                       int64_t* tiles, const char** kernel_name);
+/* D2H of [offset, offset + length) of the arena (from_stream = 0) or of the resident stream (1); synchronous. */
+int mi_hbm_fetch(mi_hbm* h, int32_t from_stream, int64_t offset, int64_t length, void* host_dst);
+
+/* K6 at kernel level (extension: the reference sets filter_pushdown=false, read_arrow.cpp:47-48): range predicate
+ * lo <= v < hi on a decoded fixed-width vector (width 1, 2, 4 or 8, signed) + validity -> per-2048-row-window selection
+ * vectors.  sel_out[window*2048 ...] holds ascending window-relative row indices, count_out[window] their number. */
 int mi_filter_range(mi_ctx* ctx, const void* values, int32_t width, const void* validity, int64_t nrows, int64_t lo,
                     int64_t hi, mi_sel_t* sel_out, uint32_t* count_out, void* stream);
 
@@ -350,7 +447,19 @@ typedef struct mi_scan_options {
                                  * vector's data points INTO the record-batch body (host body for host consumers, which
                                  * then is not DMA'd to the GPU at all; HBM copy of the body when device_resident) and
                                  * its validity is NULL = all valid -- the reference's zero-copy DirectConversion +
-                                 * unset ValidityMask.  The body stays alive until the chunk after the batch's last. */
+                                 * unset ValidityMask.  The body stays alive until the chunk after the batch's last.
+                                 * 0 = default: ON for device_resident scans (what the reference does; the GPU consumer
+                                 * reads the Arrow buffer in HBM), OFF for host consumers; -1 = never. */
+  int32_t unset_all_valid;      /* 1: a column without NULLs in a record batch gets no validity words: mi_vector.validity is
+                                 * NULL (= all valid), like the reference's unset ValidityMask; 0: 32 all-ones words per chunk */
+  int32_t filter_compact;       /* with a pushed-down filter: 1 = late materialisation, chunks hold ONLY the selected rows
+                                 * (flat vectors of mi_data_chunk.size = sel_count rows, sel = NULL; rows that fail the
+                                 * predicate are never decoded or copied back); 0 = full vectors + a selection vector.
+                                 * Needs flat projected columns (no nested types, no string views). */
+  int32_t pipeline_depth;       /* record batches in flight on the GPU (pinned + HBM slots); 0 = 3 */
+  int32_t host_decompress;      /* compressed bodies: 1 = decompress on host threads before the H2D; 0 = ship the compressed
+                                 * body over PCIe and decompress it in HBM where a GPU decoder exists (LZ4_FRAME), else host */
+  int32_t _reserved[3];
 } mi_scan_options;
 
 /* read_arrow('path') / read_arrow(['a','b']) (read_arrow.cpp:78-83).  Globs are expanded by the caller. */
@@ -359,6 +468,15 @@ int mi_scan_open_files(mi_ctx* ctx, const char* const* paths, int32_t n_paths, c
 /* scan_arrow_ipc([{ptr,size},...]) (scan_arrow_ipc.cpp:24-33). */
 int mi_scan_open_buffers(mi_ctx* ctx, const mi_ipc_buffer* buffers, int32_t n_buffers, const mi_scan_options* opts,
                          mi_scan** out);
+/* read_arrow over several GPUs of one process (the reference's unit of parallelism is one thread per file,
+ * src/file_scanner/arrow_file_scan.cpp:35-42, arrow_multi_file_info.cpp:77-86).  One context per device (or several per
+ * device: each brings its own streams and pinned ring).  Record batch k of the file list (files first, then the batches
+ * inside a file) is decoded on context k mod n_ctxs; mi_scan_next returns the chunks in record-batch order whatever
+ * device produced them (batch_index), mi_scan_count / mi_scan_sum_product drain every device on its own thread.
+ * opts->rank / world compose: this scan takes every world-th batch first, then deals its share over the contexts.
+ * Every other mi_scan_* call works on the returned handle unchanged. */
+int mi_scan_open_files_multi(mi_ctx* const* ctxs, int32_t n_ctxs, const char* const* paths, int32_t n_paths,
+                             const mi_scan_options* opts, mi_scan** out);
 void mi_scan_close(mi_scan* s);
 /* Bind result: column names + DuckDB types (names deduplicated like QueryResult::DeduplicateColumns,
  * arrow_file_scan.cpp:19). "Provided table/dataframe must have at least one column" on empty schemas. */
@@ -382,6 +500,11 @@ typedef struct mi_vector {
   int32_t n_children;
   int32_t validity_shift;
   int64_t count;            /* rows in this vector (== chunk size for top-level vectors) */
+  /* string vectors: the one allocation every long-string pointer of this vector points into (the Arrow data buffer of
+   * the record batch), or NULL when unknown.  A sink may copy [heap, heap + heap_size) wholesale instead of string by
+   * string; without it pointers are followed one at a time. */
+  const void* heap;
+  int64_t heap_size;
 } mi_vector;
 
 typedef struct mi_data_chunk {
@@ -393,11 +516,34 @@ typedef struct mi_data_chunk {
   const mi_vector* columns; /* valid until the next mi_scan_next on this scan */
   const mi_sel_t* sel;      /* pushed-down filter: ascending chunk-relative row indices, NULL when no filter is set */
   int64_t sel_count;        /* rows selected (== size when no filter is set) */
+  int64_t source_rows;      /* rows of the record batch this chunk covers (== size unless filter_compact dropped rows) */
 } mi_data_chunk;
 
-/* Pushed-down range filter lo <= column < hi on a fixed-width integer/date/decimal(<=18) column (K6; the reference
- * sets filter_pushdown=false, read_arrow.cpp:47-48, so this is an extension: DuckDB's own filter above the scan
- * yields the same rows).  Chunks then carry a selection vector. Call between bind and the first next. */
+/* Pushed-down predicates (K6).  The reference sets filter_pushdown = false (read_arrow.cpp:47-48), so this is an
+ * extension: DuckDB's own filter above the scan yields the same rows.  The forms are the ones DuckDB's TableFilterSet
+ * hands a scan: col <op> constant with = <> < <= > >=, IS NULL, IS NOT NULL, IN (list), combined
+ * by AND / OR trees over any number of columns.  Comparison columns are fixed-width integer-like after the scan
+ * (integers, BOOLEAN, DATE, TIME / TIMESTAMP, DECIMAL(<=18)) and constants are the stored integers (DECIMAL(15,2) 0.05
+ * is 5); IS [NOT] NULL takes any column.  SQL semantics: a comparison with NULL is not true, so the row is dropped
+ * unless another branch of an OR keeps it.  A filter column need not be projected.  The tree is normalised to at most
+ * 24 leaves in conjunctive normal form; larger ones are refused with MI_ENOTSUP (DuckDB then keeps the filter above the
+ * scan).  Chunks carry a selection vector (or only the selected rows: mi_scan_options.filter_compact).  Call between
+ * bind and init. */
+enum mi_filter_op {
+  MI_F_EQ = 1, MI_F_NE = 2, MI_F_LT = 3, MI_F_LE = 4, MI_F_GT = 5, MI_F_GE = 6, MI_F_IS_NULL = 7, MI_F_IS_NOT_NULL = 8,
+  MI_F_IN = 9, MI_F_AND = 16, MI_F_OR = 17
+};
+typedef struct mi_filter_node {
+  int32_t op;             /* enum mi_filter_op */
+  int32_t first_child;    /* MI_F_AND / MI_F_OR: the children are nodes[first_child .. first_child + n_children) */
+  int32_t n_children;
+  int32_t n_values;       /* MI_F_IN */
+  const char* column;     /* leaves */
+  int64_t value;          /* comparison constant */
+  const int64_t* values;  /* MI_F_IN */
+} mi_filter_node;
+int mi_scan_set_filter(mi_scan* s, const mi_filter_node* nodes, int32_t n_nodes, int32_t root);
+/* Shorthand for lo <= column < hi. */
 int mi_scan_set_filter_range(mi_scan* s, const char* column, int64_t lo, int64_t hi);
 int mi_scan_next(mi_scan* s, mi_data_chunk* out);
 /* SELECT count(*) FROM read_arrow(...) (test/sql/read_arrow.test:35-38): pulls every remaining chunk natively.
@@ -474,11 +620,25 @@ int mi_writer_open(mi_ctx* ctx, const char* path, const mi_field* fields, int32_
 /* ArrowWriteSink (write_arrow_stream.cpp:141-159): appends one DataChunk (host vectors, DuckDB layout); flushes
  * a record batch through the encode kernels when row_group_size / row_group_size_bytes is reached. */
 int mi_writer_sink(mi_writer* w, const mi_data_chunk* chunk);
+/* Per-thread sink state: ArrowWriteInitializeLocal / ArrowWriteSink / ArrowWriteCombine (write_arrow_stream.cpp:141-174).
+ * The reference's sink is called by every DuckDB thread with its own LocalFunctionData; here every local state also
+ * serializes its own row groups (own pinned staging, own HIP stream), so appending, encoding and writing of different
+ * row groups overlap.  Row groups reach the file in the order the threads finish them (DuckDB's sink without
+ * preserve_insertion_order); mi_writer_sink (one thread) and mi_writer_sink_scan keep the input order.
+ * _sink appends and flushes a record batch when row_group_size / row_group_size_bytes is reached, _combine flushes the
+ * tail; call mi_writer_finalize once every local state is combined. */
+typedef struct mi_writer_local mi_writer_local;
+int mi_writer_local_create(mi_writer* w, mi_writer_local** out);
+int mi_writer_local_sink(mi_writer_local* l, const mi_data_chunk* chunk);
+int mi_writer_local_combine(mi_writer_local* l);
+void mi_writer_local_destroy(mi_writer_local* l);
+/* COPY (FROM read_arrow(...)) TO 'file' (FORMAT ARROWS): pulls every remaining record batch of `scan` (host consumer
+ * mode) into the sink, natively -- the pump DuckDB's executor is between a scan and a copy sink.  Row groups are cut
+ * where the one-thread sink would cut them and are staged / encoded / written by several sink threads
+ * (MI_WRITER_THREADS, default cores / 3, at most 6); they reach the file in input order.  *rows = copied. */
+int mi_writer_sink_scan(mi_writer* w, mi_scan* scan, int64_t* rows);
 /* ArrowWriteCombine + ArrowWriteFinalize (write_arrow_stream.cpp:161-174): flush the tail, write EOS
  * {FF FF FF FF 00 00 00 00} (arrow_stream_writer.cpp:78-82), close. */
-/* COPY (FROM read_arrow(...)) TO 'file' (FORMAT ARROWS): pulls every remaining chunk of `scan` (host consumer mode)
- * straight into the sink, natively -- the pump DuckDB's executor is between a scan and a copy sink.  *rows = copied. */
-int mi_writer_sink_scan(mi_writer* w, mi_scan* scan, int64_t* rows);
 int mi_writer_finalize(mi_writer* w);
 void mi_writer_close(mi_writer* w);
 int64_t mi_writer_row_groups(const mi_writer* w);  /* ArrowStreamWriter::NumberOfRowGroups */

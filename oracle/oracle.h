@@ -175,6 +175,22 @@ int64_t orc_filter_range_i32(const int32_t* v, const uint64_t* valid, int64_t n,
                              uint32_t* sel);
 int64_t orc_filter_range_i64(const int64_t* v, const uint64_t* valid, int64_t n, int64_t lo, int64_t hi,
                              uint32_t* sel);
+/* General pushed-down predicates: leaves of a conjunctive normal form over decoded vectors. */
+typedef struct orc_filter_leaf {
+  const void* data;          /* decoded fixed-width vector, NULL for IS [NOT] NULL */
+  const uint64_t* validity;  /* validity words or NULL = all valid */
+  const int64_t* values;     /* IN-list */
+  int64_t value;             /* comparison constant */
+  int32_t op;                /* 1 = 2 <> 3 < 4 <= 5 > 6 >= 7 IS NULL 8 IS NOT NULL 9 IN */
+  int32_t width;             /* bytes per value: 1, 2, 4, 8 */
+  int32_t is_unsigned;
+  int32_t n_values;
+  int32_t ends_clause;       /* last leaf of its OR group */
+  int32_t _pad;
+} orc_filter_leaf;
+/* window-relative indices of the rows [0, n) that pass; returns their number */
+int64_t orc_filter_cnf(const orc_filter_leaf* leaves, int32_t n_leaves, int64_t n, uint32_t* sel);
+
 
 /* ---- encode kernels: DuckDB flat vectors -> Arrow buffers (ArrowAppender semantics) -----------------
  * `valid` may be NULL (all valid).  Row i of the input maps to row row0+i of the output buffers. */
@@ -253,6 +269,23 @@ typedef struct {
 int orc_plan_column(const orc_field* f, int32_t* kind, int64_t* param, int32_t* n_buffers);
 int orc_scan_stream(const uint8_t* buf, int64_t size, int32_t max_batches, int32_t want_checksum,
                     orc_scan_stats* st);
+
+/* The COPY TO direction as the timed CPU baseline of the K7 kernels (BASELINE config 4): every record batch of a flat
+ * stream is decoded into whole-batch DuckDB vectors first (untimed: that is the table the COPY reads), then encoded the
+ * way the reference's sink does it -- ColumnDataCollectionSerializer::Serialize concatenates the chunks into one DataChunk
+ * (src/writer/column_data_collection_serializer.cpp:97-115), ArrowAppender converts column by column (:80-95) and the
+ * record-batch encoder copies every buffer into the message body padded to 8 bytes (:73-76, 89-92).  seconds = the
+ * encode part alone; checksum folds the produced bodies (== the input bodies' buffers for a DuckDB-written stream). */
+typedef struct {
+  int64_t rows;
+  int64_t batches;
+  int64_t bytes_in;   /* DuckDB vector bytes + string payload consumed */
+  int64_t bytes_out;  /* Arrow body bytes produced */
+  uint64_t checksum;
+  double seconds;
+  int64_t mismatches; /* produced buffers that differ from the source stream's (verify != 0) */
+} orc_encode_stats;
+int orc_encode_stream(const uint8_t* buf, int64_t size, int32_t max_batches, int32_t verify, orc_encode_stats* st);
 
 #ifdef __cplusplus
 }

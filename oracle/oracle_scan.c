@@ -12,10 +12,12 @@
  *                                                     ArrowFileScan::Scan src/file_scanner/arrow_file_scan.cpp:68-72
  * Single threaded like the reference's single-file scan (src/file_scanner/arrow_multi_file_info.cpp:77-86).
  */
+#define _POSIX_C_SOURCE 199309L
 #include "oracle.h"
 
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #define MAX_FIELDS 512
 #define MAX_BUFS 2048
@@ -226,5 +228,163 @@ int orc_scan_stream(const uint8_t* buf, int64_t size, int32_t max_batches, int32
     if (rc) break;
   }
   for (int32_t c = 0; c < nf; c++) free(chunk_data[c]);
+  return rc;
+}
+
+
+/* ------------------------------------------------------------------------------------------------ COPY TO baseline */
+static double now_seconds(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int orc_encode_stream(const uint8_t* buf, int64_t size, int32_t max_batches, int32_t verify, orc_encode_stats* st) {
+  memset(st, 0, sizeof(*st));
+  static orc_msg msgs[1 << 16];
+  int32_t nmsg = 0;
+  char err[128];
+  int rc = orc_walk_stream(buf, size, msgs, 1 << 16, &nmsg, err, sizeof(err));
+  if (rc) return rc;
+  if (nmsg == 0 || msgs[0].type != ORC_MSG_SCHEMA) return ORC_EIO;
+  static orc_field fields[MAX_FIELDS];
+  int32_t nf = 0, ntop = 0, endian = 0;
+  rc = orc_decode_schema(buf + msgs[0].meta_off, msgs[0].meta_len, fields, MAX_FIELDS, &nf, &ntop, &endian);
+  if (rc) return rc;
+  if (nf != ntop) return ORC_ENOTSUP;
+  int32_t kind[MAX_FIELDS], nbuf[MAX_FIELDS];
+  int64_t param[MAX_FIELDS];
+  for (int32_t c = 0; c < nf; c++) {
+    rc = orc_plan_column(&fields[c], &kind[c], &param[c], &nbuf[c]);
+    if (rc) return rc;
+    if (kind[c] != ORC_K_COPY && kind[c] != ORC_K_DEC128 && kind[c] != ORC_K_STR32 && kind[c] != ORC_K_BOOL) return ORC_ENOTSUP;
+  }
+  static orc_node nodes[MAX_FIELDS];
+  static orc_buf bufs[MAX_BUFS];
+  int32_t done = 0;
+  for (int32_t m = 1; m < nmsg && done < max_batches && rc == ORC_OK; m++) {
+    if (msgs[m].type != ORC_MSG_RECORD_BATCH) return ORC_EIO;
+    int64_t length, dict_id;
+    int32_t nn, nb, comp, delta;
+    rc = orc_decode_record_batch(buf + msgs[m].meta_off, msgs[m].meta_len, &length, nodes, MAX_FIELDS, &nn, bufs, MAX_BUFS, &nb,
+                                 &comp, &dict_id, &delta);
+    if (rc) break;
+    if (comp != -1) return ORC_ENOTSUP;
+    const uint8_t* body = buf + msgs[m].body_off;
+    const int64_t n = length, nwords = (n + 63) / 64;
+    /* ---- untimed: the DuckDB table the COPY reads, as 2048-row chunks per column (decode of this very batch) ---- */
+    uint8_t* vec[MAX_FIELDS];
+    uint64_t* val[MAX_FIELDS];
+    int32_t width[MAX_FIELDS], first_buf[MAX_FIELDS];
+    int32_t bi = 0;
+    for (int32_t c = 0; c < nf; c++) {
+      first_buf[c] = bi;
+      orc_col_task t;
+      memset(&t, 0, sizeof(t));
+      t.kind = kind[c];
+      t.param = param[c];
+      t.validity = bufs[bi].length ? body + bufs[bi].offset : NULL;
+      t.buf1 = body + bufs[bi + 1].offset;
+      t.buf2 = nbuf[c] > 2 ? body + bufs[bi + 2].offset : NULL;
+      t.buf2_len = nbuf[c] > 2 ? bufs[bi + 2].length : 0;
+      t.null_count = nodes[c].null_count;
+      t.nrows = n;
+      t.ptr_base = (uint64_t)(uintptr_t)t.buf2;
+      width[c] = orc_out_width(kind[c], param[c]);
+      vec[c] = (uint8_t*)malloc((size_t)(n ? n : 1) * (size_t)width[c] + 16);
+      val[c] = (uint64_t*)malloc((size_t)(nwords + 1) * 8);
+      t.out_data = vec[c];
+      t.out_validity = val[c];
+      rc = orc_decode_column(&t, /*copy_direct*/ 1);
+      if (rc) break;
+      bi += nbuf[c];
+    }
+    if (rc) {
+      for (int32_t c = 0; c < nf; c++) { free(vec[c]); free(val[c]); }
+      break;
+    }
+    /* ---- timed: Serialize(ColumnDataCollection) ---- */
+    const double t0 = now_seconds();
+    int64_t body_cap = 0;
+    for (int32_t c = 0; c < nf; c++)
+      for (int32_t k = 0; k < nbuf[c]; k++) body_cap += ((bufs[first_buf[c] + k].length > (n + 7) / 8 ? bufs[first_buf[c] + k].length : (n + 7) / 8) + 7 + 8) & ~(int64_t)7;
+    uint8_t* out_body = (uint8_t*)malloc((size_t)body_cap + 64);
+    int64_t out_pos = 0;
+    for (int32_t c = 0; c < nf; c++) {
+      /* a10: the collection's chunks are concatenated into one DataChunk first */
+      uint8_t* flat = (uint8_t*)malloc((size_t)(n ? n : 1) * (size_t)width[c] + 16);
+      for (int64_t o = 0; o < n; o += ORC_VECTOR_SIZE) {
+        const int64_t k = n - o < ORC_VECTOR_SIZE ? n - o : ORC_VECTOR_SIZE;
+        memcpy(flat + o * width[c], vec[c] + o * width[c], (size_t)k * (size_t)width[c]);
+      }
+      st->bytes_in += n * width[c] + nwords * 8;
+      /* a11: ArrowAppender -- validity (always emitted, starts as 0xFF), then the data buffers */
+      const int64_t vbytes = (n + 7) / 8;
+      uint8_t* bitmap = (uint8_t*)malloc((size_t)vbytes + 8);
+      memset(bitmap, 0xFF, (size_t)vbytes + 8);
+      int64_t nulls = 0;
+      orc_enc_validity(nodes[c].null_count ? val[c] : NULL, n, 0, bitmap, &nulls);
+      uint8_t* b1 = NULL;
+      uint8_t* b2 = NULL;
+      int64_t l1 = 0, l2 = 0;
+      switch (kind[c]) {
+        case ORC_K_COPY:
+          l1 = n * width[c];
+          b1 = (uint8_t*)malloc((size_t)l1 + 8);
+          memcpy(b1, flat, (size_t)l1);
+          break;
+        case ORC_K_DEC128:
+          l1 = n * 16;
+          b1 = (uint8_t*)malloc((size_t)l1 + 8);
+          orc_enc_decimal_widen(flat, width[c], n, b1);
+          break;
+        case ORC_K_BOOL:
+          l1 = vbytes;
+          b1 = (uint8_t*)malloc((size_t)l1 + 8);
+          memset(b1, 0xFF, (size_t)l1);
+          orc_enc_bool(flat, nodes[c].null_count ? val[c] : NULL, n, 0, b1);
+          break;
+        default: { /* ORC_K_STR32 */
+          const uint8_t* heap = body + bufs[first_buf[c] + 2].offset;
+          l1 = (n + 1) * 4;
+          l2 = bufs[first_buf[c] + 2].length;
+          b1 = (uint8_t*)malloc((size_t)l1 + 8);
+          b2 = (uint8_t*)malloc((size_t)l2 + 8);
+          ((int32_t*)b1)[0] = 0;
+          rc |= orc_enc_varchar32(flat, nodes[c].null_count ? val[c] : NULL, n, 0, (uint64_t)(uintptr_t)heap, heap, (int32_t*)b1, b2);
+          st->bytes_in += l2;
+          break;
+        }
+      }
+      /* a12: every buffer is copied into the message body, padded to 8 bytes */
+      const uint8_t* parts[3] = {bitmap, b1, b2};
+      const int64_t lens[3] = {vbytes, l1, l2};
+      for (int32_t k = 0; k < nbuf[c]; k++) {
+        memcpy(out_body + out_pos, parts[k], (size_t)lens[k]);
+        const int64_t padded = (lens[k] + 7) & ~(int64_t)7;
+        memset(out_body + out_pos + lens[k], 0, (size_t)(padded - lens[k]));
+        if (verify) {
+          /* the source stream was written by the same rules: same bytes (bitmap pad bits are 1 here, the source's may be 0) */
+          const orc_buf* sb = &bufs[first_buf[c] + k];
+          int64_t cmp = lens[k] < sb->length ? lens[k] : sb->length;
+          if (k == 0) cmp = n / 8; /* whole bytes of the bitmap */
+          if ((k > 0 && lens[k] != sb->length) || memcmp(out_body + out_pos, body + sb->offset, (size_t)cmp) != 0) st->mismatches++;
+        }
+        out_pos += padded;
+      }
+      free(bitmap);
+      free(b1);
+      free(b2);
+      free(flat);
+    }
+    st->seconds += now_seconds() - t0;
+    st->bytes_out += out_pos;
+    st->checksum ^= fold(out_body, out_pos) * (uint64_t)(2 * done + 1);
+    free(out_body);
+    for (int32_t c = 0; c < nf; c++) { free(vec[c]); free(val[c]); }
+    st->rows += n;
+    st->batches++;
+    done++;
+  }
   return rc;
 }

@@ -311,6 +311,75 @@ int64_t orc_filter_range_i64(const int64_t* v, const uint64_t* valid, int64_t n,
   return c;
 }
 
+/* Predicate trees in conjunctive normal form over decoded fixed-width vectors: the rows DuckDB's own filter above the scan
+ * would keep (the reference sets filter_pushdown = false, src/scanner/read_arrow.cpp:47-48; SQL semantics: a comparison
+ * with NULL is not true).  Leaves are evaluated with the SQL operator itself (no range normalisation as in the product),
+ * one row at a time.  op: 1 = 2 <> 3 < 4 <= 5 > 6 >= 7 IS NULL 8 IS NOT NULL 9 IN; ends_clause marks the last leaf of an
+ * OR group; the filter is the AND of the groups. */
+static int64_t leaf_value(const orc_filter_leaf* l, int64_t i) {
+  switch (l->width) {
+    case 1: return l->is_unsigned ? (int64_t)((const uint8_t*)l->data)[i] : (int64_t)((const int8_t*)l->data)[i];
+    case 2: return l->is_unsigned ? (int64_t)((const uint16_t*)l->data)[i] : (int64_t)((const int16_t*)l->data)[i];
+    case 4: return l->is_unsigned ? (int64_t)((const uint32_t*)l->data)[i] : (int64_t)((const int32_t*)l->data)[i];
+    default: return ((const int64_t*)l->data)[i];
+  }
+}
+
+static int leaf_true(const orc_filter_leaf* l, int64_t i) {
+  const int valid = word_valid(l->validity, i);
+  if (l->op == 7) return !valid;
+  if (l->op == 8) return valid;
+  if (!valid) return 0;
+  const int64_t v = leaf_value(l, i), c = l->value;
+  if (l->is_unsigned && l->width == 8) { /* uint64 column: unsigned order, negative constants lie below every value */
+    const uint64_t uv = (uint64_t)v;
+    if (l->op == 9) {
+      for (int32_t k = 0; k < l->n_values; k++)
+        if (l->values[k] >= 0 && (uint64_t)l->values[k] == uv) return 1;
+      return 0;
+    }
+    if (c < 0) return l->op == 2 || l->op == 5 || l->op == 6;
+    const uint64_t uc = (uint64_t)c;
+    switch (l->op) {
+      case 1: return uv == uc;
+      case 2: return uv != uc;
+      case 3: return uv < uc;
+      case 4: return uv <= uc;
+      case 5: return uv > uc;
+      default: return uv >= uc;
+    }
+  }
+  switch (l->op) {
+    case 1: return v == c;
+    case 2: return v != c;
+    case 3: return v < c;
+    case 4: return v <= c;
+    case 5: return v > c;
+    case 6: return v >= c;
+    case 9:
+      for (int32_t k = 0; k < l->n_values; k++)
+        if (l->values[k] == v) return 1;
+      return 0;
+    default: return 0;
+  }
+}
+
+int64_t orc_filter_cnf(const orc_filter_leaf* leaves, int32_t n_leaves, int64_t n, uint32_t* sel) {
+  int64_t c = 0;
+  for (int64_t i = 0; i < n; i++) {
+    int keep = 1, group = 0;
+    for (int32_t k = 0; k < n_leaves; k++) {
+      group |= leaf_true(&leaves[k], i);
+      if (leaves[k].ends_clause) {
+        keep &= group;
+        group = 0;
+      }
+    }
+    if (keep) sel[c++] = (uint32_t)i;
+  }
+  return c;
+}
+
 /* ------------------------------------------------------------------------------------------------ K7 */
 /* ArrowAppendData::AppendValidity: the buffer was resized with 0xFF; clear the bit of every NULL. */
 void orc_enc_validity(const uint64_t* valid, int64_t n, int64_t row0, uint8_t* bitmap, int64_t* null_count) {

@@ -60,6 +60,11 @@ class ScanStats(C.Structure):
                 ("checksum", C.c_uint64)]
 
 
+class EncodeStats(C.Structure):
+    _fields_ = [("rows", C.c_int64), ("batches", C.c_int64), ("bytes_in", C.c_int64), ("bytes_out", C.c_int64),
+                ("checksum", C.c_uint64), ("seconds", C.c_double), ("mismatches", C.c_int64)]
+
+
 _lib = None
 
 
@@ -76,6 +81,8 @@ def lib():
         _lib.orc_filter_range_i32.argtypes = [P, P, I64, I32, I32, P]
         _lib.orc_filter_range_i64.restype = C.c_int64
         _lib.orc_filter_range_i64.argtypes = [P, P, I64, I64, I64, P]
+        _lib.orc_filter_cnf.restype = C.c_int64
+        _lib.orc_filter_cnf.argtypes = [P, I32, I64, P]
         _lib.orc_validity.restype = None
         _lib.orc_validity.argtypes = [P, I64, I64, I64, P]
         _lib.orc_validate_offsets32.argtypes = [P, I64, I64]
@@ -390,6 +397,18 @@ def scan_stream(buf, max_batches=1 << 30, want_checksum=False):
                     checksum=st.checksum)
 
 
+def encode_stream(buf, max_batches=1 << 30, verify=False):
+    """The timed CPU baseline of the COPY TO direction (oracle_scan.c orc_encode_stream): K7 + the reference's two extra
+    copies per record batch, single threaded; `seconds` covers the encode alone."""
+    a = _u8(buf)
+    st = EncodeStats()
+    lib().orc_encode_stream.restype = C.c_int
+    rc = lib().orc_encode_stream(_ptr(a), C.c_int64(a.size), C.c_int32(min(max_batches, (1 << 31) - 1)), C.c_int32(1 if verify else 0),
+                                 C.byref(st))
+    return rc, dict(rows=st.rows, batches=st.batches, bytes_in=st.bytes_in, bytes_out=st.bytes_out, checksum=st.checksum,
+                    seconds=st.seconds, mismatches=st.mismatches)
+
+
 # ------------------------------------------------------------------------------------------ logical views
 def valid_bits(validity_words, n):
     bits = np.unpackbits(validity_words.view(np.uint8), bitorder="little")[:n]
@@ -423,3 +442,37 @@ def fixed_to_pylist(data, validity_words, n, dtype):
     vals = data.view(dtype)[:n]
     ok = valid_bits(validity_words, n)
     return [vals[i].item() if ok[i] else None for i in range(n)]
+
+
+class FilterLeaf(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("validity", C.c_void_p), ("values", C.c_void_p), ("value", C.c_int64),
+                ("op", C.c_int32), ("width", C.c_int32), ("is_unsigned", C.c_int32), ("n_values", C.c_int32),
+                ("ends_clause", C.c_int32), ("_pad", C.c_int32)]
+
+
+_FILTER_OPS = {"=": 1, "<>": 2, "!=": 2, "<": 3, "<=": 4, ">": 5, ">=": 6, "is null": 7, "is not null": 8, "in": 9}
+
+
+def filter_cnf(clauses, columns, n):
+    """The rows [0, n) that pass AND-of-ORs `clauses` = [[(column, op, value), ...], ...] over `columns` =
+    {name: (data ndarray of the stored integers, validity uint64 words or None)} -> ascending row indices (orc_filter_cnf)."""
+    leaves, keep = [], []
+    for clause in clauses:
+        for j, leaf in enumerate(clause):
+            data, valid = columns[leaf[0]]
+            data = np.ascontiguousarray(data)
+            keep.append(data)
+            L = FilterLeaf(data=data.ctypes.data, validity=valid.ctypes.data if valid is not None else None,
+                           op=_FILTER_OPS[leaf[1].lower()], width=data.dtype.itemsize, is_unsigned=int(data.dtype.kind == "u"),
+                           ends_clause=int(j == len(clause) - 1))
+            if leaf[1].lower() == "in":
+                vals = np.array(list(leaf[2]), np.int64)
+                keep.append(vals)
+                L.values, L.n_values = vals.ctypes.data, len(vals)
+            elif len(leaf) > 2:
+                L.value = int(leaf[2])
+            leaves.append(L)
+    arr = (FilterLeaf * max(len(leaves), 1))(*leaves)
+    sel = np.zeros(max(n, 1), np.uint32)
+    c = lib().orc_filter_cnf(arr, len(leaves), n, sel.ctypes.data)
+    return sel[:c].copy()

@@ -61,7 +61,7 @@ int main(void) {
 
 def test_versions():
     assert da.nanoarrow_version() == "0.7.0-SNAPSHOT"  # test/sql/nanoarrow.test:15-18
-    assert da.version().startswith("mi_arrow_ipc 1 gfx950")
+    assert da.version().startswith("mi_arrow_ipc 2 gfx950")
 
 
 def test_no_cpu_fallback_without_device():

@@ -237,7 +237,7 @@ def test_filter_range_matches_oracle(ctx, torch, golden_dir, expected):
     hs.launch()
     assert hs.status() == 0
     revenue = passing = 0
-    obase = hs.d_out.data_ptr()
+    obase = hs.out_ptr
     for b, lay in zip(hs.fetch(), hs.layout):
         n = b["nrows"]
         cols = {c["name"]: c for c in b["columns"]}
@@ -309,30 +309,27 @@ def test_sf1_lineitem_properties_and_sampled_parity(ctx, torch):
         assert_streams_equal([got[bi]], want)
 
 
-def test_zero_copy_plan_leaves_direct_columns_in_the_body(ctx):
-    """HbmStream.zero_copy_plan(): int64 / date32 columns without NULLs get no task -- their vector is the Arrow buffer in
-    HBM (alias_addr) -- and every other column is transcoded exactly as in the full plan."""
-    import torch
+def test_zero_copy_layout_leaves_direct_columns_in_the_body(ctx):
+    """mi_hbm_options.zero_copy_direct: int64 / date32 columns without NULLs get no task -- their vector is the Arrow
+    buffer in HBM (alias_off) -- and every other column is transcoded exactly as in the full plan.  With unset_all_valid
+    on top, columns without NULLs carry no validity words at all (the reference leaves the mask unset)."""
     from duckdb_arrow_amd.hbm import HbmStream
     buf, info = da.synth_lineitem_stream(scale_factor=0.02, seed=5)
-    hs = HbmStream(ctx, buf)
+    full = HbmStream(ctx, buf)
     _, want = po.decode_stream(buf)
-    zp = hs.zero_copy_plan()
-    assert zp.n_tasks == hs.plan.n_tasks * 9 // 16        # 7 of lineitem's 16 columns are plain fixed width
-    hs.d_out.zero_()
-    zp.launch(torch.cuda.current_stream().cuda_stream)
-    assert zp.status() == 0
-    got = hs.fetch()
-    base = hs.d_in.data_ptr()
-    d_in = hs.d_in.cpu().numpy()
-    for gb, wb, lay in zip(got, want, hs.layout):
-        for gc, wc, e in zip(gb["columns"], wb["columns"], lay["columns"]):
-            if e["alias_addr"]:
-                assert not gc["data"].any()   # untouched arena
-                a = e["alias_addr"] - base
-                assert np.array_equal(d_in[a: a + wc["data"].size], wc["data"]), gc["name"]
-            else:
-                assert_nodes_equal(gc, wc, gc["name"])
+    for unset in (False, True):
+        hs = HbmStream(ctx, buf, zero_copy_direct=True, unset_all_valid=unset, share_stream_of=full)
+        assert hs.n_tasks == full.n_tasks * 9 // 16        # 7 of lineitem's 16 columns are plain fixed width
+        assert hs.stats()["bytes_written"] < full.stats()["bytes_written"]
+        hs.launch()
+        assert hs.status() == 0
+        got = hs.fetch()
+        for gb, wb in zip(got, want):
+            for gc, wc in zip(gb["columns"], wb["columns"]):
+                assert gc["aliased"] == (gc["kind"] == _ffi.K_COPY), gc["name"]
+                assert gc["validity_unset"] == (unset or gc["aliased"]), gc["name"]
+                assert_nodes_equal(gc, wc, gc["name"])    # aliased data = the stream bytes, unset validity = all ones
+        hs.close()
 
 
 @pytest.mark.parametrize("width,dtype", [(2, np.int16), (4, np.int32), (8, np.int64)])

@@ -18,7 +18,7 @@ def sf10():
     from duckdb_arrow_amd.hbm import HbmStream
     buf, info = da.synth_lineitem_stream(scale_factor=10.0, seed=42)
     ctx = da.Context(0)
-    hs = HbmStream(ctx, buf)
+    hs = HbmStream(ctx, buf, memory="torch")   # torch owns the buffers: the checks below run on the device through torch
     hs.launch()
     assert hs.status() == 0
     torch.cuda.synchronize()

@@ -42,7 +42,7 @@ def test_encode_is_the_inverse_of_decode_on_lineitem(con, torch):
     hs.launch()
     assert hs.status() == 0
     torch.cuda.synchronize()
-    in_base, out_base = hs.d_in.data_ptr(), hs.d_out.data_ptr()
+    in_base, out_base = hs.in_ptr, hs.out_ptr
     tasks, outs = [], []
     enc_kind = {_ffi.K_COPY: _ffi.K_ENC_COPY, _ffi.K_DEC128: _ffi.K_ENC_DEC128, _ffi.K_STR32: _ffi.K_ENC_STR32}
     for lay in hs.layout:
@@ -501,3 +501,76 @@ def test_sink_string_staging_modes_mix(con, tmp_path):
     L.mi_writer_close(w)
     got = ipc.open_stream(path).read_all().column("s").to_pylist()
     assert got == want
+
+
+# ---------------------------------------------------------------------------------------- several sink threads
+def test_parallel_copy_pump_writes_the_one_thread_file(con, tmp_path, monkeypatch):
+    """mi_writer_sink_scan with several sink threads (MI_WRITER_THREADS): row groups are cut where the one-thread sink cuts
+    them and claim their file ranges in input order, so the file is byte-identical to the one-thread file -- for record
+    batches larger than, equal to and smaller than row_group_size, rows that are no multiple of 2048, NULLs and long strings."""
+    import duckdb_arrow_amd as da
+    rng = np.random.default_rng(21)
+    n = 70000
+    t = pa.table({"k": pa.array(np.arange(n, dtype=np.int64)),
+                  "d": pa.array(rng.integers(0, 1000, n), pa.int64()).cast(pa.decimal128(15, 0)),
+                  "s": pa.array(["str %d %s" % (i, "y" * int(k)) for i, k in enumerate(rng.integers(0, 40, n))], mask=rng.random(n) < 0.1),
+                  "f": pa.array(rng.random(n) < 0.5, mask=rng.random(n) < 0.2)})
+    for chunk, rgs in ((9000, 9000), (25000, 8192), (3000, 10000), (7001, 5000)):
+        src = str(tmp_path / ("src_%d.arrows" % chunk))
+        with ipc.new_stream(src, t.schema) as w:
+            w.write_table(t, max_chunksize=chunk)
+        outs = []
+        for threads in ("1", "4"):
+            monkeypatch.setenv("MI_WRITER_THREADS", threads)
+            out = str(tmp_path / ("out_%d_%s.arrows" % (chunk, threads)))
+            con.copy_to(con.read_arrow(src), out, row_group_size=rgs)
+            outs.append(open(out, "rb").read())
+        assert outs[0] == outs[1], (chunk, rgs)
+        got = ipc.open_stream(pa.BufferReader(outs[1])).read_all()
+        assert got.equals(t), (chunk, rgs)
+        sizes = [b.num_rows for b in ipc.open_stream(pa.BufferReader(outs[1]))]
+        assert sum(sizes) == n and all(x >= rgs for x in sizes[:-1]) and all(x < rgs + 2048 for x in sizes)
+
+
+def test_local_sink_states_from_several_threads(con, tmp_path):
+    """mi_writer_local_*: every thread buffers, encodes and writes its own row groups (ArrowWriteSink with per-thread local
+    state, write_arrow_stream.cpp:141-159); row groups land in completion order, every row exactly once."""
+    import ctypes as C
+    import threading
+    import duckdb_arrow_amd as da
+    from duckdb_arrow_amd import _ffi
+    L = _ffi.lib()
+    names, types = ["t", "i", "s"], ["INTEGER", "BIGINT", "VARCHAR"]
+    path = str(tmp_path / "threads.arrows")
+    o = _ffi.WriteOptions()
+    _ffi.check(L.mi_write_options_init(C.byref(o)))
+    _ffi.check(L.mi_write_options_set(C.byref(o), b"row_group_size", b"5000"))
+    _ffi.check(L.mi_write_options_finalize(C.byref(o)))
+    w = C.c_void_p()
+    _ffi.check(L.mi_writer_open(con.ctx._h, path.encode(), da._c_fields(names, types), 3, C.byref(o), C.byref(w)))
+    errors = []
+
+    def work(tid):
+        try:
+            keep = []
+            tab = da.Table(names, types, [[tid] * 12000, list(range(12000)), ["thread %d row %d long enough to leave the struct" % (tid, i) for i in range(12000)]])
+            loc = C.c_void_p()
+            _ffi.check(L.mi_writer_local_create(w, C.byref(loc)))
+            for ch in da._chunks_from_table(tab, keep):
+                _ffi.check(L.mi_writer_local_sink(loc, C.byref(ch)))
+            _ffi.check(L.mi_writer_local_combine(loc))
+            L.mi_writer_local_destroy(loc)
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [x.start() for x in ts]
+    [x.join() for x in ts]
+    assert not errors, errors
+    _ffi.check(L.mi_writer_finalize(w))
+    assert L.mi_writer_row_groups(w) == 4 * 3
+    L.mi_writer_close(w)
+    got = ipc.open_stream(path).read_all()
+    assert got.num_rows == 48000
+    rows = sorted(zip(got.column("t").to_pylist(), got.column("i").to_pylist(), got.column("s").to_pylist()))
+    assert rows == [(t_, i, "thread %d row %d long enough to leave the struct" % (t_, i)) for t_ in range(4) for i in range(12000)]

@@ -96,7 +96,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t1
     assert hs.status() == 0
-    per_class = np.zeros(6)
+    per_class = np.zeros(7)
     for _ in range(5):
         per_class += np.array(hs.plan.launch_timed(stream))
     per_class /= 5

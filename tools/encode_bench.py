@@ -29,7 +29,7 @@ def main():
     hs.launch()
     assert hs.status() == 0
     torch.cuda.synchronize()
-    in_base, out_base = hs.d_in.data_ptr(), hs.d_out.data_ptr()
+    in_base, out_base = hs.in_ptr, hs.out_ptr
     enc_kind = {_ffi.K_COPY: _ffi.K_ENC_COPY, _ffi.K_DEC128: _ffi.K_ENC_DEC128, _ffi.K_STR32: _ffi.K_ENC_STR32}
     total = 0
     spans = []
