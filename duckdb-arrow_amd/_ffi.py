@@ -19,8 +19,8 @@ K_COPY, K_BOOL, K_DEC128, K_DATE64, K_MUL_I32, K_MUL_I64, K_DIV_I64, K_STR32, K_
     K_STRUCT = range(1, 22)
 K_ENC_COPY, K_ENC_DEC128, K_ENC_BOOL, K_ENC_STR32, K_ENC_VALIDITY, K_ENC_LIST32 = 32, 33, 34, 35, 36, 37
 
-ST_BAD_OFFSETS, ST_STRING_TOO_LARGE, ST_MUL_OVERFLOW, ST_INDEX_RANGE, ST_DECIMAL_RANGE, ST_OFFSET_OVERFLOW, ST_DICT_INDEX = \
-    1, 2, 4, 8, 16, 32, 64
+ST_BAD_OFFSETS, ST_STRING_TOO_LARGE, ST_MUL_OVERFLOW, ST_INDEX_RANGE, ST_DECIMAL_RANGE, ST_OFFSET_OVERFLOW, ST_DICT_INDEX, ST_INTERNAL = \
+    1, 2, 4, 8, 16, 32, 64, 128
 
 
 class Field(C.Structure):

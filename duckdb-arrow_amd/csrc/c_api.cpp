@@ -64,7 +64,7 @@ struct mi_plan {
 // the dominant kernel of every class, as rocprofv3 prints it
 extern "C" const char* KernelNameOfClass(int32_t cls) {
   static const char* names[device::kNumClasses] = {"transcode_copy", "transcode_dec128", "transcode_string", "transcode_misc_light",
-                                                  "encode_fixed", "encode_string_v5", "transcode_gather"};
+                                                  "encode_fixed", "encode_string_1p", "transcode_gather"};
   return (cls >= 0 && cls < device::kNumClasses) ? names[cls] : "";
 }
 

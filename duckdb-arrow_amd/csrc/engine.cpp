@@ -280,8 +280,8 @@ void Plan::Set(const mi_col_task* in_tasks, int32_t n_tasks, hipStream_t upload_
         tiles += nt;
         if (tiles > 0xFFFFFFF0ull) throw InvalidInputException("plan has too many tiles");
         tile_task.insert(tile_task.end(), static_cast<size_t>(nt), local_task);
-        if (c == device::kClassEncString) sl.misc_groups |= t.kind == MI_K_ENC_LIST32 ? 2u : 1u;
         if (c == device::kClassMisc) sl.misc_groups |= 1u << device::MiscGroupOfKind(t.kind);
+        if (c == device::kClassEncString && t.kind == MI_K_ENC_LIST32) sl.misc_groups |= 2u;
         order[i] = {static_cast<int>(slices.size()), static_cast<int32_t>(local_task)};
         local_task++;
         tasks.push_back(t);
@@ -305,7 +305,8 @@ void Plan::Set(const mi_col_task* in_tasks, int32_t n_tasks, hipStream_t upload_
     MI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_status), 64));
     MI_HIP_CHECK(hipMemset(d_status, 0, 64));
   }
-  if (class_tiles[device::kClassEncString]) EnsureDevice(&d_tile_sums, &cap_tile_sums, class_tiles[device::kClassEncString]);
+  if (class_tiles[device::kClassEncString]) EnsureDevice(&d_tile_sums, &cap_tile_sums, 2 * static_cast<size_t>(class_tiles[device::kClassEncString]) + 1);
+  if (class_tiles[device::kClassGather]) EnsureDevice(&d_gather_bases, &cap_gather_bases, tile_task.size());
   if (n_null_counts) {
     const size_t before = cap_null_counts;
     EnsureDevice(&d_null_counts, &cap_null_counts, static_cast<size_t>(n_null_counts));
@@ -348,6 +349,7 @@ Plan::~Plan() {
   if (d_tile_begin) (void)hipFree(d_tile_begin);
   if (d_status) (void)hipFree(d_status);
   if (d_tile_sums) (void)hipFree(d_tile_sums);
+  if (d_gather_bases) (void)hipFree(d_gather_bases);
   if (d_null_counts) (void)hipFree(d_null_counts);
   if (h_tasks) (void)hipHostFree(h_tasks);
   if (h_tile_begin) (void)hipHostFree(h_tile_begin);
@@ -365,12 +367,10 @@ void Plan::LaunchSlice(const ClassSlice& cs, hipStream_t s) {
       MI_HIP_CHECK(device::LaunchEncodeFixed(t, tb, tt, cs.n_tasks, cs.total_tiles, d_null_counts, s));
       break;
     case device::kClassEncString:
-      MI_HIP_CHECK(device::LaunchEncodeStringTileSums(t, tb, tt, cs.n_tasks, cs.total_tiles, d_tile_sums, s));
-      MI_HIP_CHECK(device::LaunchEncodeStringScan(t, tb, cs.n_tasks, d_tile_sums, d_status, s));
-      MI_HIP_CHECK(device::LaunchEncodeString(t, tb, tt, cs.n_tasks, cs.total_tiles, d_tile_sums, d_null_counts, cs.misc_groups, s));
+      MI_HIP_CHECK(device::LaunchEncodeString(t, tb, tt, cs.n_tasks, cs.total_tiles, d_tile_sums, d_null_counts, d_status, (cs.misc_groups & 2u) != 0, s));
       break;
     case device::kClassGather:
-      MI_HIP_CHECK(device::LaunchGather(t, tb, tt, cs.n_tasks, cs.total_tiles, d_status, s));
+      MI_HIP_CHECK(device::LaunchGather(t, tb, tt, cs.n_tasks, cs.total_tiles, d_gather_bases + cs.tile_task_at, d_status, s));
       break;
     default:
       MI_HIP_CHECK(device::LaunchTranscode(cs.cls, t, tb, tt, cs.n_tasks, cs.total_tiles, d_status, cs.misc_groups, s));
@@ -443,6 +443,7 @@ void ThrowForStatus(uint32_t bits) {
   if (bits & MI_ST_INDEX_RANGE) throw ConversionException("DuckDB only supports indices that fit on an uint32");
   if (bits & MI_ST_DICT_INDEX) throw InternalException("Arrow IPC validation failed: dictionary index out of range");
   if (bits & MI_ST_DECIMAL_RANGE) throw ConversionException("Decimal value does not fit the physical type of its declared precision");
+  if (bits & MI_ST_INTERNAL) throw InternalException("a kernel gave up waiting for another workgroup (bounded spin exceeded)");
   if (bits & MI_ST_OFFSET_OVERFLOW)
     throw InvalidInputException(
         "Arrow Appender: The maximum total string size for regular string buffers is 2147483647 but the offset exceeds this.\n"

@@ -64,6 +64,8 @@ struct Plan {
   std::vector<uint32_t> tile_task;
   uint32_t* d_status = nullptr;
   int64_t* d_tile_sums = nullptr;    // encode plans with string columns
+  int64_t* d_gather_bases = nullptr; // gather plans: first output row of every window (indexed like tile_task)
+  size_t cap_gather_bases = 0;
   int64_t* d_null_counts = nullptr;  // encode plans: one counter per task
   int64_t n_null_counts = 0;
   uint32_t total_tiles = 0;

@@ -56,8 +56,9 @@ struct AggSumProductArgs {
 hipError_t LaunchAggSumProduct(const AggSumProductArgs& args, unsigned long long* d_acc, int num_cus, hipStream_t stream);
 
 // Late materialisation: tasks with mi_col_task.sel decode only the selected rows, compacted per window (kernels_gather.hip)
+// d_window_base: total_tiles words of scratch (first output row of every window, filled by the launch)
 hipError_t LaunchGather(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task, int32_t n_tasks,
-                        uint32_t total_tiles, uint32_t* d_status, hipStream_t stream);
+                        uint32_t total_tiles, int64_t* d_window_base, uint32_t* d_status, hipStream_t stream);
 
 // K6: pushed-down predicate -> one ascending selection vector per 2048-row window (kernels_filter.hip).  The predicate is
 // in conjunctive normal form: leaves in clause order, kLeafEndsClause on the last leaf of every clause (a clause is the
@@ -88,16 +89,13 @@ hipError_t LaunchFilterProgram(const FilterProgram& prog, int64_t nrows, mi_sel_
 hipError_t LaunchFilterRange(const void* values, int32_t width, const void* validity, int64_t nrows, int64_t lo,
                              int64_t hi, mi_sel_t* sel_out, uint32_t* count_out, hipStream_t stream);
 
-// K7d helpers (string encode needs a scan across the batch): per-tile payload byte sums, then per-task exclusive scan
-hipError_t LaunchEncodeStringTileSums(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
-                                      int32_t n_tasks, uint32_t total_tiles, int64_t* d_tile_sums, hipStream_t stream);
-hipError_t LaunchEncodeStringScan(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, int32_t n_tasks,
-                                  int64_t* d_tile_sums, uint32_t* d_status, hipStream_t stream);
+// K7 launches.  The string / list kernel is a single pass (decoupled look-back across the tiles of a column); it needs
+// 2 * total_tiles + 1 state words (zeroed by the launch).
 hipError_t LaunchEncodeFixed(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
                              int32_t n_tasks, uint32_t total_tiles, int64_t* d_null_counts, hipStream_t stream);
 hipError_t LaunchEncodeString(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
-                              int32_t n_tasks, uint32_t total_tiles, int64_t* d_tile_sums, int64_t* d_null_counts, uint32_t groups,
-                              hipStream_t stream);
+                              int32_t n_tasks, uint32_t total_tiles, int64_t* d_tile_state, int64_t* d_null_counts,
+                              uint32_t* d_status, bool has_lists, hipStream_t stream);
 
 }  // namespace device
 }  // namespace miarrow

@@ -121,59 +121,11 @@ __device__ __forceinline__ int64_t block_exclusive_scan(int64_t v, int64_t* tota
   return base + incl - v;
 }
 
-// K7d pass 1: payload bytes per tile (valid rows only) -> tile_sums[tile]
-__global__ __launch_bounds__(kBlockThreads) void encode_string_tile_sums(const mi_col_task* __restrict__ tasks,
-                                                                         const uint32_t* __restrict__ tile_begin, const uint32_t* __restrict__ tile_task,
-                                                                         int n_tasks, uint32_t total_tiles,
-                                                                         int64_t* __restrict__ tile_sums) {
-  __shared__ int64_t lds4[kBlockThreads / 64];
-  for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
-    MI_TILE_PROLOGUE();
-    // string_t.length (dword 0) or, for MI_K_ENC_LIST32, list_entry_t.length (low dword of the second u64) every 16 B
-    gptr<const uint32_t> lens = GC<uint32_t>(t.buf1) + 4 * row0 + (t.kind == MI_K_ENC_LIST32 ? 2 : 0);
-    gptr<const uint64_t> valid = GC<uint64_t>(t.validity);
-    const bool has = t.validity != nullptr;
-    int64_t local = 0;
-    for (int r = threadIdx.x; r < n; r += kBlockThreads)
-      if (enc_row_valid(valid, has, row0 + r)) local += lens[4 * r];
-    int64_t total;
-    block_exclusive_scan(local, &total, lds4);
-    if (threadIdx.x == 0) tile_sums[tile] = total;
-  }
-}
-
-// K7d pass 2: per task, exclusive scan of its tiles' sums (in place) + INT32_MAX overflow check.  One workgroup
-// per task; a 122880-row batch has 60 tiles, so this is a handful of waves.
-__global__ __launch_bounds__(kBlockThreads) void encode_string_scan(const mi_col_task* __restrict__ tasks,
-                                                                    const uint32_t* __restrict__ tile_begin,
-                                                                    int n_tasks, int64_t* __restrict__ tile_sums,
-                                                                    uint32_t* __restrict__ status) {
-  __shared__ int64_t lds4[kBlockThreads / 64];
-  for (int ti = blockIdx.x; ti < n_tasks; ti += gridDim.x) {
-    const uint32_t first = tile_begin[ti], last = tile_begin[ti + 1];
-    int64_t carry = 0;
-    for (uint32_t base = first; base < last; base += kBlockThreads) {
-      const uint32_t i = base + threadIdx.x;
-      const int64_t v = i < last ? tile_sums[i] : 0;
-      int64_t total;
-      const int64_t ex = block_exclusive_scan(v, &total, lds4);
-      if (i < last) tile_sums[i] = carry + ex;
-      carry += total;
-    }
-    if (threadIdx.x == 0 && carry > 0x7FFFFFFFll && !(tasks[ti].flags & 1)) atomicOr(status, MI_ST_OFFSET_OVERFLOW);
-  }
-}
-
-// K7d pass 3: offsets + payload.  The tile is processed as 8 sub-blocks of 256 rows (lane r = row, so the 16-byte
-// string_t loads and the 4-byte offset stores are coalesced); per sub-block a wave scan + 4-wave LDS combine gives every
-// row its output position, the payload bytes of the sub-block are assembled in LDS (inline bytes come from the string_t
-// registers, long strings from the heap behind the pointer) and leave as coalesced 16-byte stores.  A sub-block whose
-// payload exceeds the LDS stage falls back to direct byte stores.
 constexpr int kEncStage = 16 * 1024;  // bytes of payload staged per 256-row sub-block (16 KB x 8 workgroups per CU)
 
-// One tile of K7d pass 3 with 64-bit positions: sub-block by sub-block (256 rows), byte-wise LDS assembly, a sub-block
-// whose payload exceeds the stage falls back to direct byte stores.  Used for list offsets and as the fallback of
-// encode_string_v5 for tiles that hold a string of >= 8 MiB (encode_string_redo).
+// One tile with 64-bit positions: sub-block by sub-block (256 rows), byte-wise LDS assembly, a sub-block whose payload
+// exceeds the stage falls back to direct byte stores.  The slow, exact path of encode_string_1p for tiles that hold a string
+// of >= 8 MiB.
 __device__ __forceinline__ void encode_string_tile_generic(const mi_col_task& t, int64_t row0, int n, int64_t base,
                                                            int64_t* lds4, uint8_t* stage) {
   gptr<const u32x4> str = GC<u32x4>(t.buf1) + row0;
@@ -260,24 +212,6 @@ __device__ __forceinline__ void encode_string_tile_generic(const mi_col_task& t,
   }
 }
 
-// list / map offsets (MI_K_ENC_LIST32 tiles: running sums of list_entry_t lengths, no payload); string tiles belong to
-// encode_string_v5
-__global__ __launch_bounds__(kBlockThreads) void encode_list_offsets(const mi_col_task* __restrict__ tasks,
-                                                                     const uint32_t* __restrict__ tile_begin,
-                                                                     const uint32_t* __restrict__ tile_task, int n_tasks,
-                                                                     uint32_t total_tiles, const int64_t* __restrict__ tile_sums,
-                                                                     int64_t* __restrict__ null_counts) {
-  __shared__ int64_t lds4[kBlockThreads / 64];
-  __shared__ __attribute__((aligned(16))) uint8_t stage[kEncStage + 16];
-  for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
-    MI_TILE_PROLOGUE();
-    if (t.kind != MI_K_ENC_LIST32) continue;  // uniform
-    enc_tile_validity(t, row0, n, null_counts);
-    encode_string_tile_generic(t, row0, n, tile_sums[tile], lds4, stage);
-    __syncthreads();
-  }
-}
-
 // ---- dword-granular LDS assembly ------------------------------------------------------------------------------
 // W[0..N] hold a source byte stream that starts at byte `sh` (0..3) of W[0] (W[N+1] readable, zero); writes its first
 // cnt <= 4N bytes at dst (LDS): <= 3 head bytes up to dst's 4-byte boundary, whole dwords funnel-shifted to the
@@ -313,6 +247,7 @@ __device__ __forceinline__ void lds_put_stream(uint8_t* dst, uint32_t (&W)[N + 2
   if (tc > 1) tp[1] = static_cast<uint8_t>(tailw >> 8);
   if (tc > 2) tp[2] = static_cast<uint8_t>(tailw >> 16);
 }
+
 
 // The first <= 48 bytes of a heap string starting at `src`: 13 aligned dwords cover them at any misalignment.
 __device__ __forceinline__ void heap_load13(gptr<const uint8_t> src, uint32_t cnt, uint32_t (&W)[14]) {
@@ -351,148 +286,248 @@ __device__ __forceinline__ void string_bytes_to_lds(uint8_t* dst, const u32x4& s
   }
 }
 
-// K7d pass 3.  rocprofv3 counters showed the first formulations bound by VALU issue
-// (1.1 G wave-instructions per SF10 table, 165 per 64 one-byte strings), not by HBM, so everything here is about fewer
-// instructions per row and fewer dependent round trips:
-//  * the tile's validity words are fetched once (LDS); the NEXT sub-block's string_t is requested (clamped address,
-//    so unconditionally) before this one is touched;
-//  * a long string's first 48 heap bytes arrive as ONE batch of 13 aligned dword loads (the original walked the string
-//    one dependent dword at a time: 7 HBM round trips for a 27-byte l_comment);
-//  * the scan is a 6-step DPP wave scan + one LDS exchange of the 4 wave totals, in 32-bit arithmetic (a sub-block
-//    holding a string of >= 8 MiB is handed to the 64-bit formulation);
-//  * payload is assembled in LDS with dword stores (source stream funnel-shifted with v_alignbyte_b32 to the string
-//    start, then to the destination's 4-byte phase; <= 3 head and <= 3 tail byte stores, all predicated straight-line
-//    code), in windows of <= 8 KiB so a sub-block of any size is staged; two stage buffers alternate: one barrier per
-//    window; all positions inside a sub-block are 32-bit;
-//  * the stage leaves as coalesced 16-byte nontemporal stores through a 16-byte aligned uniform base pointer.
+// ---------------------------------------------------------------------------------------------------- K7d, single pass
+// string_t rows (or list_entry_t rows: offsets only) -> Arrow offsets + data in ONE pass over HBM: every tile first adds up
+// its own lengths (a pass over the length fields, whose cache lines the main loop then finds in L2), publishes the sum and
+// picks up the sum of the tiles before it in the same column (decoupled look-back, Merrill & Garland), so the string_t rows
+// come from HBM exactly once and a column costs one launch.  The first formulation ran three launches (per-tile sums, a scan
+// over them, the encode) and read every string_t twice: at 21..47 B/row of algorithmic traffic those 16 B/row were why its
+// 4.2 TB/s of real traffic showed as 3.2 TB/s algorithmic.
+//
+// The encode of a tile is the loop the counters shaped (rocprofv3 SQ_INSTS_* in profiles/r01_encode): 256-row sub-blocks,
+// lane = row (coalesced 16-byte string_t loads, coalesced offset stores); the NEXT sub-block's string_t is requested before
+// this one is touched; a long string's first 48 heap bytes arrive as one batch of 13 aligned dword loads; a 6-step DPP wave
+// scan + one LDS exchange of the 4 wave totals places every row; the payload is assembled in LDS with dword stores (two
+// v_alignbyte_b32 funnel shifts, <= 3 head / tail byte stores, predicated straight-line code) in windows of <= 8 KiB on two
+// alternating stage buffers (one barrier per window) and leaves as coalesced 16-byte nontemporal stores.
+//
+// Look-back words: tile_state[tile] bits 62..63 = 0 nothing yet, 1 = sum of this tile, 2 = sum of every tile of the column up
+// to and including this one.  They are read and written with RELAXED agent-scope atomics: the word is the whole message, and
+// an acquire / release pair would make every tile write back and invalidate its XCD's L2 (measured: 12x slower).
+// tile_state[total_tiles] = the ticket counter: tiles are numbered in the order their workgroups START, so a tile's
+// predecessors are always running or done whatever order the grid is dispatched in.
+// tile_state[total_tiles + 1 + tile] = 0, or (1 << 63 | first output byte) of a tile left to encode_string_slow: list offsets
+// (no payload) and tiles holding a string of >= 8 MiB (32-bit positions inside a sub-block could wrap).
 constexpr uint32_t kEncBigLen = 1u << 23;
 constexpr int kEncStage5 = 8 * 1024;       // bytes per stage buffer
 constexpr int kEncStageBuf = kEncStage5 + 64;
-static_assert(2 * kEncStageBuf >= kEncStage + 16, "the 64-bit formulation borrows both stage buffers");
+constexpr uint64_t kStateMask = (1ull << 62) - 1ull;
 
-__global__ __launch_bounds__(kBlockThreads, 6) void encode_string_v5(const mi_col_task* __restrict__ tasks,
-                                                                  const uint32_t* __restrict__ tile_begin,
-                                                                  const uint32_t* __restrict__ tile_task, int n_tasks,
-                                                                  uint32_t total_tiles, int64_t* __restrict__ tile_sums,
-                                                                  int64_t* __restrict__ null_counts) {
+__global__ __launch_bounds__(kBlockThreads, 6) void encode_string_1p(const mi_col_task* __restrict__ tasks,
+                                                                     const uint32_t* __restrict__ tile_begin,
+                                                                     const uint32_t* __restrict__ tile_task, int n_tasks,
+                                                                     uint32_t total_tiles, unsigned long long* __restrict__ tile_state,
+                                                                     int64_t* __restrict__ null_counts, uint32_t* __restrict__ status) {
   constexpr int kWaves = kBlockThreads / 64;
   static_assert(kWaves == 4, "wave totals travel as one 16-byte LDS row");
-  __shared__ int64_t lds4[kWaves];
   __shared__ uint64_t s_valid[kTileRows / 64];
   __shared__ __attribute__((aligned(16))) uint32_t s_tot[2][kWaves];
+  __shared__ unsigned long long s_sum[kWaves];
+  __shared__ uint32_t s_tiny[kWaves];
+  __shared__ int64_t s_prefix;
+  __shared__ uint32_t s_tile;
   __shared__ __attribute__((aligned(16))) uint8_t stage[2 * kEncStageBuf];
+  (void)n_tasks;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
-    MI_TILE_PROLOGUE();
-    if (t.kind == MI_K_ENC_LIST32) continue;  // uniform: list offsets are the other launch's tiles (encode_list_offsets)
-    enc_tile_validity(t, row0, n, null_counts, s_valid);
-    gptr<const u32x4> str = GC<u32x4>(t.buf1) + row0;
-    gptr<const uint8_t> heap = GC<uint8_t>(t.buf2);
-    gptr<int32_t> offp = GM<int32_t>(t.out_data) + row0 + 1;
-    gptr<int64_t> offp64 = GM<int64_t>(t.out_data) + row0 + 1;
-    const bool large = (t.flags & 1) != 0;  // LargeUtf8: int64 offsets (arrow_large_buffer_size)
-    gptr<uint8_t> data = GM<uint8_t>(t.out_aux);
-    const int64_t tile_base = tile_sums[tile];
-    int64_t base = tile_base;
-    if (row0 == 0 && threadIdx.x == 0) {
-      if (large) offp64[-1] = 0;
-      else offp[-1] = 0;
+  if (threadIdx.x == 0) s_tile = static_cast<uint32_t>(atomicAdd(&tile_state[total_tiles], 1ull));
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  if (tile >= total_tiles) return;
+  MI_TILE_PROLOGUE();
+  const bool is_list = t.kind == MI_K_ENC_LIST32;
+  const bool large = (t.flags & 1) != 0;  // LargeUtf8 / LargeList: int64 offsets (arrow_large_buffer_size)
+  enc_tile_validity(t, row0, n, null_counts, s_valid);
+  gptr<const u32x4> str = GC<u32x4>(t.buf1) + row0;
+  // the first sub-block's rows are on their way while the tile adds up its lengths
+  u32x4 nxt = __builtin_nontemporal_load(str + (static_cast<int>(threadIdx.x) < n ? static_cast<int>(threadIdx.x) : n - 1));
+  __syncthreads();  // s_valid
+  // ---- the tile's payload size: the length field of every valid row (dword 0 of a string_t, the low dword of a
+  // list_entry_t's length), 64 bits so that it is exact whatever the strings hold
+  {
+    gptr<const uint32_t> lens = GC<uint32_t>(t.buf1) + 4 * row0 + (is_list ? 2 : 0);
+    unsigned long long local = 0;
+    uint32_t longest = 0;
+#pragma unroll
+    for (int k = 0; k < kTileRows / kBlockThreads; k++) {
+      const int r = static_cast<int>(threadIdx.x) + k * kBlockThreads;
+      if (r < n && ((s_valid[r >> 6] >> (r & 63)) & 1)) {
+        const uint32_t l = lens[4 * r];
+        local += l;
+        longest = longest > l ? longest : l;
+      }
     }
-    const int nsub = (n + kBlockThreads - 1) / kBlockThreads;
-    u32x4 nxt = __builtin_nontemporal_load(str + (static_cast<int>(threadIdx.x) < n ? static_cast<int>(threadIdx.x) : n - 1));
-    __syncthreads();  // s_valid
-    uint32_t buf = 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) local += __shfl_down(local, d, 64);
+    const bool wave_big = __any(longest >= kEncBigLen), wave_tiny = !__any(longest > 4u);
+    if (lane == 0) {
+      s_sum[wave] = local | (wave_big ? (1ull << 63) : 0ull);
+      s_tiny[wave] = wave_tiny ? 1u : 0u;
+    }
+  }
+  __syncthreads();
+  const unsigned long long packed = s_sum[0] | s_sum[1] | s_sum[2] | s_sum[3];
+  const bool slow = is_list || (packed >> 63) != 0;  // uniform
+  // every string of the tile is at most 4 bytes (flags, codes): its payload is the low bytes of string_t dword 1
+  const bool tiny = (s_tiny[0] & s_tiny[1] & s_tiny[2] & s_tiny[3]) != 0;  // uniform
+  const int64_t tile_total = static_cast<int64_t>((s_sum[0] & kStateMask) + (s_sum[1] & kStateMask) + (s_sum[2] & kStateMask) + (s_sum[3] & kStateMask));
+  // ---- decoupled look-back over the tiles of this column (wave 0; one window = the 64 tiles before the current point)
+  const uint32_t first_tile = tile_begin[ti];
+  if (wave == 0) {
+    if (lane == 0) {
+      const unsigned long long mine = (tile == first_tile ? (2ull << 62) : (1ull << 62)) | (static_cast<unsigned long long>(tile_total) & kStateMask);
+      __hip_atomic_store(&tile_state[tile], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    int64_t prefix = 0;
+    int64_t hi = static_cast<int64_t>(tile) - 1;  // nearest predecessor not yet accounted for
+    while (hi >= static_cast<int64_t>(first_tile)) {
+      const int64_t j = hi - lane;
+      unsigned long long st = 2ull << 62;  // lanes past the column's first tile: a finished, empty prefix
+      if (j >= static_cast<int64_t>(first_tile)) {
+        st = __hip_atomic_load(&tile_state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the predecessor started before this tile (ticket order) and publishes after one load + one scan; the bound only
+        // keeps a logic error from hanging the device (~1 s), it is never reached
+        for (int spins = 0; (st >> 62) == 0; spins++) {
+          if (spins > (1 << 22)) {
+            atomicOr(status, MI_ST_INTERNAL);
+            st = 2ull << 62;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+          st = __hip_atomic_load(&tile_state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      // the nearest tile (smallest lane) that already knows its inclusive prefix ends the walk
+      const uint64_t done_mask = __ballot((st >> 62) == 2ull);
+      const int stop = done_mask ? __builtin_ctzll(done_mask) : 64;
+      int64_t v = lane <= stop ? static_cast<int64_t>(st & kStateMask) : 0;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+      prefix += __shfl(v, 0, 64);
+      if (done_mask) break;
+      hi -= 64;
+    }
+    if (lane == 0) {
+      if (tile != first_tile)
+        __hip_atomic_store(&tile_state[tile], (2ull << 62) | (static_cast<unsigned long long>(prefix + tile_total) & kStateMask), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      s_prefix = prefix;
+      // the column's last tile knows the size of its data buffer: int32 offsets must fit (ArrowAppender's check)
+      if (tile + 1 == tile_begin[ti + 1] && !large && prefix + tile_total > 0x7FFFFFFFll) atomicOr(status, MI_ST_OFFSET_OVERFLOW);
+      if (slow) tile_state[total_tiles + 1 + tile] = static_cast<unsigned long long>(prefix) | (1ull << 63);
+    }
+  }
+  if (slow) return;  // uniform: encode_string_slow (launched right behind) takes the tile with 64-bit positions
+  __syncthreads();
+  const int64_t tile_base = s_prefix;
+  gptr<const uint8_t> heap = GC<uint8_t>(t.buf2);
+  gptr<int32_t> offp = GM<int32_t>(t.out_data) + row0 + 1;
+  gptr<int64_t> offp64 = GM<int64_t>(t.out_data) + row0 + 1;
+  gptr<uint8_t> data = GM<uint8_t>(t.out_aux);
+  int64_t base = tile_base;
+  if (row0 == 0 && threadIdx.x == 0) {
+    if (large) offp64[-1] = 0;
+    else offp[-1] = 0;
+  }
+  const int nsub = (n + kBlockThreads - 1) / kBlockThreads;
+  uint32_t buf = 0;
 #pragma clang loop unroll(disable)
-    for (int k = 0; k < nsub; k++) {
-      const int r = threadIdx.x + k * kBlockThreads;
-      const u32x4 s = nxt;
-      {
-        const int rn = r + kBlockThreads;
-        nxt = __builtin_nontemporal_load(str + (rn < n ? rn : n - 1));
-      }
-      const bool ok = r < n && ((s_valid[r >> 6] >> (r & 63)) & 1);
-      const uint32_t len = ok ? s.x : 0u;
-      uint32_t W[14];
-      if (len > 12) {
-        const uint64_t p = static_cast<uint64_t>(s.z) | (static_cast<uint64_t>(s.w) << 32);
-        heap_load13(heap + (p - t.ptr_base), len, W);
-      }
-      // exclusive scan of the sub-block's lengths
-      const uint32_t incl = wave_inclusive_scan_u32(len);
-      const bool wave_big = __any(len >= kEncBigLen);
-      if (lane == 63) s_tot[k & 1][wave] = wave_big ? 0x80000000u : incl;
-      __syncthreads();
-      const u32x4 tot = *reinterpret_cast<const u32x4*>(&s_tot[k & 1][0]);
-      if ((tot.x | tot.y | tot.z | tot.w) & 0x80000000u) {
-        // uniform: a string of >= 8 MiB in this sub-block -- 32-bit sums may wrap.  The tile is handed to the 64-bit
-        // formulation (encode_string_redo, launched right after this kernel) by setting the sign bit of its base; the
-        // rare path stays out of this kernel's register budget (inlined here it cost 28 VGPRs = two occupancy steps)
-        if (threadIdx.x == 0) tile_sums[tile] = tile_base | static_cast<int64_t>(0x8000000000000000ull);
-        break;
-      }
-      const uint32_t before = (wave > 0 ? tot.x : 0u) + (wave > 1 ? tot.y : 0u) + (wave > 2 ? tot.z : 0u);
-      const uint32_t total = tot.x + tot.y + tot.z + tot.w;
-      const uint32_t ex = before + incl - len;
-      if (r < n) {
-        if (large) offp64[r] = base + ex + len;
-        else offp[r] = static_cast<int32_t>(base + ex + len);
-      }
-      for (uint32_t w0 = 0; w0 < total;) {  // uniform: stage windows
-        const uint32_t shiftw = static_cast<uint32_t>((base + w0) & 15);
-        const uint32_t room = static_cast<uint32_t>(kEncStage5) - shiftw;
-        const uint32_t w1 = total - w0 < room ? total : w0 + room;
-        uint8_t* st = stage + buf * kEncStageBuf;
-        const uint32_t lo = ex > w0 ? ex : w0, hi = ex + len < w1 ? ex + len : w1;
-        if (lo < hi) string_bytes_to_lds(st + shiftw + (lo - w0), s, heap, t.ptr_base, lo - ex, hi - lo, W);
-        __syncthreads();
-        // stage bytes [shiftw, end) -> gbase[shiftw, end); gbase is 16-byte aligned
-        const uint32_t end = shiftw + (w1 - w0);
-        gptr<uint8_t> gbase = data + (base + w0) - shiftw;
-        const uint32_t nch = (end + 15) >> 4;
-        for (uint32_t c = threadIdx.x; c < nch; c += kBlockThreads) {
-          const uint32_t clo = c << 4;
-          if (clo >= shiftw && clo + 16 <= end)
-            __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(st + clo), (gptr<u32x4>)(gbase + clo));
-        }
-        if (threadIdx.x < 32) {  // the (at most two) partial 16-byte rows, one byte per lane
-          const uint32_t lastlo = (end - 1) & ~15u;
-          const uint32_t idx = threadIdx.x < 16 ? threadIdx.x : lastlo + (threadIdx.x - 16);
-          const bool first_partial = shiftw != 0 || end < 16;
-          const bool last_partial = (end & 15u) != 0 && lastlo != 0;
-          const bool mine = threadIdx.x < 16 ? first_partial : last_partial;
-          if (mine && idx >= shiftw && idx < end) gbase[idx] = st[idx];
-        }
-        buf ^= 1u;
-        w0 = w1;
-      }
-      base += total;
+  for (int k = 0; k < nsub; k++) {
+    const int r = threadIdx.x + k * kBlockThreads;
+    const u32x4 s = nxt;
+    {
+      const int rn = r + kBlockThreads;
+      nxt = __builtin_nontemporal_load(str + (rn < n ? rn : n - 1));
     }
-    __syncthreads();  // s_valid / stage are rewritten by the next tile
+    const bool ok = r < n && ((s_valid[r >> 6] >> (r & 63)) & 1);
+    const uint32_t len = ok ? s.x : 0u;
+    uint32_t W[14];
+    if (len > 12) {
+      const uint64_t p = static_cast<uint64_t>(s.z) | (static_cast<uint64_t>(s.w) << 32);
+      heap_load13(heap + (p - t.ptr_base), len, W);
+    }
+    // exclusive scan of the sub-block's lengths (every length is < 8 MiB here: 256 of them fit 32 bits)
+    const uint32_t incl = wave_inclusive_scan_u32(len);
+    if (lane == 63) s_tot[k & 1][wave] = incl;
+    __syncthreads();
+    const u32x4 tot = *reinterpret_cast<const u32x4*>(&s_tot[k & 1][0]);
+    const uint32_t before = (wave > 0 ? tot.x : 0u) + (wave > 1 ? tot.y : 0u) + (wave > 2 ? tot.z : 0u);
+    const uint32_t total = tot.x + tot.y + tot.z + tot.w;
+    const uint32_t ex = before + incl - len;
+    if (r < n) {
+      if (large) offp64[r] = base + ex + len;
+      else offp[r] = static_cast<int32_t>(base + ex + len);
+    }
+    for (uint32_t w0 = 0; w0 < total;) {  // uniform: stage windows
+      const uint32_t shiftw = static_cast<uint32_t>((base + w0) & 15);
+      const uint32_t room = static_cast<uint32_t>(kEncStage5) - shiftw;
+      const uint32_t w1 = total - w0 < room ? total : w0 + room;
+      uint8_t* st = stage + buf * kEncStageBuf;
+      const uint32_t lo = ex > w0 ? ex : w0, hi = ex + len < w1 ? ex + len : w1;
+      if (tiny) {  // uniform; <= 1 KiB per sub-block: always one window
+        uint8_t* d = st + shiftw + ex;
+        if (len > 0) d[0] = static_cast<uint8_t>(s.y);
+        if (len > 1) d[1] = static_cast<uint8_t>(s.y >> 8);
+        if (len > 2) d[2] = static_cast<uint8_t>(s.y >> 16);
+        if (len > 3) d[3] = static_cast<uint8_t>(s.y >> 24);
+      } else if (lo < hi) {
+        string_bytes_to_lds(st + shiftw + (lo - w0), s, heap, t.ptr_base, lo - ex, hi - lo, W);
+      }
+      __syncthreads();
+      // stage bytes [shiftw, end) -> gbase[shiftw, end); gbase is 16-byte aligned
+      const uint32_t end = shiftw + (w1 - w0);
+      gptr<uint8_t> gbase = data + (base + w0) - shiftw;
+      const uint32_t nch = (end + 15) >> 4;
+      for (uint32_t c = threadIdx.x; c < nch; c += kBlockThreads) {
+        const uint32_t clo = c << 4;
+        if (clo >= shiftw && clo + 16 <= end)
+          __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(st + clo), (gptr<u32x4>)(gbase + clo));
+      }
+      if (threadIdx.x < 32) {  // the (at most two) partial 16-byte rows, one byte per lane
+        const uint32_t lastlo = (end - 1) & ~15u;
+        const uint32_t idx = threadIdx.x < 16 ? threadIdx.x : lastlo + (threadIdx.x - 16);
+        const bool first_partial = shiftw != 0 || end < 16;
+        const bool last_partial = (end & 15u) != 0 && lastlo != 0;
+        const bool mine = threadIdx.x < 16 ? first_partial : last_partial;
+        if (mine && idx >= shiftw && idx < end) gbase[idx] = st[idx];
+      }
+      buf ^= 1u;
+      w0 = w1;
+    }
+    base += total;
   }
 }
 
-// Tiles encode_string_v5 gave up on (sign bit of tile_sums set): 64-bit positions, sub-block by sub-block.  A small
-// persistent grid sweeps the flags 256 at a time; validity bitmap and NULL count were already written by v5.
-__global__ __launch_bounds__(kBlockThreads) void encode_string_redo(const mi_col_task* __restrict__ tasks,
-                                                                    const uint32_t* __restrict__ tile_begin,
-                                                                    const uint32_t* __restrict__ tile_task, int n_tasks,
-                                                                    uint32_t total_tiles, const int64_t* __restrict__ tile_sums,
-                                                                    int64_t* __restrict__ null_counts) {
+// Tiles encode_string_1p left alone (list offsets; a string of >= 8 MiB): 64-bit positions, sub-block by sub-block.  A small
+// persistent grid sweeps the flags 256 at a time; validity bitmap and NULL count were already written by encode_string_1p.
+__global__ __launch_bounds__(kBlockThreads) void encode_string_slow(const mi_col_task* __restrict__ tasks,
+                                                                   const uint32_t* __restrict__ tile_begin,
+                                                                   const uint32_t* __restrict__ tile_task, int n_tasks,
+                                                                   uint32_t total_tiles, const unsigned long long* __restrict__ tile_state,
+                                                                   int per_tile) {
   __shared__ int64_t lds4[kBlockThreads / 64];
   __shared__ __attribute__((aligned(16))) uint8_t stage[kEncStage + 16];
   __shared__ uint32_t s_todo[kBlockThreads];
   __shared__ uint32_t s_ntodo;
+  (void)n_tasks;
+  const unsigned long long* flags = tile_state + total_tiles + 1;
+  if (per_tile) {  // plans with list columns: many tiles are flagged, one workgroup each
+    const uint32_t tile = blockIdx.x;
+    if (tile >= total_tiles || !(flags[tile] >> 63)) return;  // uniform
+    MI_TILE_PROLOGUE();
+    encode_string_tile_generic(t, row0, n, static_cast<int64_t>(flags[tile] & 0x7FFFFFFFFFFFFFFFull), lds4, stage);
+    return;
+  }
   for (uint32_t first = blockIdx.x * kBlockThreads; first < total_tiles; first += gridDim.x * kBlockThreads) {
     if (threadIdx.x == 0) s_ntodo = 0;
     __syncthreads();
     const uint32_t mine = first + threadIdx.x;
-    if (mine < total_tiles && tile_sums[mine] < 0) s_todo[atomicAdd(&s_ntodo, 1u)] = mine;
+    if (mine < total_tiles && (flags[mine] >> 63)) s_todo[atomicAdd(&s_ntodo, 1u)] = mine;
     __syncthreads();
     const uint32_t ntodo = s_ntodo;
     for (uint32_t j = 0; j < ntodo; j++) {
       const uint32_t tile = s_todo[j];
       MI_TILE_PROLOGUE();
-      encode_string_tile_generic(t, row0, n, tile_sums[tile] & 0x7FFFFFFFFFFFFFFFll, lds4, stage);
+      encode_string_tile_generic(t, row0, n, static_cast<int64_t>(flags[tile] & 0x7FFFFFFFFFFFFFFFull), lds4, stage);
       __syncthreads();
     }
     __syncthreads();
@@ -503,25 +538,6 @@ __global__ __launch_bounds__(kBlockThreads) void encode_string_redo(const mi_col
 
 // Encode launches follow the decode rule: one workgroup per tile (the dispatcher balances them), owner of a tile from
 // the tile -> task table.
-hipError_t LaunchEncodeStringTileSums(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
-                                      int32_t n_tasks, uint32_t total_tiles, int64_t* d_tile_sums, hipStream_t stream) {
-  MI_DROP_STALE_ERROR();
-  if (total_tiles == 0) return hipSuccess;
-  hipLaunchKernelGGL(encode_string_tile_sums, dim3(total_tiles), dim3(kBlockThreads), 0, stream, d_tasks, d_tile_begin, d_tile_task,
-                     n_tasks, total_tiles, d_tile_sums);
-  return hipGetLastError();
-}
-
-hipError_t LaunchEncodeStringScan(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, int32_t n_tasks,
-                                  int64_t* d_tile_sums, uint32_t* d_status, hipStream_t stream) {
-  MI_DROP_STALE_ERROR();
-  if (n_tasks == 0) return hipSuccess;
-  const uint32_t grid = n_tasks < 2048 ? static_cast<uint32_t>(n_tasks) : 2048u;
-  hipLaunchKernelGGL(encode_string_scan, dim3(grid), dim3(kBlockThreads), 0, stream, d_tasks, d_tile_begin, n_tasks,
-                     d_tile_sums, d_status);
-  return hipGetLastError();
-}
-
 hipError_t LaunchEncodeFixed(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
                              int32_t n_tasks, uint32_t total_tiles, int64_t* d_null_counts, hipStream_t stream) {
   MI_DROP_STALE_ERROR();
@@ -531,22 +547,20 @@ hipError_t LaunchEncodeFixed(const mi_col_task* d_tasks, const uint32_t* d_tile_
   return hipGetLastError();
 }
 
+// d_tile_state: 2 * total_tiles + 1 words (look-back states, the ticket counter, the big-tile flags), zeroed here
 hipError_t LaunchEncodeString(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
-                              int32_t n_tasks, uint32_t total_tiles, int64_t* d_tile_sums, int64_t* d_null_counts,
-                              uint32_t groups, hipStream_t stream) {
+                              int32_t n_tasks, uint32_t total_tiles, int64_t* d_tile_state, int64_t* d_null_counts,
+                              uint32_t* d_status, bool has_lists, hipStream_t stream) {
   MI_DROP_STALE_ERROR();
   if (total_tiles == 0) return hipSuccess;
-  const dim3 grid(total_tiles), block(kBlockThreads);
-  if (groups & 1u) {  // strings
-    hipLaunchKernelGGL(encode_string_v5, grid, block, 0, stream, d_tasks, d_tile_begin, d_tile_task, n_tasks, total_tiles, d_tile_sums,
-                       d_null_counts);
-    const uint32_t sweep = (total_tiles + kBlockThreads - 1) / kBlockThreads;
-    hipLaunchKernelGGL(encode_string_redo, dim3(sweep < 512u ? sweep : 512u), block, 0, stream, d_tasks, d_tile_begin, d_tile_task,
-                       n_tasks, total_tiles, d_tile_sums, d_null_counts);
-  }
-  if (groups & 2u)  // list / map offsets
-    hipLaunchKernelGGL(encode_list_offsets, grid, block, 0, stream, d_tasks, d_tile_begin, d_tile_task, n_tasks, total_tiles, d_tile_sums,
-                       d_null_counts);
+  hipError_t e = hipMemsetAsync(d_tile_state, 0, (2 * static_cast<size_t>(total_tiles) + 1) * sizeof(int64_t), stream);
+  if (e != hipSuccess) return e;
+  unsigned long long* state = reinterpret_cast<unsigned long long*>(d_tile_state);
+  hipLaunchKernelGGL(encode_string_1p, dim3(total_tiles), dim3(kBlockThreads), 0, stream, d_tasks, d_tile_begin, d_tile_task, n_tasks,
+                     total_tiles, state, d_null_counts, d_status);
+  const uint32_t sweep = (total_tiles + kBlockThreads - 1) / kBlockThreads;
+  hipLaunchKernelGGL(encode_string_slow, dim3(has_lists ? total_tiles : (sweep < 512u ? sweep : 512u)), dim3(kBlockThreads), 0, stream,
+                     d_tasks, d_tile_begin, d_tile_task, n_tasks, total_tiles, state, has_lists ? 1 : 0);
   return hipGetLastError();
 }
 

@@ -94,30 +94,54 @@ __device__ __forceinline__ void gather_string(const mi_col_task& t, int64_t row0
   raise(status, err);
 }
 
+// First output row of every window = selected rows of the windows before it in the same column: one workgroup per task
+// scans the task's counts (a record batch has a few dozen windows; a 100 M row column handed over at kernel level has 50 k).
+__global__ __launch_bounds__(kBlockThreads) void gather_window_bases(const mi_col_task* __restrict__ tasks,
+                                                                     const uint32_t* __restrict__ tile_begin, int n_tasks,
+                                                                     int64_t* __restrict__ window_base) {
+  __shared__ int64_t s_wave[kBlockThreads / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int ti = blockIdx.x; ti < n_tasks; ti += gridDim.x) {
+    const uint32_t first = tile_begin[ti], last = tile_begin[ti + 1];
+    gptr<const uint32_t> counts = GC<uint32_t>(tasks[ti].sel_count);
+    int64_t carry = 0;
+    for (uint32_t base = first; base < last; base += kBlockThreads) {  // uniform
+      const uint32_t i = base + threadIdx.x;
+      const int64_t v = i < last ? static_cast<int64_t>(counts[i - first]) : 0;
+      int64_t incl = v;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int64_t up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+      }
+      __syncthreads();  // the previous round's readers are done
+      if (lane == 63) s_wave[wave] = incl;
+      __syncthreads();
+      int64_t before = 0, total = 0;
+#pragma unroll
+      for (int w = 0; w < kBlockThreads / 64; w++) {
+        if (w < wave) before += s_wave[w];
+        total += s_wave[w];
+      }
+      if (i < last) window_base[i] = carry + before + incl - v;
+      carry += total;
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlockThreads) void transcode_gather(const mi_col_task* __restrict__ tasks,
                                                                   const uint32_t* __restrict__ tile_begin,
                                                                   const uint32_t* __restrict__ tile_task, int n_tasks,
-                                                                  uint32_t total_tiles, uint32_t* __restrict__ status) {
+                                                                  uint32_t total_tiles, const int64_t* __restrict__ window_base,
+                                                                  uint32_t* __restrict__ status) {
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     MI_TILE_PROLOGUE();
     (void)n;
     const int64_t window = row0 / kTileRows;
     gptr<const uint32_t> sel = GC<uint32_t>(t.sel) + row0;
-    gptr<const uint32_t> counts = GC<uint32_t>(t.sel_count);
-    const int cnt = static_cast<int>(counts[window]);
+    const int cnt = static_cast<int>(GC<uint32_t>(t.sel_count)[window]);
     if (cnt <= 0) continue;  // uniform
-    // first output row of this window = selected rows of the windows before it (a few dozen counts: one pass per lane)
-    __shared__ uint32_t s_part[kBlockThreads / 64];
-    uint32_t part = 0;
-    for (int64_t i = threadIdx.x; i < window; i += kBlockThreads) part += counts[i];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) part += __shfl_down(part, d, 64);
-    __syncthreads();  // the previous tile's readers of s_part are done
-    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = part;
-    __syncthreads();
-    int64_t out0 = 0;
-#pragma unroll
-    for (int i = 0; i < kBlockThreads / 64; i++) out0 += s_part[i];
+    const int64_t out0 = window_base[tile];  // first output row of this window (gather_window_bases)
     switch (t.kind) {
       case MI_K_COPY:
         switch (t.param) {
@@ -238,11 +262,13 @@ bool KindCanGather(int32_t kind) {
 }
 
 hipError_t LaunchGather(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task, int32_t n_tasks,
-                        uint32_t total_tiles, uint32_t* d_status, hipStream_t stream) {
+                        uint32_t total_tiles, int64_t* d_window_base, uint32_t* d_status, hipStream_t stream) {
   MI_DROP_STALE_ERROR();
   if (total_tiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(gather_window_bases, dim3(static_cast<uint32_t>(n_tasks < 4096 ? n_tasks : 4096)), dim3(kBlockThreads), 0, stream, d_tasks,
+                     d_tile_begin, n_tasks, d_window_base);
   hipLaunchKernelGGL(transcode_gather, dim3(total_tiles), dim3(kBlockThreads), 0, stream, d_tasks, d_tile_begin, d_tile_task, n_tasks,
-                     total_tiles, d_status);
+                     total_tiles, d_window_base, d_status);
   return hipGetLastError();
 }
 

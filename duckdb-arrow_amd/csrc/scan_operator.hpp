@@ -282,7 +282,6 @@ class MultiDeviceScan : public ScanBase {
   std::vector<mi_data_chunk> pending;   // one chunk per sub-scan, valid until that sub-scan's next Next()
   std::vector<char> have, done;
   int last_emitted = -1;
-  bool started = false;
 };
 
 }  // namespace miarrow

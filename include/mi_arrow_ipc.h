@@ -304,6 +304,7 @@ typedef struct mi_col_task {
 #define MI_ST_DECIMAL_RANGE 16u   /* decimal128 value does not fit the declared precision's physical type */
 #define MI_ST_OFFSET_OVERFLOW 32u /* encode: int32 offsets exceed INT32_MAX ("SET arrow_large_buffer_size=true") */
 #define MI_ST_DICT_INDEX 64u      /* a valid row's dictionary index is >= the dictionary length (FULL validation) */
+#define MI_ST_INTERNAL 128u       /* a kernel gave up waiting for another workgroup (bounded spin): results are not valid */
 
 /* Uploads the task table to HBM (descriptor table + tile index) and returns a reusable plan.  One plan =
  * any number of (batch, column) tasks = ONE fused kernel launch per mi_plan_launch. */

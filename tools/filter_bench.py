@@ -1,10 +1,13 @@
-"""Kernel-level timing of the K6 range filter on 240 M resident int32 values (wall clock around 20 launches)."""
-import sys, os, time
+"""Kernel-level timing of K6 on resident int32 / int64 values: the one-leaf range (mi_filter_range) and, through the scan
+operator's own entry points, a compacting gather (transcode_gather) behind it.  HIP-event-free: wall clock around 20 launches."""
+import sys, os, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import duckdb_arrow_amd as da
+from duckdb_arrow_amd import _ffi
 ctx = da.Context(0)
 n = 240_000_000
+out = {"rows": n}
 vals = torch.randint(8036, 10562, (n,), dtype=torch.int32, device="cuda")
 sel = torch.empty(n, dtype=torch.int32, device="cuda")
 cnt = torch.zeros((n + 2047) // 2048, dtype=torch.int32, device="cuda")
@@ -18,4 +21,27 @@ for _ in range(20):
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / 20 * 1e3
 k = int(cnt.sum().item())
-print("filter_range int32: %.3f ms, %.1f G rows/s, selected %.4f, alg bytes %.2f GB -> %.0f GB/s" % (ms, n / ms / 1e6, k / n, (4 * n + 4 * k + cnt.numel() * 4) / 1e9, (4 * n + 4 * k + cnt.numel() * 4) / ms / 1e6))
+alg = 4 * n + 4 * k + cnt.numel() * 4
+out["filter_program_range_int32"] = {"ms": ms, "G_rows_per_s": n / ms / 1e6, "selectivity": k / n, "algorithmic_bytes": alg, "GBps": alg / ms / 1e6}
+# late materialisation behind it: an int64 column gathered through the selection vector into a dense array
+src = torch.randint(0, 1 << 40, (n,), dtype=torch.int64, device="cuda")
+dst = torch.empty(k + 64, dtype=torch.int64, device="cuda")
+task = da.make_task(_ffi.K_COPY, n, src.data_ptr(), dst.data_ptr(), param=8, null_count=0, sel=sel.data_ptr(), sel_count=cnt.data_ptr())
+plan = da.Plan(ctx, [task])
+for _ in range(3):
+    plan.launch(s)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20):
+    plan.launch(s)
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / 20 * 1e3
+assert plan.status() == 0
+# spot check against torch
+w0 = int(cnt[0].item())
+want = src[:2048][sel[:w0].long()]
+assert torch.equal(dst[:w0], want)
+alg = 4 * k + 8 * k + 8 * k + cnt.numel() * 4   # sel + the selected values in and out
+out["transcode_gather_int64"] = {"ms": ms, "selected": k, "algorithmic_bytes": alg, "GBps": alg / ms / 1e6,
+                                 "note": "the source column is touched sector-wise: at 14 % selectivity nearly every 64-byte line holds a selected row"}
+print(json.dumps(out))

@@ -1,15 +1,27 @@
 #!/bin/bash
-# The profile recipe of one round, run ON the GPU box (through gpurun):  bash tools/profile_round.sh <tag>
-# Three separate rocprofv3 runs of the SAME bench command: kernel stats, then one PMC pass per counter (counters are
-# never combined with hip/hsa/sys tracing).  Outputs land under gpurun_out/<tag>_*; tools/profile_summary.py turns
-# them into profiles/<tag>/.
+# The profile recipe of one round, run ON the GPU box (through gpurun):  bash tools/profile_round.sh <tag> [workloads...]
+# Per workload three separate rocprofv3 runs of the SAME command: kernel stats, then one PMC pass per counter (counters are
+# never combined with hip/hsa/sys tracing).  Outputs land under gpurun_out/<tag>_<workload>_*; tools/profile_summary.py
+# turns them into profiles/<tag>/<workload>/.  Workloads: decode (bench.py, the headline), encode (tools/encode_bench.py,
+# BASELINE config 4), commits (tools/commits_bench.py, config 5), filter (tools/filter_bench.py, K6 + gather).
 set -eo pipefail
-tag=${1:-r01}
+tag=${1:-r02}
+shift || true
+workloads=${@:-decode encode commits filter}
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-BENCH="bench.py --steps 3 --warmup 1 --no-cpu-baseline"
-timeout -k 10 300 python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_stats -o runc --output-format csv -- python3 bench.py --no-cpu-baseline > gpurun_out/${tag}_stats.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/${tag}_fetch -o runc --output-format csv -- python3 $BENCH > gpurun_out/${tag}_fetch.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/${tag}_write -o runc --output-format csv -- python3 $BENCH > gpurun_out/${tag}_write.log 2>&1
-cat gpurun_out/${tag}_bench.json
+for w in $workloads; do
+  case $w in
+    decode)  full="bench.py --no-operator-path"; short="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-operator-path" ;;
+    encode)  full="tools/encode_bench.py --sf 10 --per-column"; short="tools/encode_bench.py --sf 10 --rounds 3" ;;
+    commits) full="tools/commits_bench.py"; short="tools/commits_bench.py" ;;
+    filter)  full="tools/filter_bench.py"; short="tools/filter_bench.py" ;;
+    *) echo "unknown workload $w"; exit 2 ;;
+  esac
+  p=gpurun_out/${tag}_${w}
+  timeout -k 10 400 python3 $full > ${p}.json 2> ${p}.err
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats -d ${p}_stats -o runc --output-format csv -- python3 $short > ${p}_stats.log 2>&1
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d ${p}_fetch -o runc --output-format csv -- python3 $short > ${p}_fetch.log 2>&1
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d ${p}_write -o runc --output-format csv -- python3 $short > ${p}_write.log 2>&1
+  echo "== $w"; tail -c 600 ${p}.json; echo
+done

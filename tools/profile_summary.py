@@ -22,7 +22,7 @@ KERNELS = ("transcode_copy", "transcode_dec128", "transcode_string", "transcode_
 
 
 def short(name):
-    m = re.search(r"(transcode_\w+|encode_\w+|filter_range)", name)
+    m = re.search(r"(transcode_\w+|encode_\w+|filter_\w+|agg_sum_product)", name)
     return m.group(1) if m else None
 
 
@@ -45,12 +45,22 @@ def main():
     ap.add_argument("--write")
     ap.add_argument("--bench", nargs="*", default=[])
     ap.add_argument("--note", default="")
+    ap.add_argument("--latest", default="", help="also write the traffic summary here (profiles/pmc_traffic_latest.json)")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     if a.stats:
         for path in glob.glob(os.path.join(a.stats, "**", "*_kernel_stats.csv"), recursive=True):
-            shutil.copy(path, os.path.join(a.out, "kernel_stats.csv"))
+            # our kernels only (torch's fill / copy kernels of the harness are noise here), names shortened
+            with open(path, newline="") as f, open(os.path.join(a.out, "kernel_stats.csv"), "w", newline="") as g:
+                rd = csv.reader(f)
+                wr = csv.writer(g)
+                head = next(rd)
+                wr.writerow(head)
+                for row in rd:
+                    k = short(row[0])
+                    if k:
+                        wr.writerow([k] + row[1:])
     if a.fetch and a.write:
         fetch, write = counter_avg(a.fetch, "FETCH_SIZE"), counter_avg(a.write, "WRITE_SIZE")
         traffic = {k: int(2 * fetch[k]["avg_KB"] * 1024 + write.get(k, {"avg_KB": 0})["avg_KB"] * 1024) for k in fetch}
@@ -58,7 +68,10 @@ def main():
                        " Values are KB per dispatch; on gfx950 FETCH_SIZE counts 1/2 of wide coalesced reads "
                        "(MI355X_MICROARCH.md, HBM) so read bytes = 2*FETCH_SIZE*1024.",
                "FETCH_SIZE": fetch, "WRITE_SIZE": write, "traffic_bytes_per_launch": traffic}
-        for p in (os.path.join(a.out, "pmc_traffic.json"), os.path.join(os.path.dirname(a.out.rstrip("/")), "pmc_traffic_latest.json")):
+        targets = [os.path.join(a.out, "pmc_traffic.json")]
+        if a.latest:   # the headline workload: bench.py picks `roofline.traffic` up from here
+            targets.append(a.latest)
+        for p in targets:
             with open(p, "w") as f:
                 json.dump(doc, f, indent=1)
     for b in a.bench:
