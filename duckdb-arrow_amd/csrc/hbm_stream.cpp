@@ -28,7 +28,8 @@ class HbmStream {
     std::vector<ArrowIPCBuffer> bufs;
     bufs.emplace_back(reinterpret_cast<uint64_t>(host), static_cast<uint64_t>(size));
     IPCBufferStreamReader rd(bufs);
-    rd.GetBaseSchema();
+    if (rd.GetBaseSchema().endianness != 0)
+      throw NotImplementedException("mi_hbm_open takes little-endian streams: the resident copy IS the stream (big-endian bodies are swapped by the scan operator's reader)");
     if (o.columns && o.n_columns > 0) {
       std::vector<std::string> names;
       for (int32_t i = 0; i < o.n_columns; i++) names.emplace_back(o.columns[i] ? o.columns[i] : "");

@@ -71,10 +71,13 @@ const ArrowSchemaModel& IPCStreamReader::GetBaseSchema() {
   if (base_schema.features & (1u << 1)) {
     throw IOException("This stream uses unsupported feature DICTIONARY_REPLACEMENT");
   }
-  if (base_schema.endianness != 0) {
-    // The reference byte-swaps through nanoarrow (base_stream_reader.cpp:68-69); the device path is little-endian only.
-    throw NotImplementedException("Big-endian Arrow IPC streams are not supported by the MI355X scan path");
-  }
+  // Big-endian streams (Schema.endianness = Big): metadata and message prefixes are little-endian whatever the producer,
+  // only the buffers hold big-endian values.  The reference hands this to nanoarrow, which swaps while it decodes
+  // (ArrowIpcDecoderSetEndianness, base_stream_reader.cpp:68-69); here the body of every message is swapped in place right
+  // after it is read (SwapBodyEndianness), so that everything downstream -- kernels, C stream export, planner -- sees the
+  // little-endian layout it expects.
+  if (base_schema.endianness != 0 && base_schema.endianness != 1)
+    throw IOException("Unknown Schema.endianness " + std::to_string(base_schema.endianness));
   have_base_schema = true;
   return base_schema;
 }
@@ -182,6 +185,7 @@ bool IPCStreamReader::GetNextBatch(DecodedBatch* out, bool accept_dictionaries, 
     return true;
   }
   if (meta.compression != -1 && cur_size > 0) DecompressBody(&meta);
+  if (base_schema.endianness == 1 && cur_size > 0) SwapBodyEndianness(meta);
   SliceBatch(meta, out);
   return true;
 }
@@ -385,6 +389,9 @@ void Lz4DecompressFrame(const Lz4Api& z, uint8_t* dst, int64_t n, const uint8_t*
 }
 }  // namespace
 
+static void SubtreeBufferBounds(const ArrowField& f, const RecordBatchMeta& meta, size_t* node, size_t* variadic, bool value_only,
+                                std::vector<int64_t>* out);
+
 void IPCStreamReader::DecompressBody(RecordBatchMeta* meta) {
   if (meta->compression != 0 && meta->compression != 1) throw IOException("Unknown BodyCompression codec " + std::to_string(meta->compression));
   const bool lz4 = meta->compression == 0;
@@ -397,6 +404,23 @@ void IPCStreamReader::DecompressBody(RecordBatchMeta* meta) {
   // the projection are neither read (DecodeBody) nor decompressed
   const std::vector<char> needed = NeededBuffers(*meta);
   const size_t nbuf = meta->buffers.size();
+  std::vector<int64_t> bound;
+  {
+    size_t node = 0, variadic = 0;
+    if (meta->is_dictionary) {
+      std::function<const ArrowField*(const ArrowField&)> find = [&](const ArrowField& f) -> const ArrowField* {
+        if (f.has_dictionary && f.dict_id == meta->dict_id) return &f;
+        for (auto& c : f.children)
+          if (const ArrowField* hit = find(c)) return hit;
+        return nullptr;
+      };
+      for (auto& f : base_schema.fields)
+        if (const ArrowField* hit = find(f)) { SubtreeBufferBounds(*hit, *meta, &node, &variadic, true, &bound); break; }
+    } else {
+      for (auto& f : base_schema.fields) SubtreeBufferBounds(f, *meta, &node, &variadic, false, &bound);
+    }
+    if (bound.size() != nbuf) bound.assign(nbuf, int64_t(1) << 40);  // metadata the walk cannot follow: validation reports it
+  }
   std::vector<int64_t> ulen(nbuf, 0), opos(nbuf, 0);
   int64_t total = 0;
   for (size_t i = 0; i < nbuf; i++) {
@@ -413,8 +437,9 @@ void IPCStreamReader::DecompressBody(RecordBatchMeta* meta) {
     std::memcpy(&declared, cur_ptr + b.offset, 8);
     const int64_t n = declared == -1 ? b.length - 8 : declared;
     if (n < 0) throw IOException("Compressed buffer " + std::to_string(i) + " declares a negative uncompressed length");
-    if (n > (int64_t(1) << 40) || total > (int64_t(1) << 41))
-      throw IOException("Compressed buffer " + std::to_string(i) + " declares an implausible uncompressed length of " + std::to_string(n) + " bytes");
+    if (n > bound[i] || total > (int64_t(1) << 41))
+      throw IOException("Compressed buffer " + std::to_string(i) + " declares an uncompressed length of " + std::to_string(n) +
+                        " bytes, more than its field node (" + std::to_string(bound[i]) + " bytes at most) can hold");
     if (!lz4 && declared != -1 && z.frame_content_size) {
       // the ZSTD frame header carries the content size too: a length prefix that disagrees with it is rejected before
       // anything is allocated for it (the reference finds out after decompressing: base_stream_reader.cpp:24-29)
@@ -466,6 +491,66 @@ void IPCStreamReader::DecompressBody(RecordBatchMeta* meta) {
   cur_ptr = out;
   cur_size = total;
   meta->compression = -1;
+}
+
+// Upper bound of the UNCOMPRESSED size of every RecordBatch.buffers entry, from the field nodes alone: a compressed buffer
+// declares its own uncompressed length, and that number sizes an allocation (pinned, for scans) before a byte is decoded --
+// a few damaged bytes must not be able to ask for terabytes.  Validity, fixed-width data and offsets are bounded by the
+// node's row count; string data by the offset width (2 GiB for int32 offsets); what the walk cannot follow keeps 2^40.
+static void SubtreeBufferBounds(const ArrowField& f, const RecordBatchMeta& meta, size_t* node, size_t* variadic, bool value_only,
+                                std::vector<int64_t>* out) {
+  constexpr int64_t kLoose = int64_t(1) << 40;
+  const int64_t n = *node < meta.nodes.size() ? std::max<int64_t>(0, std::min<int64_t>(meta.nodes[*node].first, kLoose)) : kLoose;
+  (*node)++;
+  auto rows = [&](int64_t per_row, int64_t extra_rows = 0) {
+    int64_t b = 0;
+    if (per_row <= 0 || __builtin_mul_overflow(n + extra_rows, per_row, &b) || b > kLoose) return kLoose;
+    return b + 64;
+  };
+  const int64_t bitmap = (n + 7) / 8 + 64;
+  if (f.has_dictionary && !value_only) {
+    out->push_back(bitmap);
+    out->push_back(rows(f.dict_index_bit_width / 8));
+    return;
+  }
+  switch (f.type) {
+    case MI_AT_NULL: break;
+    case MI_AT_STRUCT: case MI_AT_FIXED_LIST: out->push_back(bitmap); break;
+    case MI_AT_UTF8: case MI_AT_BINARY: out->push_back(bitmap); out->push_back(rows(4, 1)); out->push_back((int64_t(1) << 31) + 64); break;
+    case MI_AT_LARGE_UTF8: case MI_AT_LARGE_BINARY: out->push_back(bitmap); out->push_back(rows(8, 1)); out->push_back(kLoose); break;
+    case MI_AT_LIST: case MI_AT_MAP: out->push_back(bitmap); out->push_back(rows(4, 1)); break;
+    case MI_AT_LARGE_LIST: out->push_back(bitmap); out->push_back(rows(8, 1)); break;
+    case MI_AT_UTF8_VIEW: case MI_AT_BINARY_VIEW: {
+      out->push_back(bitmap);
+      out->push_back(rows(16));
+      const int64_t vc = *variadic < meta.variadic_counts.size() ? meta.variadic_counts[(*variadic)++] : 0;
+      for (int64_t k = 0; k < vc && k < (1 << 20); k++) out->push_back(kLoose);
+      break;
+    }
+    case MI_AT_UNION: out->push_back(rows(1)); if (f.unit == 1) out->push_back(rows(4)); break;
+    case MI_AT_BOOL: out->push_back(bitmap); out->push_back(bitmap); break;
+    default: {
+      int32_t kind, w, nb;
+      int64_t param;
+      out->push_back(bitmap);
+      int64_t width = 16;  // the widest fixed-width value of the format (decimal256 aside, which is not decoded)
+      if (f.Plan(&kind, &param, &w, &nb, true)) {
+        switch (kind) {
+          case MI_K_COPY: case MI_K_FIXED_BINARY: width = param; break;
+          case MI_K_DEC128: case MI_K_INTERVAL_MDN: width = 16; break;
+          case MI_K_NARROW: width = param & 0xFF; break;
+          case MI_K_HALF_FLOAT: width = 2; break;
+          case MI_K_MUL_I32: case MI_K_INTERVAL_MONTHS: width = 4; break;
+          default: width = 8; break;
+        }
+      } else if (f.type == MI_AT_DECIMAL) {
+        width = 32;
+      }
+      out->push_back(rows(width));
+      break;
+    }
+  }
+  for (auto& c : f.children) SubtreeBufferBounds(c, meta, node, variadic, false, out);
 }
 
 // Number of RecordBatch.buffers entries a field subtree owns (same rules as the walk in SliceBatch)
@@ -533,6 +618,147 @@ std::vector<std::pair<int64_t, int64_t>> IPCStreamReader::ProjectedBodyRanges(co
   }
   if (ranges.empty()) ranges.emplace_back(0, 0);  // nothing to read at all (projection of empty buffers)
   return ranges;
+}
+
+// ------------------------------------------------------------------------------------------------ big-endian bodies
+namespace {
+enum class Swap : int { NONE = 0, W2 = 2, W4 = 4, W8 = 8, W16 = 16, W32 = 32, MONTH_DAY_NANO = 100, VIEW = 101 };
+
+void SwapElements(uint8_t* p, int64_t bytes, Swap how) {
+  switch (how) {
+    case Swap::NONE: return;
+    case Swap::W2: { uint16_t* v = reinterpret_cast<uint16_t*>(p); for (int64_t i = 0; i < bytes / 2; i++) v[i] = __builtin_bswap16(v[i]); return; }
+    case Swap::W4: { uint32_t* v = reinterpret_cast<uint32_t*>(p); for (int64_t i = 0; i < bytes / 4; i++) v[i] = __builtin_bswap32(v[i]); return; }
+    case Swap::W8: { uint64_t* v = reinterpret_cast<uint64_t*>(p); for (int64_t i = 0; i < bytes / 8; i++) v[i] = __builtin_bswap64(v[i]); return; }
+    case Swap::W16: case Swap::W32: {  // one wide integer: the whole value is reversed
+      const int w = static_cast<int>(how);
+      for (int64_t i = 0; i + w <= bytes; i += w) std::reverse(p + i, p + i + w);
+      return;
+    }
+    case Swap::MONTH_DAY_NANO:  // {int32 months, int32 days, int64 nanoseconds}
+      for (int64_t i = 0; i + 16 <= bytes; i += 16) {
+        uint32_t a, b;
+        uint64_t c;
+        std::memcpy(&a, p + i, 4);
+        std::memcpy(&b, p + i + 4, 4);
+        std::memcpy(&c, p + i + 8, 8);
+        a = __builtin_bswap32(a);
+        b = __builtin_bswap32(b);
+        c = __builtin_bswap64(c);
+        std::memcpy(p + i, &a, 4);
+        std::memcpy(p + i + 4, &b, 4);
+        std::memcpy(p + i + 8, &c, 8);
+      }
+      return;
+    case Swap::VIEW:  // {int32 length, 12 inline bytes} or {int32 length, 4 prefix bytes, int32 buffer, int32 offset}
+      for (int64_t i = 0; i + 16 <= bytes; i += 16) {
+        uint32_t len;
+        std::memcpy(&len, p + i, 4);
+        len = __builtin_bswap32(len);
+        std::memcpy(p + i, &len, 4);
+        if (static_cast<int32_t>(len) > 12) {
+          uint32_t bi, bo;
+          std::memcpy(&bi, p + i + 8, 4);
+          std::memcpy(&bo, p + i + 12, 4);
+          bi = __builtin_bswap32(bi);
+          bo = __builtin_bswap32(bo);
+          std::memcpy(p + i + 8, &bi, 4);
+          std::memcpy(p + i + 12, &bo, 4);
+        }
+      }
+      return;
+  }
+}
+
+// How every RecordBatch.buffers entry of a field subtree is stored (Arrow columnar format, "Endianness"): only multi-byte
+// numbers are affected -- bitmaps, boolean data, string / binary payloads and fixed_size_binary values are byte sequences.
+void SubtreeSwaps(const ArrowField& f, const RecordBatchMeta& meta, size_t* variadic, bool value_only, std::vector<Swap>* out) {
+  auto of_width = [](int bytes) {
+    switch (bytes) {
+      case 2: return Swap::W2;
+      case 4: return Swap::W4;
+      case 8: return Swap::W8;
+      case 16: return Swap::W16;
+      case 32: return Swap::W32;
+      default: return Swap::NONE;
+    }
+  };
+  if (f.has_dictionary && !value_only) {
+    out->push_back(Swap::NONE);
+    out->push_back(of_width(f.dict_index_bit_width / 8));
+    return;
+  }
+  switch (f.type) {
+    case MI_AT_NULL: break;
+    case MI_AT_STRUCT: case MI_AT_FIXED_LIST: out->push_back(Swap::NONE); break;
+    case MI_AT_UTF8: case MI_AT_BINARY: case MI_AT_LIST: case MI_AT_MAP:
+      out->push_back(Swap::NONE);
+      out->push_back(Swap::W4);
+      if (f.type == MI_AT_UTF8 || f.type == MI_AT_BINARY) out->push_back(Swap::NONE);
+      break;
+    case MI_AT_LARGE_UTF8: case MI_AT_LARGE_BINARY: case MI_AT_LARGE_LIST:
+      out->push_back(Swap::NONE);
+      out->push_back(Swap::W8);
+      if (f.type != MI_AT_LARGE_LIST) out->push_back(Swap::NONE);
+      break;
+    case MI_AT_UTF8_VIEW: case MI_AT_BINARY_VIEW: {
+      out->push_back(Swap::NONE);
+      out->push_back(Swap::VIEW);
+      const int64_t vc = *variadic < meta.variadic_counts.size() ? meta.variadic_counts[(*variadic)++] : 0;
+      for (int64_t k = 0; k < vc && k < (1 << 20); k++) out->push_back(Swap::NONE);
+      break;
+    }
+    case MI_AT_UNION: out->push_back(Swap::NONE); if (f.unit == 1) out->push_back(Swap::W4); break;
+    case MI_AT_BOOL: case MI_AT_FIXED_BINARY: out->push_back(Swap::NONE); out->push_back(Swap::NONE); break;
+    case MI_AT_INT: out->push_back(Swap::NONE); out->push_back(of_width(f.bit_width / 8)); break;
+    case MI_AT_FLOAT: out->push_back(Swap::NONE); out->push_back(of_width(f.precision == 0 ? 2 : f.precision == 1 ? 4 : 8)); break;
+    case MI_AT_DECIMAL: out->push_back(Swap::NONE); out->push_back(of_width(f.bit_width / 8)); break;
+    case MI_AT_DATE: out->push_back(Swap::NONE); out->push_back(f.unit == 0 ? Swap::W4 : Swap::W8); break;
+    case MI_AT_TIME: out->push_back(Swap::NONE); out->push_back(of_width(f.bit_width / 8)); break;
+    case MI_AT_TIMESTAMP: case MI_AT_DURATION: out->push_back(Swap::NONE); out->push_back(Swap::W8); break;
+    case MI_AT_INTERVAL:
+      out->push_back(Swap::NONE);
+      out->push_back(f.unit == 2 ? Swap::MONTH_DAY_NANO : Swap::W4);  // year_month: int32; day_time: two int32
+      break;
+    default: out->push_back(Swap::NONE); out->push_back(Swap::NONE); break;
+  }
+  for (auto& c : f.children) SubtreeSwaps(c, meta, variadic, false, out);
+}
+}  // namespace
+
+void IPCStreamReader::SwapBodyEndianness(const RecordBatchMeta& meta) {
+  std::vector<Swap> how;
+  size_t variadic = 0;
+  if (meta.is_dictionary) {
+    std::function<const ArrowField*(const ArrowField&)> find = [&](const ArrowField& f) -> const ArrowField* {
+      if (f.has_dictionary && f.dict_id == meta.dict_id) return &f;
+      for (auto& c : f.children)
+        if (const ArrowField* hit = find(c)) return hit;
+      return nullptr;
+    };
+    for (auto& f : base_schema.fields)
+      if (const ArrowField* hit = find(f)) { SubtreeSwaps(*hit, meta, &variadic, true, &how); break; }
+  } else {
+    for (auto& f : base_schema.fields) SubtreeSwaps(f, meta, &variadic, false, &how);
+  }
+  if (how.size() != meta.buffers.size()) return;  // metadata the walk cannot follow: the full validation reports it
+  // the body must be ours to rewrite: caller-owned buffers (scan_arrow_ipc) are copied first
+  if (!cur_owner) {
+    uint8_t* copy = nullptr;
+    std::shared_ptr<void> owner = DefaultBodyAlloc(static_cast<size_t>(cur_size) + 64, message.type, &copy);
+    std::memcpy(copy, cur_ptr, static_cast<size_t>(cur_size));
+    cur_owner = owner;
+    cur_ptr = copy;
+  }
+  uint8_t* body = const_cast<uint8_t*>(cur_ptr);
+  const std::vector<char> needed = NeededBuffers(meta);
+  IoPool::Get().Run(static_cast<int>(how.size()), [&](int i) {
+    const mi_buffer_span& b = meta.buffers[static_cast<size_t>(i)];
+    if (how[static_cast<size_t>(i)] == Swap::NONE || b.length <= 0) return;
+    if (!needed.empty() && !needed[static_cast<size_t>(i)]) return;    // never read from the file: nothing there to swap
+    if (!SpanInside(b.offset, b.length, cur_size)) return;             // reported by SliceBatch
+    SwapElements(body + b.offset, b.length, how[static_cast<size_t>(i)]);
+  });
 }
 
 static std::string BufferSizeError(const std::string& column, int buffer, int64_t need, int64_t have) {

@@ -141,6 +141,9 @@ class IPCStreamReader {
   //! Replaces cur_ptr/cur_size with the decompressed body and rewrites meta->buffers (ZSTD, per buffer; the CPU step the
   //! reference performs in DuckDBDecompressZstd, base_stream_reader.cpp:11-32)
   void DecompressBody(RecordBatchMeta* meta);
+  //! Big-endian stream: every multi-byte number of the body is swapped in place (after decompression), so the rest of the
+  //! path sees little-endian buffers (what nanoarrow's decoder does for the reference, base_stream_reader.cpp:68-69)
+  void SwapBodyEndianness(const RecordBatchMeta& meta);
   std::shared_ptr<void> compressed_owner;
 
   MessageHeader message;               // the decoder's message_type / body_size_bytes

@@ -35,7 +35,8 @@ bool KindCanGather(int32_t kind);
 // `tile_task[tile]` = task index (within the slice) of every tile of the slice.  One workgroup per tile.
 hipError_t LaunchTranscode(int cls, const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task,
                            int32_t n_tasks, uint32_t total_tiles, uint32_t* d_status, uint32_t misc_groups, hipStream_t stream);
-// which transcode_misc kernel owns a kind of the misc class: 0 common flat kinds (one wave per tile), 1 nested, 2 rare flat
+// which transcode_misc kernel owns a kind of the misc class: 0 / 3 common flat kinds (one wave per tile; 3 = 8-byte inputs),
+// 1 nested, 2 rare flat
 int MiscGroupOfKind(int32_t kind);
 
 //! Fused consumer: sum(a * b) over the rows that pass up to 4 conjunctive range filters, straight

@@ -155,88 +155,9 @@ __global__ __launch_bounds__(kBlockThreads) void transcode_string(const mi_col_t
   }
 }
 
-// ---------------------------------------------------------------------------------------------------- K2
-// Bit-packed bool -> one byte per row, all rows (valid or not).  Lane i expands rows [8i, 8i+8) = one source byte
-// (two when the bit offset is not byte aligned) into one 8-byte store.
-template <int T = kBlockThreads>
-__device__ __forceinline__ void tile_bool(const mi_col_task& t, int64_t row0, int n) {
-  gptr<const uint8_t> bits = GC<uint8_t>(t.buf1);
-  gptr<uint8_t> out = GM<uint8_t>(t.out_data) + row0;
-  const int64_t last_byte = (t.row_offset + t.nrows - 1) >> 3;
-  for (int r = 8 * threadIdx.x; r < n; r += 8 * T) {  // 8 rows per lane and pass: one byte (two when unaligned) -> 8 bytes
-    const int64_t bit = t.row_offset + row0 + r;
-    const int64_t byte = bit >> 3;
-    const int sh = static_cast<int>(bit & 7);
-    uint32_t b = bits[byte];
-    if (sh != 0 && byte + 1 <= last_byte) b |= static_cast<uint32_t>(bits[byte + 1]) << 8;
-    b = (b >> sh) & 0xFFu;
-    uint64_t y = (static_cast<uint64_t>(b) * 0x0101010101010101ull) & 0x8040201008040201ull;
-    y = ((y + 0x7F7F7F7F7F7F7F7Full) >> 7) & 0x0101010101010101ull;
-    if (r + 8 <= n) {
-      *(gptr<uint64_t>)(out + r) = y;
-    } else {
-      for (int k = 0; r + k < n; k++) out[r + k] = static_cast<uint8_t>(y >> (8 * k));
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------- K3c
-template <int T = kBlockThreads>
-__device__ __forceinline__ void tile_date64(const mi_col_task& t, int64_t row0, int n) {
-  gptr<const int64_t> src = GC<int64_t>(t.buf1) + t.row_offset + row0;
-  gptr<int32_t> out = GM<int32_t>(t.out_data) + row0;
-#pragma unroll 2  // 64-bit division by a constant is register hungry; 4 copies cost the class one occupancy step
-  for (int r = threadIdx.x; r < n; r += T) out[r] = static_cast<int32_t>(src[r] / 86400000ll);
-}
-
-template <int T = kBlockThreads>
-__device__ __forceinline__ void tile_mul_i32(const mi_col_task& t, int64_t row0, int n, const uint64_t* s_valid) {
-  gptr<const int32_t> src = GC<int32_t>(t.buf1) + t.row_offset + row0;
-  gptr<int64_t> out = GM<int64_t>(t.out_data) + row0;
-  const bool has_nulls = tile_needs_mask(t);
-#pragma unroll 4
-  for (int r = threadIdx.x; r < n; r += T) {
-    const bool ok = row_valid(s_valid, has_nulls, r);
-    out[r] = ok ? static_cast<int64_t>(src[r]) * t.param : 0;  // int32 * 1e6 cannot overflow int64
-  }
-}
-
-template <int T = kBlockThreads>
-__device__ __forceinline__ void tile_mul_i64(const mi_col_task& t, int64_t row0, int n, uint32_t* status, const uint64_t* s_valid) {
-  gptr<const int64_t> src = GC<int64_t>(t.buf1) + t.row_offset + row0;
-  gptr<int64_t> out = GM<int64_t>(t.out_data) + row0;
-  const bool has_nulls = tile_needs_mask(t);
-  uint32_t err = 0;
-#pragma unroll 4
-  for (int r = threadIdx.x; r < n; r += T) {
-    int64_t v = 0;
-    if (row_valid(s_valid, has_nulls, r)) {
-      if (__builtin_mul_overflow(src[r], t.param, &v)) {  // TryMultiplyOperator => ConversionException
-        v = 0;
-        err = MI_ST_MUL_OVERFLOW;
-      }
-    }
-    out[r] = v;
-  }
-  raise(status, err);
-}
-
-template <int T = kBlockThreads>
-__device__ __forceinline__ void tile_div_i64(const mi_col_task& t, int64_t row0, int n) {
-  gptr<const int64_t> src = GC<int64_t>(t.buf1) + t.row_offset + row0;
-  gptr<int64_t> out = GM<int64_t>(t.out_data) + row0;
-  const int64_t d = t.param;
-  // the divisors the type mapping produces are 1000 (ns -> us) and powers of it: constant divisions are a multiply-high,
-  // the generic 64-bit division (~100 instructions, dozens of registers) stays out of the unrolled loops
-  if (d == 1000) {
-#pragma unroll 4
-    for (int r = threadIdx.x; r < n; r += T) out[r] = src[r] / 1000;  // all rows, like upstream
-    return;
-  }
-#pragma unroll 1
-  for (int r = threadIdx.x; r < n; r += T) out[r] = src[r] / d;
-}
-
+// ---------------------------------------------------------------------------------------------------- K2, K3c, K5
+// bool bit -> byte, date64 -> date32, time / timestamp unit casts and dictionary indices -> sel_t are the common flat kinds:
+// they live in transcode_misc_light below (one wave per tile).  The rare kinds follow.
 __device__ __forceinline__ void tile_duration(const mi_col_task& t, int64_t row0, int n, uint32_t* status, const uint64_t* s_valid) {
   gptr<const int64_t> src = GC<int64_t>(t.buf1) + t.row_offset + row0;
   gptr<u32x4> out = GM<u32x4>(t.out_data) + row0;
@@ -409,56 +330,99 @@ __device__ __forceinline__ void tile_strview(const mi_col_task& t, int64_t row0,
   raise(status, err);
 }
 
-// ---------------------------------------------------------------------------------------------------- K5
-// Dictionary indices -> sel_t; NULL -> dict_len (the extra NULL slot of the decoded dictionary).
-template <int T = kBlockThreads>
-__device__ __forceinline__ void tile_dict(const mi_col_task& t, int64_t row0, int n, uint32_t* status, const uint64_t* s_valid) {
-  const int iw = static_cast<int>(t.param & 0xFF);
-  const bool is_signed = ((t.param >> 8) & 1) != 0;
-  gptr<const uint8_t> idx = GC<uint8_t>(t.buf1) + (t.row_offset + row0) * iw;
-  gptr<uint32_t> out = GM<uint32_t>(t.out_data) + row0;
-  const bool has_nulls = tile_needs_mask(t);
-  const uint32_t dict_len = static_cast<uint32_t>(t.param2);
-  uint32_t err = 0;
-#pragma unroll 4
-  for (int r = threadIdx.x; r < n; r += T) {
-    uint32_t sel = dict_len;
-    if (row_valid(s_valid, has_nulls, r)) {
-      uint64_t v;
-      switch (iw) {
-        case 1: v = is_signed ? static_cast<uint64_t>(static_cast<int64_t>(((gptr<const int8_t>)idx)[r])) : idx[r]; break;
-        case 2: v = is_signed ? static_cast<uint64_t>(static_cast<int64_t>(((gptr<const int16_t>)idx)[r]))
-                              : ((gptr<const uint16_t>)idx)[r]; break;
-        case 4: v = is_signed ? static_cast<uint64_t>(static_cast<int64_t>(((gptr<const int32_t>)idx)[r]))
-                              : ((gptr<const uint32_t>)idx)[r]; break;
-        default: v = ((gptr<const uint64_t>)idx)[r]; break;
-      }
-      if (v > 0xFFFFFFFFull) {  // "DuckDB only supports indices that fit on an uint32"
-        err = MI_ST_INDEX_RANGE;
-        v = dict_len;
-      } else if (v >= dict_len) {  // the selection vector must never point past the dictionary's NULL slot
-        err = MI_ST_DICT_INDEX;
-        v = dict_len;
-      }
-      sel = static_cast<uint32_t>(v);
-    }
-    out[r] = sel;
-  }
-  raise(status, err);
-}
-
 __device__ __forceinline__ int misc_group_of(int32_t kind) {
   switch (kind) {
-    case MI_K_BOOL: case MI_K_DICT: case MI_K_DATE64: case MI_K_MUL_I32: case MI_K_MUL_I64: case MI_K_DIV_I64: return 0;
+    case MI_K_BOOL: case MI_K_DICT: case MI_K_MUL_I32: return 0;
+    case MI_K_DATE64: case MI_K_MUL_I64: case MI_K_DIV_I64: return 3;
     case MI_K_STRUCT: case MI_K_LIST32: case MI_K_LIST64: case MI_K_STRVIEW: return 1;
     default: return 2;
   }
 }
 
-// The common flat kinds (group 0) move 2-16 KB per tile: with 256-thread workgroups a CU holds 8 such
-// tiles and each is one chain of dependent round trips (task lookup, bitmap, data), which left the kernel latency bound
-// (1.8-2.3 TB/s).  Here ONE WAVE owns a tile (32 rows per lane): 32 independent tiles per CU, no workgroup barriers.
+// The common flat kinds (group 0) move 2-16 KB per tile: with 256-thread workgroups a CU holds 8 such tiles and each is
+// one chain of dependent round trips (task lookup, bitmap, data), which left the kernel latency bound (1.8-2.3 TB/s).
+// Here ONE WAVE owns a tile -- 32 independent tiles per CU, no workgroup barriers -- and a lane moves 4 consecutive rows
+// per access (16-byte loads and stores), with every load of the tile (or of half of it, for 8-byte inputs) issued before
+// the first value is used: a tile is one or two round trips instead of the eight a row-per-lane loop with 4 loads in
+// flight needed (3.0 TB/s on config 5's bool + dictionary columns, profiles/r01_final).
 constexpr int kLightThreads = 64;
+
+// out[r] = f(r, src[r]) for r < n <= 2048 by one wave; GROUP passes of 64 x V rows are in flight at a time.
+template <typename IN, typename OUT, int V, int GROUP, typename F>
+__device__ __forceinline__ void light_map(gptr<const IN> src, gptr<OUT> out, int n, F&& f) {
+  typedef IN in_vec __attribute__((ext_vector_type(V)));
+  typedef in_vec in_vec_a __attribute__((aligned(sizeof(IN))));                 // Arrow buffers: element aligned only
+  typedef OUT out_vec __attribute__((ext_vector_type(V)));
+  typedef out_vec out_vec_a __attribute__((aligned(V * sizeof(OUT) < 16 ? V * sizeof(OUT) : 16)));  // tiles start 16-byte aligned
+  constexpr int PASSES = kTileRows / (kLightThreads * V);
+  static_assert(PASSES % GROUP == 0, "whole groups");
+  const int lane = threadIdx.x;
+#pragma unroll
+  for (int g = 0; g < PASSES; g += GROUP) {
+    if ((g * kLightThreads) * V >= n) break;  // uniform
+    in_vec vin[GROUP];
+#pragma unroll
+    for (int p = 0; p < GROUP; p++) {
+      const int base = ((g + p) * kLightThreads + lane) * V;
+      if (base + V <= n) {
+        vin[p] = __builtin_nontemporal_load((gptr<const in_vec_a>)(src + base));
+      } else {
+#pragma unroll
+        for (int k = 0; k < V; k++) vin[p][k] = base + k < n ? src[base + k] : IN(0);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < GROUP; p++) {
+      const int base = ((g + p) * kLightThreads + lane) * V;
+      out_vec vout;
+#pragma unroll
+      for (int k = 0; k < V; k++) vout[k] = f(base + k, vin[p][k]);
+      if (base + V <= n) {
+        __builtin_nontemporal_store(vout, (gptr<out_vec_a>)(out + base));
+      } else {
+#pragma unroll
+        for (int k = 0; k < V; k++)
+          if (base + k < n) out[base + k] = vout[k];
+      }
+    }
+  }
+}
+
+// Bit-packed bool -> one byte per row: lane i expands rows [32 i, 32 i + 32) (4 bytes in, two 16-byte stores out)
+__device__ __forceinline__ void light_bool(const mi_col_task& t, int64_t row0, int n) {
+  gptr<const uint8_t> bits = GC<uint8_t>(t.buf1);
+  gptr<uint8_t> out = GM<uint8_t>(t.out_data) + row0;
+  const int64_t last_byte = (t.row_offset + t.nrows - 1) >> 3;
+  const int r = 32 * static_cast<int>(threadIdx.x);
+  if (r >= n) return;
+  const int64_t bit = t.row_offset + row0 + r;
+  const int64_t byte = bit >> 3;
+  const int sh = static_cast<int>(bit & 7);
+  uint64_t raw = 0;  // up to 5 source bytes
+#pragma unroll
+  for (int k = 0; k < 5; k++)
+    if (byte + k <= last_byte) raw |= static_cast<uint64_t>(bits[byte + k]) << (8 * k);
+  const uint32_t b32 = static_cast<uint32_t>(raw >> sh);
+  uint64_t y[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint64_t b = (b32 >> (8 * k)) & 0xFFu;
+    uint64_t v = (b * 0x0101010101010101ull) & 0x8040201008040201ull;
+    y[k] = ((v + 0x7F7F7F7F7F7F7F7Full) >> 7) & 0x0101010101010101ull;
+  }
+  if (r + 32 <= n) {
+    __builtin_nontemporal_store(u32x4{static_cast<uint32_t>(y[0]), static_cast<uint32_t>(y[0] >> 32), static_cast<uint32_t>(y[1]), static_cast<uint32_t>(y[1] >> 32)},
+                                (gptr<u32x4>)(out + r));
+    __builtin_nontemporal_store(u32x4{static_cast<uint32_t>(y[2]), static_cast<uint32_t>(y[2] >> 32), static_cast<uint32_t>(y[3]), static_cast<uint32_t>(y[3] >> 32)},
+                                (gptr<u32x4>)(out + r + 16));
+  } else {
+    for (int k = 0; r + k < n; k++) out[r + k] = static_cast<uint8_t>(y[k >> 3] >> (8 * (k & 7)));
+  }
+}
+
+// WIDE = false: bool, dictionary indices, int32 -> int64 casts; true: the 8-byte inputs (date64, timestamp / time unit
+// casts), whose 64-bit multiply-high arithmetic wants a register budget of its own
+template <bool WIDE>
 __global__ __launch_bounds__(kLightThreads) void transcode_misc_light(const mi_col_task* __restrict__ tasks,
                                                                       const uint32_t* __restrict__ tile_begin,
                                                                       const uint32_t* __restrict__ tile_task, int n_tasks,
@@ -466,18 +430,90 @@ __global__ __launch_bounds__(kLightThreads) void transcode_misc_light(const mi_c
   __shared__ uint64_t s_valid[kTileRows / 64];
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     MI_TILE_PROLOGUE();
-    if (misc_group_of(t.kind) != 0) continue;  // uniform: another group's launch owns this tile
+    if (misc_group_of(t.kind) != (WIDE ? 3 : 0)) continue;  // uniform: another group's launch owns this tile
     if (tile_needs_mask(t)) __syncthreads();
     tile_validity<kLightThreads>(t, row0, n, s_valid);
-    switch (t.kind) {
-      case MI_K_BOOL: tile_bool<kLightThreads>(t, row0, n); break;
-      case MI_K_DATE64: tile_date64<kLightThreads>(t, row0, n); break;
-      case MI_K_MUL_I32: tile_mul_i32<kLightThreads>(t, row0, n, s_valid); break;
-      case MI_K_MUL_I64: tile_mul_i64<kLightThreads>(t, row0, n, status, s_valid); break;
-      case MI_K_DIV_I64: tile_div_i64<kLightThreads>(t, row0, n); break;
-      case MI_K_DICT: tile_dict<kLightThreads>(t, row0, n, status, s_valid); break;
+    const bool has_nulls = tile_needs_mask(t);
+    auto valid = [&](int r) { return row_valid(s_valid, has_nulls, r); };
+    uint32_t err = 0;
+    switch (WIDE ? t.kind : 0) {
+      case MI_K_DATE64:
+        light_map<int64_t, int32_t, 4, 4>(GC<int64_t>(t.buf1) + t.row_offset + row0, GM<int32_t>(t.out_data) + row0, n,
+                                          [&](int, int64_t v) { return static_cast<int32_t>(v / 86400000ll); });
+        break;
+      case MI_K_MUL_I64: {
+        const int64_t factor = t.param;
+        light_map<int64_t, int64_t, 4, 4>(GC<int64_t>(t.buf1) + t.row_offset + row0, GM<int64_t>(t.out_data) + row0, n, [&](int r, int64_t v) {
+          int64_t o = 0;
+          if (valid(r) && __builtin_mul_overflow(v, factor, &o)) {  // TryMultiplyOperator => ConversionException
+            o = 0;
+            err = MI_ST_MUL_OVERFLOW;
+          }
+          return o;
+        });
+        break;
+      }
+      case MI_K_DIV_I64: {
+        // the divisors the type mapping produces are 1000 (ns -> us) and powers of it: a constant division is a
+        // multiply-high, the generic 64-bit division (~100 instructions, dozens of registers) stays out of the unrolled code
+        const int64_t d = t.param;
+        if (d == 1000) {
+          light_map<int64_t, int64_t, 4, 4>(GC<int64_t>(t.buf1) + t.row_offset + row0, GM<int64_t>(t.out_data) + row0, n,
+                                            [&](int, int64_t v) { return v / 1000; });  // all rows, like upstream
+        } else {
+          gptr<const int64_t> src = GC<int64_t>(t.buf1) + t.row_offset + row0;
+          gptr<int64_t> out = GM<int64_t>(t.out_data) + row0;
+#pragma unroll 1
+          for (int r = threadIdx.x; r < n; r += kLightThreads) out[r] = src[r] / d;
+        }
+        break;
+      }
       default: break;
     }
+    switch (WIDE ? 0 : t.kind) {
+      case MI_K_BOOL: light_bool(t, row0, n); break;
+      case MI_K_MUL_I32: {
+        const int64_t factor = t.param;  // int32 * 1e6 cannot overflow int64
+        light_map<int32_t, int64_t, 4, 4>(GC<int32_t>(t.buf1) + t.row_offset + row0, GM<int64_t>(t.out_data) + row0, n,
+                                          [&](int r, int32_t v) { return valid(r) ? static_cast<int64_t>(v) * factor : int64_t(0); });
+        break;
+      }
+      case MI_K_DICT: {
+        // indices -> sel_t; NULL -> dict_len (the extra NULL slot of the decoded dictionary)
+        const int iw = static_cast<int>(t.param & 0xFF);
+        const bool is_signed = ((t.param >> 8) & 1) != 0;
+        const uint32_t dict_len = static_cast<uint32_t>(t.param2);
+        auto to_sel = [&](int r, uint64_t v) {
+          if (!valid(r)) return dict_len;
+          if (v > 0xFFFFFFFFull) {  // "DuckDB only supports indices that fit on an uint32"
+            err = MI_ST_INDEX_RANGE;
+            return dict_len;
+          }
+          if (v >= dict_len) {  // the selection vector must never point past the dictionary's NULL slot
+            err = MI_ST_DICT_INDEX;
+            return dict_len;
+          }
+          return static_cast<uint32_t>(v);
+        };
+        gptr<uint32_t> out = GM<uint32_t>(t.out_data) + row0;
+        gptr<const uint8_t> idx = GC<uint8_t>(t.buf1) + (t.row_offset + row0) * iw;
+        if (iw == 4) {
+          if (is_signed) light_map<int32_t, uint32_t, 4, 8>((gptr<const int32_t>)idx, out, n, [&](int r, int32_t v) { return to_sel(r, static_cast<uint64_t>(static_cast<int64_t>(v))); });
+          else light_map<uint32_t, uint32_t, 4, 8>((gptr<const uint32_t>)idx, out, n, [&](int r, uint32_t v) { return to_sel(r, v); });
+        } else if (iw == 2) {
+          if (is_signed) light_map<int16_t, uint32_t, 4, 8>((gptr<const int16_t>)idx, out, n, [&](int r, int16_t v) { return to_sel(r, static_cast<uint64_t>(static_cast<int64_t>(v))); });
+          else light_map<uint16_t, uint32_t, 4, 8>((gptr<const uint16_t>)idx, out, n, [&](int r, uint16_t v) { return to_sel(r, v); });
+        } else if (iw == 1) {
+          if (is_signed) light_map<int8_t, uint32_t, 4, 8>((gptr<const int8_t>)idx, out, n, [&](int r, int8_t v) { return to_sel(r, static_cast<uint64_t>(static_cast<int64_t>(v))); });
+          else light_map<uint8_t, uint32_t, 4, 8>(idx, out, n, [&](int r, uint8_t v) { return to_sel(r, v); });
+        } else {
+          light_map<uint64_t, uint32_t, 4, 4>((gptr<const uint64_t>)idx, out, n, [&](int r, uint64_t v) { return to_sel(r, v); });  // a negative int64 is > UINT32_MAX too
+        }
+        break;
+      }
+      default: break;
+    }
+    raise(status, err);
   }
 }
 
@@ -489,7 +525,7 @@ __global__ __launch_bounds__(kBlockThreads) void transcode_misc(const mi_col_tas
                                                                 const uint32_t* __restrict__ tile_begin,
                                                                 const uint32_t* __restrict__ tile_task, int n_tasks,
                                                                 uint32_t total_tiles, uint32_t* __restrict__ status) {
-  static_assert(GROUP == 1 || GROUP == 2, "group 0 is transcode_misc_light");
+  static_assert(GROUP == 1 || GROUP == 2, "groups 0 and 3 are transcode_misc_light");
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     MI_TILE_PROLOGUE();
     __shared__ uint64_t s_valid[kTileRows / 64];
@@ -554,7 +590,8 @@ int ClassOfTask(const mi_col_task& t) {
 
 int MiscGroupOfKind(int32_t kind) {
   switch (kind) {
-    case MI_K_BOOL: case MI_K_DICT: case MI_K_DATE64: case MI_K_MUL_I32: case MI_K_MUL_I64: case MI_K_DIV_I64: return 0;
+    case MI_K_BOOL: case MI_K_DICT: case MI_K_MUL_I32: return 0;
+    case MI_K_DATE64: case MI_K_MUL_I64: case MI_K_DIV_I64: return 3;
     case MI_K_STRUCT: case MI_K_LIST32: case MI_K_LIST64: case MI_K_STRVIEW: return 1;
     default: return 2;
   }
@@ -573,7 +610,8 @@ hipError_t LaunchTranscode(int cls, const mi_col_task* d_tasks, const uint32_t* 
     case kClassDec128: MI_LAUNCH(transcode_dec128, block); break;
     case kClassString: MI_LAUNCH(transcode_string, block); break;
     case kClassMisc:
-      if (misc_groups & 1u) MI_LAUNCH(transcode_misc_light, dim3(kLightThreads));
+      if (misc_groups & 1u) MI_LAUNCH(transcode_misc_light<false>, dim3(kLightThreads));
+      if (misc_groups & 8u) MI_LAUNCH(transcode_misc_light<true>, dim3(kLightThreads));
       if (misc_groups & 2u) MI_LAUNCH(transcode_misc<1>, block);
       if (misc_groups & 4u) MI_LAUNCH(transcode_misc<2>, block);
       break;

@@ -5,8 +5,6 @@
 
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
-#include <sys/mman.h>
-#include <sys/vfs.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -27,6 +25,7 @@ namespace {
 struct SinkTimers {
   double append = 0, serialize = 0, write = 0;
   bool on = std::getenv("MI_WRITER_TIMING") != nullptr;
+  std::mutex mu;  // several sink threads add their stage times
 };
 SinkTimers& Timers() {
   static SinkTimers t;
@@ -36,7 +35,12 @@ struct ScopedTimer {
   double* acc;
   std::chrono::steady_clock::time_point t0;
   explicit ScopedTimer(double* a) : acc(Timers().on ? a : nullptr) { if (acc) t0 = std::chrono::steady_clock::now(); }
-  ~ScopedTimer() { if (acc) *acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+  ~ScopedTimer() {
+    if (!acc) return;
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::lock_guard<std::mutex> lk(Timers().mu);
+    *acc += dt;
+  }
 };
 constexpr size_t kBufferAlign = 64;  // Arrow's recommended buffer alignment; any multiple of 8 is valid IPC
 size_t RoundUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -455,7 +459,6 @@ ArrowStreamWriter::~ArrowStreamWriter() {
   }
   io_cv.notify_all();
   if (io_thread.joinable()) io_thread.join();  // queued batches are still written
-  if (fd >= 0 && use_mmap && !finalized) (void)::ftruncate(fd, static_cast<off_t>(total_written));  // abandoned: no zero tail
   if (fd >= 0) ::close(fd);
 }
 
@@ -470,27 +473,14 @@ void ArrowStreamWriter::InitOutputFile(const std::string& file_path) {
   // FILE_FLAGS_WRITE | FILE_FLAGS_FILE_CREATE_NEW (arrow_stream_writer.cpp:49-53): always a fresh file
   fd = ::open(file_path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
   if (fd < 0) throw IOException("Cannot open file \"" + file_path + "\": " + std::strerror(errno));
-  // How record batches reach the file.  write() / pwrite() into ONE tmpfs file are serialised by the inode lock (several
-  // writers are slower than one: 2.0 s for 10.5 GB with one, 3.9 s with four), while stores through a shared mapping only
-  // take the page-fault path, which runs in parallel: on tmpfs (page cache = the file) row groups are memcpy'd into
-  // mappings of their claimed ranges; everywhere else they are pwritten.  MI_WRITER_IO=pwrite|mmap overrides.
-  struct statfs fs;
-  use_mmap = ::fstatfs(fd, &fs) == 0 && static_cast<unsigned long>(fs.f_type) == 0x01021994ul /* TMPFS_MAGIC */;
-  if (const char* v = std::getenv("MI_WRITER_IO")) use_mmap = std::string(v) == "mmap";
+  // Record batches are pwritten at claimed offsets by whichever thread serialized them.  (On tmpfs the page cache IS the
+  // file and every new page is allocated, charged and zeroed under the write: measured on the MI355X box ~5-6 GB/s into one
+  // file whether 1, 2, 4 or 6 threads pwrite and whether they write() or store through a shared mapping -- the end-to-end
+  // COPY of SF10 is bound by that, not by staging or the K7 kernels: tools/copy_bench.py)
 }
 
 void ArrowStreamWriter::WriteAt(int64_t offset, const uint8_t* p, size_t n) {
   ScopedTimer timer(&Timers().write);
-  if (n == 0) return;
-  if (use_mmap) {
-    const int64_t page = offset & ~static_cast<int64_t>(4095);
-    const size_t span = static_cast<size_t>(offset - page) + n;
-    void* m = ::mmap(nullptr, span, PROT_READ | PROT_WRITE, MAP_SHARED, fd, static_cast<off_t>(page));
-    if (m == MAP_FAILED) throw IOException("Could not map file \"" + file_name + "\" for writing: " + std::strerror(errno));
-    std::memcpy(static_cast<uint8_t*>(m) + (offset - page), p, n);
-    ::munmap(m, span);
-    return;
-  }
   size_t done = 0;
   while (done < n) {
     ssize_t w = ::pwrite(fd, p + done, n - done, static_cast<off_t>(offset + static_cast<int64_t>(done)));
@@ -507,17 +497,7 @@ int64_t ArrowStreamWriter::ReserveRowGroup(size_t bytes) {
   const int64_t at = static_cast<int64_t>(total_written);
   total_written += bytes;
   ++row_group_count;
-  GrowMapped();
   return at;
-}
-
-// mapped output: the file is extended ahead of the writers (a store past EOF through a mapping is a SIGBUS) in 1 GiB
-// steps and cut back to its real size when the writer is finalized.  Caller holds io_mu.
-void ArrowStreamWriter::GrowMapped() {
-  if (!use_mmap || total_written <= mapped_cap) return;
-  mapped_cap = (total_written + (idx_t(1) << 30)) & ~((idx_t(1) << 30) - 1);
-  if (::ftruncate(fd, static_cast<off_t>(mapped_cap)) != 0)
-    throw IOException("Could not extend file \"" + file_name + "\": " + std::strerror(errno));
 }
 
 void ArrowStreamWriter::WriteData(const uint8_t* p, size_t n) {
@@ -526,7 +506,6 @@ void ArrowStreamWriter::WriteData(const uint8_t* p, size_t n) {
     std::lock_guard<std::mutex> lk(io_mu);
     at = static_cast<int64_t>(total_written);
     total_written += n;
-    GrowMapped();
   }
   WriteAt(at, p, n);
 }
@@ -604,8 +583,6 @@ void ArrowStreamWriter::Finalize() {
   DrainIo();
   const uint8_t end_of_stream[] = {0xFF, 0xFF, 0xFF, 0xFF, 0x00, 0x00, 0x00, 0x00};
   WriteData(end_of_stream, sizeof(end_of_stream));
-  if (use_mmap && ::ftruncate(fd, static_cast<off_t>(total_written)) != 0)
-    throw IOException("Could not set the size of file \"" + file_name + "\": " + std::strerror(errno));
   ::close(fd);
   fd = -1;
   finalized = true;
@@ -1013,6 +990,9 @@ void PumpScanParallel(mi_writer* w, ArrowScan* scan, int threads, int64_t* rows_
   }
   cv.notify_all();
   for (auto& t : workers) t.join();
+  if (Timers().on)
+    std::fprintf(stderr, "[mi_writer] pump with %d sink threads (thread-seconds): append %.3f, serialize (H2D + K7 + D2H) %.3f, write %.3f\n", threads,
+                 Timers().append, Timers().serialize, Timers().write);
   // give every batch back before reporting
   for (int tok : to_release) scan->ReleaseBatch(held[static_cast<size_t>(tok)].ref);
   if (error) std::rethrow_exception(error);

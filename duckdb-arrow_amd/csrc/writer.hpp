@@ -144,9 +144,6 @@ class ArrowStreamWriter {
   void InitSchema(const std::vector<ArrowField>& fields, const std::vector<std::pair<std::string, std::string>>& metadata);
   void InitOutputFile(const std::string& file_path);
   void WriteData(const uint8_t* p, size_t n);   // appends at the end of what has been claimed so far
-  void GrowMapped();
-  bool use_mmap = false;
-  idx_t mapped_cap = 0;
 
   // record-batch messages are written by an I/O thread while the sink stages the next row group; two body buffers
   // alternate (the reference writes synchronously inside Flush, arrow_stream_writer.cpp:66-77)

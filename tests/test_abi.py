@@ -85,13 +85,13 @@ def test_product_does_not_import_the_oracle():
                 assert "pyoracle" not in text and "liboracle" not in text and "oracle.h" not in text, os.path.join(root, f)
 
 
-def _build_c_example(tmp_path):
+def _build_c_example(tmp_path, name="q6"):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = str(tmp_path / "q6")
+    exe = str(tmp_path / name)
     libdir = os.path.join(root, "duckdb-arrow_amd")
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"),
-                    os.path.join(root, "examples", "q6.c"), "-L" + libdir, "-lmi_arrow_ipc", "-Wl,-rpath," + libdir, "-o", exe],
+                    os.path.join(root, "examples", name + ".c"), "-L" + libdir, "-lmi_arrow_ipc", "-Wl,-rpath," + libdir, "-o", exe],
                    check=True, capture_output=True)
     return exe
 
@@ -118,3 +118,19 @@ def test_plain_c_client_computes_q6(tmp_path):
     r = subprocess.run([exe, os.path.join(root, "tests", "golden", "lineitem_sf0_01_q6.arrows")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "revenue = 1193053.2253  (1191 of 60175 rows pass)" in r.stdout
+
+
+def test_hbm_example_builds(tmp_path):
+    """examples/hbm_scan.c: the headline measurement from plain C99 (mi_hbm_* + mi_synth_*), -Werror clean."""
+    _build_c_example(tmp_path, "hbm_scan")
+
+
+@pytest.mark.gpu
+def test_plain_c_client_runs_the_hbm_resident_scan(tmp_path):
+    """The HBM-resident super-batch mode is reachable without Python: the C program plans, launches and times the scan of a
+    small synthetic lineitem and reads a vector element back."""
+    import subprocess
+    exe = _build_c_example(tmp_path, "hbm_scan")
+    r = subprocess.run([exe, "0.05", "3"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "300060 rows in 3 messages, 48 tasks" in r.stdout and "transcode_string" in r.stdout and "l_orderkey[0] = " in r.stdout
