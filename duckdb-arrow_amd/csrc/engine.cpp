@@ -425,6 +425,10 @@ std::vector<int64_t> Plan::NullCounts(bool reset) {
     MI_HIP_CHECK(hipMemcpy(per_slot.data(), d_null_counts, per_slot.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
     if (reset) MI_HIP_CHECK(hipMemset(d_null_counts, 0, per_slot.size() * sizeof(int64_t)));
   }
+  return MapNullCounts(per_slot.data());
+}
+
+std::vector<int64_t> Plan::MapNullCounts(const int64_t* per_slot) const {
   // back to the caller's task order (non-encode tasks report 0)
   std::vector<int64_t> out(order.size(), 0);
   for (size_t i = 0; i < order.size(); i++) {

@@ -94,6 +94,8 @@ struct Plan {
           class_rows[device::kNumClasses] = {0};
   uint32_t Status();
   std::vector<int64_t> NullCounts(bool reset);
+  //! per_slot = a host copy of d_null_counts (n_null_counts entries) -> NULL counts in the caller's task order
+  std::vector<int64_t> MapNullCounts(const int64_t* per_slot) const;
 };
 
 // status word -> the exception the reference would throw

@@ -707,8 +707,8 @@ void ArrowScan::EnqueueBatch(Slot& s) {
     s.needs_stage_b = true;
     return;
   }
-  if (!opts.device_resident && !agg.on && s.d2h_bytes > 0)
-    MI_HIP_CHECK(hipMemcpyAsync(s.h_out, s.d_out, s.d2h_bytes, hipMemcpyDeviceToHost, ctx->d2h_stream));
+  s.host_vectors = !opts.device_resident && !agg.on && s.d2h_bytes > 0 && !keep_on_device;
+  if (s.host_vectors) MI_HIP_CHECK(hipMemcpyAsync(s.h_out, s.d_out, s.d2h_bytes, hipMemcpyDeviceToHost, ctx->d2h_stream));
   // the device status word travels with the results instead of costing a stream-wide synchronisation
   MI_HIP_CHECK(hipMemcpyAsync(&s.h_status[0], s.plan->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->d2h_stream));
   s.h_status[1] = 0;
@@ -1077,6 +1077,39 @@ void ArrowScan::ReleaseBatch(const BatchRef& ref) {
   Slot& s = slots[static_cast<size_t>(ref.slot)];
   s.busy = false;
   s.batch.owner.reset();
+}
+
+void ArrowScan::EnsureHostVectors(const BatchRef& ref) {
+  Slot& s = slots[static_cast<size_t>(ref.slot)];
+  if (s.host_vectors || opts.device_resident || s.compact || s.d2h_bytes == 0) return;
+  ctx->Bind();
+  MI_HIP_CHECK(hipMemcpy(s.h_out, s.d_out, s.d2h_bytes, hipMemcpyDeviceToHost));
+  s.host_vectors = true;
+}
+
+void ArrowScan::DeviceColumn(const BatchRef& ref, size_t c, DeviceColumnView* out) const {
+  *out = DeviceColumnView();
+  const Slot& s = slots[static_cast<size_t>(ref.slot)];
+  if (s.compact || c >= out_columns.size() || out_columns[c].is_filename || out_columns[c].is_hive || s.col_root[c] < 0) return;
+  const PlannedNode& pn = s.planner.nodes[static_cast<size_t>(s.col_root[c])];
+  if (!pn.children.empty() || pn.dict_id >= 0 || pn.source_node < 0) return;
+  if (pn.alias_body_off >= 0 && !opts.device_resident) return;   // aliased into the HOST body: not in HBM at all
+  const DecodedNode& dn = s.batch.nodes[static_cast<size_t>(pn.source_node)];
+  out->kind = pn.kind;
+  out->width = pn.width;
+  out->null_count = pn.null_count;
+  out->d_data = pn.alias_body_off >= 0 ? s.d_in + pn.alias_body_off : s.d_out + pn.data_off;
+  out->d_validity = (pn.valid_off >= 0 && pn.null_count != 0) ? s.d_out + pn.valid_off : nullptr;
+  if (pn.null_count != 0 && pn.valid_off < 0) return;
+  if (pn.kind == MI_K_STR32 || pn.kind == MI_K_STR64) {
+    if (dn.spans.size() < 3) return;
+    out->offset_width = pn.kind == MI_K_STR64 ? 8 : 4;
+    out->d_heap = s.d_in + dn.spans[2].offset;
+    out->ptr_base = pn.ptr_base;
+    out->h_offsets = s.batch.body + dn.spans[1].offset;
+    out->h_validity = dn.spans[0].length > 0 ? s.batch.body + dn.spans[0].offset : nullptr;
+  }
+  out->flat = true;
 }
 
 void ArrowScan::BuildChunk(const BatchRef& ref, int32_t window, ChunkStorage* st, mi_data_chunk* out) {

@@ -73,6 +73,20 @@ struct BatchRef {
   int64_t chunk_rows = 0;    // rows its chunks hold together: nrows, or `selected` when the batch was compacted
 };
 
+//! A decoded top-level column of an acquired record batch where it lies in HBM (the fused COPY reads it there)
+struct DeviceColumnView {
+  bool flat = false;                  // a leaf vector without dictionary / children; the fields below are set only then
+  const uint8_t* d_data = nullptr;    // DuckDB vector data (row 0 of the batch)
+  const uint8_t* d_validity = nullptr;  // validity words, NULL when the column has no NULLs
+  int32_t kind = 0, width = 0;
+  int64_t null_count = 0;
+  const uint8_t* d_heap = nullptr;    // string kinds: device copy of the Arrow data buffer ...
+  uint64_t ptr_base = 0;              // ... and the pointer value its byte 0 has inside the string_t rows
+  const uint8_t* h_offsets = nullptr; // string kinds: the Arrow offsets / validity bitmap in the host body
+  const uint8_t* h_validity = nullptr;
+  int32_t offset_width = 0;
+};
+
 class ScanBase {
  public:
   virtual ~ScanBase() = default;
@@ -122,6 +136,12 @@ class ArrowScan : public ScanBase {
   size_t NumOutputColumns() const { return out_columns.size(); }
   const std::vector<ScanColumn>& OutputColumns() const { return out_columns; }
   bool Initialized() const { return initialized; }
+  bool HasFilter() const { return has_filter; }
+  //! Host consumers only: decoded vectors of the record batches enqueued from now on stay in HBM (no copy into the pinned
+  //! output slot) until EnsureHostVectors asks for them -- a consumer that reads them on the GPU (the fused COPY) sets this
+  void KeepVectorsOnDevice(bool on) { keep_on_device = on; }
+  void EnsureHostVectors(const BatchRef& ref);
+  void DeviceColumn(const BatchRef& ref, size_t column, DeviceColumnView* out) const;
 
  private:
   struct Source {
@@ -171,6 +191,7 @@ class ArrowScan : public ScanBase {
     size_t d2h_bytes = 0;                              // bytes that travel back to the host
     size_t stage_a_bytes = 0;                          // arena bytes of the full-width arrays (+ sel, counts)
     bool compact = false;                              // chunks hold only the selected rows (dense arrays behind stage A's)
+    bool host_vectors = false;                         // h_out holds the decoded vectors
     bool needs_stage_b = false;                        // compaction: the gather + copy back wait for the counts
     uint8_t* compact_region = nullptr;                 // device address of the dense arrays
   };
@@ -259,6 +280,7 @@ class ArrowScan : public ScanBase {
   std::vector<int32_t> filter_columns;
   std::vector<void*> d_in_lists;         // per leaf (clause order): its IN-list in HBM, or NULL
   bool compact = false;
+  bool keep_on_device = false;
 };
 
 //! read_arrow over several GPUs of one process: one ArrowScan per context, record batch k of the file list

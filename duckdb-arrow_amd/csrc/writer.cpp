@@ -836,11 +836,11 @@ int SinkThreads() {
 // their 2048-row chunks into row groups exactly where the one-thread sink would flush (after the chunk that reaches
 // row_group_size rows / row_group_size_bytes); each row group goes to one of T sink threads which appends its chunks,
 // encodes it and writes it -- claims of the file range happen in row-group order, so the file equals the one-thread file.
-void PumpScanParallel(mi_writer* w, ArrowScan* scan, int threads, int64_t* rows_out) {
+void PumpScanParallel(mi_writer* w, ArrowScan* scan, int threads, int64_t* rows_out, const BatchRef* first = nullptr) {
   struct Piece { int batch; int32_t w0, w1; };        // windows [w0, w1) of held batch `batch`
   struct Job { std::vector<Piece> pieces; int64_t seq = 0; };
   struct Held { BatchRef ref; int pieces_open = 0; bool fully_cut = false; };
-  scan->EnsurePipelineDepth(threads + 4);
+  if (!first) scan->EnsurePipelineDepth(threads + 4);   // with a batch already acquired the caller has done it
   std::mutex mu;
   std::condition_variable cv;
   std::deque<Job> jobs;
@@ -944,11 +944,15 @@ void PumpScanParallel(mi_writer* w, ArrowScan* scan, int threads, int64_t* rows_
     while (true) {
       release_ready(false);
       BatchRef ref;
-      if (!scan->AcquireBatch(&ref)) {
+      if (first) {
+        ref = *first;
+        first = nullptr;
+      } else if (!scan->AcquireBatch(&ref)) {
         if (scan->Exhausted()) break;
         release_ready(true);   // every slot is held by a sink thread: wait for one to come back
         continue;
       }
+      scan->EnsureHostVectors(ref);
       rows += ref.chunk_rows;
       int tok;
       {
@@ -998,6 +1002,376 @@ void PumpScanParallel(mi_writer* w, ArrowScan* scan, int threads, int64_t* rows_
   if (error) std::rethrow_exception(error);
   if (rows_out) *rows_out = rows;
 }
+
+// ---- the fused COPY (FROM read_arrow(...)) TO 'file': decode and encode both run on the GPU, so the decoded vectors never
+// have to leave HBM.  For every row group that lies inside one record batch of the scan the K7 kernels read the scan slot's
+// vectors where the K1-K4 kernels wrote them (string payloads: the HBM copy of the Arrow data buffer the string_t rows
+// point into) and write the IPC body; only that body travels back (one D2H) and is written by an I/O thread.  Per row this
+// takes the host out of the loop except for pread -> H2D and D2H -> pwrite: no D2H of the vectors, no staging copy, no H2D
+// of the staged rows (DESIGN.md section 10 has the byte counts).  Row groups are cut exactly where the one-thread sink cuts
+// them (after the 2048-row chunk that reaches row_group_size); rows of a row group that straddles two record batches take
+// the host path (EnsureHostVectors + ChunkCollection) on the pump thread, so the file is byte-identical to the
+// one-thread file in every case.
+struct FusedEncoder {
+  uint8_t* d_body = nullptr;  size_t d_cap = 0;
+  uint8_t* h_body = nullptr;  size_t h_cap = 0;
+  int64_t* h_nulls = nullptr; size_t h_nulls_cap = 0;   // pinned copy of the plan's NULL counters
+  uint32_t* h_status = nullptr;
+  std::unique_ptr<Plan> plan;
+  hipEvent_t encoded = nullptr, done = nullptr;
+  bool busy = false;
+  // the row group in flight
+  int64_t nrows = 0, body_size = 0;
+  std::vector<mi_buffer_span> spans;
+  std::vector<int32_t> first_span;
+};
+
+bool FusedSinkPossible(mi_writer* w, ArrowScan* scan) {
+  if (std::getenv("MI_WRITER_NO_FUSED")) return false;
+  if (scan->HasFilter() || w->buffer->Count() != 0) return false;
+  const auto& cols = scan->OutputColumns();
+  if (cols.size() != w->buffer->roots.size() || w->buffer->columns.size() != cols.size()) return false;   // flat schema only
+  for (size_t c = 0; c < cols.size(); c++) {
+    if (cols[c].is_filename || cols[c].is_hive) return false;
+    const auto& wc = w->buffer->columns[static_cast<size_t>(w->buffer->roots[c])];
+    if (!wc.children.empty()) return false;
+    if (wc.enc_kind != MI_K_ENC_COPY && wc.enc_kind != MI_K_ENC_DEC128 && wc.enc_kind != MI_K_ENC_BOOL && wc.enc_kind != MI_K_ENC_STR32) return false;
+  }
+  return true;
+}
+
+void PumpScanFused(mi_writer* w, ArrowScan* scan, const BatchRef& first, int64_t rows_per_group, int64_t* rows_out) {
+  Context* ctx = w->ctx;
+  ArrowStreamWriter& out = *w->writer;
+  ctx->Bind();
+  constexpr int kEncoders = 4;
+  std::vector<FusedEncoder> enc(kEncoders);
+  hipStream_t enc_stream = nullptr, back_stream = nullptr;
+  MI_HIP_CHECK(hipStreamCreateWithFlags(&enc_stream, hipStreamNonBlocking));
+  MI_HIP_CHECK(hipStreamCreateWithFlags(&back_stream, hipStreamNonBlocking));
+  for (auto& e : enc) {
+    e.plan = std::make_unique<Plan>(ctx);
+    MI_HIP_CHECK(hipEventCreateWithFlags(&e.encoded, hipEventDisableTiming));
+    MI_HIP_CHECK(hipEventCreateWithFlags(&e.done, hipEventDisableTiming));
+    MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e.h_status), 64, hipHostMallocDefault));
+  }
+  auto local = MakeLocal(w);             // host path of row groups that straddle record batches
+  ChunkStorage storage;
+  mi_data_chunk chunk;
+
+  struct WriteJob {
+    int enc = -1;                        // fused encoder; -1: `header` / `body` are ready (host-serialized row group)
+    int tok = -1;                        // batch token whose open count drops once the GPU has read it
+    std::vector<uint8_t> header;
+    const uint8_t* body = nullptr;
+    size_t body_size = 0;
+  };
+  struct Held { BatchRef ref; int open = 0; bool fully_cut = false; bool released = false; };
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<WriteJob> jobs;
+  std::vector<Held> held;
+  std::deque<int> to_release;
+  bool stop = false;
+  int64_t jobs_written = 0, jobs_queued = 0;
+  std::exception_ptr error;
+  const size_t n_cols = scan->NumOutputColumns();
+
+  std::thread io([&] {
+    try {
+      ctx->Bind();
+      while (true) {
+        WriteJob job;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return stop || error || !jobs.empty(); });
+          if (error || jobs.empty()) return;
+          job = std::move(jobs.front());
+          jobs.pop_front();
+        }
+        if (job.enc >= 0) {
+          FusedEncoder& e = enc[static_cast<size_t>(job.enc)];
+          MI_HIP_CHECK(hipEventSynchronize(e.done));
+          {
+            std::lock_guard<std::mutex> lk(mu);   // the GPU is done with the scan slot
+            Held& h = held[static_cast<size_t>(job.tok)];
+            if (--h.open == 0 && h.fully_cut && !h.released) {
+              h.released = true;
+              to_release.push_back(job.tok);
+            }
+          }
+          cv.notify_all();
+          ThrowForStatus(e.h_status[0]);
+          const std::vector<int64_t> nulls = e.plan->MapNullCounts(e.h_nulls);
+          std::vector<std::pair<int64_t, int64_t>> nodes;
+          for (size_t c = 0; c < n_cols; c++) nodes.emplace_back(e.nrows, nulls[c]);
+          job.header = EncodeRecordBatchMessage(e.nrows, nodes, e.spans, e.body_size);
+          job.body = e.h_body;
+          job.body_size = static_cast<size_t>(e.body_size);
+        }
+        const int64_t at = out.ReserveRowGroup(job.header.size() + job.body_size);
+        out.WriteAt(at, job.header.data(), job.header.size());
+        out.WriteAt(at + static_cast<int64_t>(job.header.size()), job.body, job.body_size);
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          if (job.enc >= 0) enc[static_cast<size_t>(job.enc)].busy = false;
+          ++jobs_written;
+        }
+        cv.notify_all();
+      }
+    } catch (...) {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!error) error = std::current_exception();
+      cv.notify_all();
+    }
+  });
+
+  auto release_ready = [&](bool wait) {
+    std::unique_lock<std::mutex> lk(mu);
+    if (wait) cv.wait(lk, [&] { return error || !to_release.empty(); });
+    if (error) std::rethrow_exception(error);
+    while (!to_release.empty()) {
+      const int tok = to_release.front();
+      to_release.pop_front();
+      const BatchRef ref = held[static_cast<size_t>(tok)].ref;
+      lk.unlock();
+      scan->ReleaseBatch(ref);
+      lk.lock();
+    }
+  };
+  auto queue_job = [&](WriteJob&& job) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      jobs.push_back(std::move(job));
+      ++jobs_queued;
+    }
+    cv.notify_all();
+  };
+  // valid string bytes of rows [r0, r0 + m): the size of the Arrow data buffer the encoder will fill
+  auto payload_of = [](const DeviceColumnView& v, int64_t r0, int64_t m) -> int64_t {
+    auto off = [&](int64_t i) -> int64_t {
+      if (v.offset_width == 8) { int64_t x; std::memcpy(&x, v.h_offsets + i * 8, 8); return x; }
+      int32_t x; std::memcpy(&x, v.h_offsets + i * 4, 4); return x;
+    };
+    if (v.null_count == 0 || !v.h_validity) return off(r0 + m) - off(r0);
+    int64_t total = 0;
+    for (int64_t i = r0; i < r0 + m; i++)
+      if ((v.h_validity[i >> 3] >> (i & 7)) & 1) total += off(i + 1) - off(i);
+    return total;
+  };
+  // can rows of this batch be encoded where they lie?
+  auto views_of = [&](const BatchRef& ref, std::vector<DeviceColumnView>* views) -> bool {
+    views->resize(n_cols);
+    for (size_t c = 0; c < n_cols; c++) {
+      DeviceColumnView& v = (*views)[c];
+      scan->DeviceColumn(ref, c, &v);
+      if (!v.flat) return false;
+      const auto& wc = w->buffer->columns[static_cast<size_t>(w->buffer->roots[c])];
+      const bool is_string = v.kind == MI_K_STR32 || v.kind == MI_K_STR64;
+      if (wc.enc_kind == MI_K_ENC_STR32) {
+        if (!is_string) return false;
+      } else if (is_string || v.width != wc.width || v.kind == MI_K_STRVIEW || v.kind == MI_K_FIXED_BINARY) {
+        return false;
+      }
+    }
+    return true;
+  };
+  auto encode_on_gpu = [&](int tok, const std::vector<DeviceColumnView>& views, int64_t r0, int64_t m) {
+    // a free encoder (at most kEncoders row groups between the kernels and the file)
+    int ei = -1;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] {
+        if (error) return true;
+        for (int i = 0; i < kEncoders; i++)
+          if (!enc[static_cast<size_t>(i)].busy) { ei = i; return true; }
+        return false;
+      });
+      if (error) std::rethrow_exception(error);
+      enc[static_cast<size_t>(ei)].busy = true;
+      held[static_cast<size_t>(tok)].open++;
+    }
+    FusedEncoder& e = enc[static_cast<size_t>(ei)];
+    e.nrows = m;
+    e.spans.clear();
+    e.first_span.assign(n_cols, 0);
+    size_t body_off = 0;
+    auto add_span = [&](int64_t len) {
+      e.spans.push_back(mi_buffer_span{static_cast<int64_t>(body_off), len});
+      body_off += RoundUp(static_cast<size_t>(len), kBufferAlign);
+    };
+    std::vector<int64_t> payload(n_cols, 0);
+    for (size_t c = 0; c < n_cols; c++) {
+      const auto& wc = w->buffer->columns[static_cast<size_t>(w->buffer->roots[c])];
+      e.first_span[c] = static_cast<int32_t>(e.spans.size());
+      add_span((m + 7) / 8);
+      switch (wc.enc_kind) {
+        case MI_K_ENC_COPY: add_span(m * wc.param); break;
+        case MI_K_ENC_DEC128: add_span(m * 16); break;
+        case MI_K_ENC_BOOL: add_span((m + 7) / 8); break;
+        default: {
+          payload[c] = payload_of(views[c], r0, m);
+          if (payload[c] > 0x7FFFFFFFll && !wc.large_offsets)
+            throw InvalidInputException(
+                "Arrow Appender: The maximum total string size for regular string buffers is 2147483647 but the offset of " +
+                std::to_string(payload[c]) + " exceeds this.\n* SET arrow_large_buffer_size=true to use large string buffers");
+          add_span((m + 1) * (wc.large_offsets ? 8 : 4));
+          add_span(payload[c]);
+        }
+      }
+    }
+    e.body_size = static_cast<int64_t>(body_off);
+    GrowDevice(&e.d_body, &e.d_cap, body_off + 256);
+    { size_t zero = 0; GrowPinned(&e.h_body, &e.h_cap, body_off + 256, zero); }
+    MI_HIP_CHECK(hipMemsetAsync(e.d_body, 0, body_off, enc_stream));
+    std::vector<mi_col_task> tasks(n_cols);
+    for (size_t c = 0; c < n_cols; c++) {
+      const auto& wc = w->buffer->columns[static_cast<size_t>(w->buffer->roots[c])];
+      const DeviceColumnView& v = views[c];
+      const size_t sp = static_cast<size_t>(e.first_span[c]);
+      mi_col_task& t = tasks[c];
+      std::memset(&t, 0, sizeof(t));
+      t.nrows = m;
+      t.kind = wc.enc_kind;
+      t.param = wc.param;
+      t.flags = wc.large_offsets ? 1 : 0;
+      t.buf1 = v.d_data + static_cast<size_t>(r0) * static_cast<size_t>(v.width);
+      t.validity = v.d_validity ? v.d_validity + static_cast<size_t>(r0 / 64) * 8 : nullptr;   // r0 is a multiple of 2048
+      t.out_validity = e.d_body + e.spans[sp].offset;
+      t.out_data = e.d_body + e.spans[sp + 1].offset;
+      if (wc.enc_kind == MI_K_ENC_STR32) {
+        t.buf2 = v.d_heap;
+        t.buf2_len = payload[c];
+        t.ptr_base = v.ptr_base;
+        t.out_aux = e.d_body + e.spans[sp + 2].offset;
+      }
+    }
+    e.plan->Set(tasks.data(), static_cast<int32_t>(tasks.size()), enc_stream);
+    MI_HIP_CHECK(hipMemsetAsync(e.plan->d_status, 0, sizeof(uint32_t), enc_stream));
+    if (e.plan->n_null_counts) MI_HIP_CHECK(hipMemsetAsync(e.plan->d_null_counts, 0, static_cast<size_t>(e.plan->n_null_counts) * 8, enc_stream));
+    e.plan->Launch(enc_stream);
+    MI_HIP_CHECK(hipEventRecord(e.encoded, enc_stream));
+    MI_HIP_CHECK(hipStreamWaitEvent(back_stream, e.encoded, 0));
+    MI_HIP_CHECK(hipMemcpyAsync(e.h_body, e.d_body, body_off, hipMemcpyDeviceToHost, back_stream));
+    { size_t zero = 0; GrowPinned(&e.h_nulls, &e.h_nulls_cap, static_cast<size_t>(e.plan->n_null_counts + 1) * 8, zero); }
+    if (e.plan->n_null_counts)
+      MI_HIP_CHECK(hipMemcpyAsync(e.h_nulls, e.plan->d_null_counts, static_cast<size_t>(e.plan->n_null_counts) * 8, hipMemcpyDeviceToHost, back_stream));
+    MI_HIP_CHECK(hipMemcpyAsync(e.h_status, e.plan->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, back_stream));
+    MI_HIP_CHECK(hipEventRecord(e.done, back_stream));
+    WriteJob job;
+    job.enc = ei;
+    job.tok = tok;
+    queue_job(std::move(job));
+  };
+  // the host path: serialise the rows buffered in `local` and hand them to the I/O thread; its body buffer is reused by
+  // the next host-path row group, so wait until it is written (row groups that straddle batches are the exception)
+  auto flush_host = [&] {
+    if (local->serializer->Serialize(*local->buffer) == 0) {
+      local->buffer->Reset();
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return error || jobs_written == jobs_queued; });
+      out.CountEmptyFlush();
+      return;
+    }
+    local->buffer->Reset();
+    WriteJob job;
+    job.header = local->serializer->GetHeader();
+    job.body = local->serializer->GetBody();
+    job.body_size = static_cast<size_t>(local->serializer->GetBodySize());
+    queue_job(std::move(job));
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return error || jobs_written == jobs_queued; });
+    if (error) std::rethrow_exception(error);
+  };
+
+  int64_t rows = 0;
+  std::exception_ptr pump_error;
+  try {
+    const int64_t group_rows = (rows_per_group + MI_VECTOR_SIZE - 1) / MI_VECTOR_SIZE * MI_VECTOR_SIZE;
+    int64_t carry = 0;                      // rows buffered on the host path
+    bool have_first = true;
+    std::vector<DeviceColumnView> views;
+    while (true) {
+      release_ready(false);
+      BatchRef ref;
+      if (have_first) {
+        ref = first;
+        have_first = false;
+      } else if (!scan->AcquireBatch(&ref)) {
+        if (scan->Exhausted()) break;
+        release_ready(true);
+        continue;
+      }
+      rows += ref.chunk_rows;
+      int tok;
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        held.push_back(Held{ref, 0, false, false});
+        tok = static_cast<int>(held.size() - 1);
+      }
+      const int64_t n = ref.chunk_rows;
+      const bool on_gpu = n > 0 && views_of(ref, &views);
+      int64_t r = 0;
+      while (r < n) {
+        if (carry == 0 && on_gpu && n - r >= rows_per_group) {
+          const int64_t m = std::min(group_rows, n - r);
+          encode_on_gpu(tok, views, r, m);
+          r += m;
+          continue;
+        }
+        // host path, chunk by chunk until the row group is full or the batch ends
+        scan->EnsureHostVectors(ref);
+        const int32_t wi = static_cast<int32_t>(r / MI_VECTOR_SIZE);
+        scan->BuildChunk(ref, wi, &storage, &chunk);
+        local->buffer->Append(chunk);
+        carry += chunk.size;
+        r += chunk.size;
+        if (carry >= rows_per_group) {
+          flush_host();
+          carry = 0;
+        }
+      }
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        Held& h = held[static_cast<size_t>(tok)];
+        h.fully_cut = true;
+        if (h.open == 0 && !h.released) {
+          h.released = true;
+          to_release.push_back(tok);
+        }
+      }
+    }
+    if (carry > 0) flush_host();   // the tail row group (ArrowWriteCombine)
+  } catch (...) {
+    pump_error = std::current_exception();
+    std::lock_guard<std::mutex> lk(mu);
+    if (!error) error = pump_error;
+  }
+  {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return error || jobs_written == jobs_queued; });
+    stop = true;
+  }
+  cv.notify_all();
+  io.join();
+  (void)hipStreamSynchronize(enc_stream);
+  (void)hipStreamSynchronize(back_stream);
+  for (size_t tok = 0; tok < held.size(); tok++)
+    if (!held[tok].released || std::find(to_release.begin(), to_release.end(), static_cast<int>(tok)) != to_release.end()) scan->ReleaseBatch(held[tok].ref);
+  for (auto& e : enc) {
+    e.plan.reset();
+    if (e.d_body) (void)hipFree(e.d_body);
+    if (e.h_body) (void)hipHostFree(e.h_body);
+    if (e.h_nulls) (void)hipHostFree(e.h_nulls);
+    if (e.h_status) (void)hipHostFree(e.h_status);
+    if (e.encoded) (void)hipEventDestroy(e.encoded);
+    if (e.done) (void)hipEventDestroy(e.done);
+  }
+  (void)hipStreamDestroy(enc_stream);
+  (void)hipStreamDestroy(back_stream);
+  if (error) std::rethrow_exception(error);
+  if (rows_out) *rows_out = rows;
+}
 }  // namespace
 
 extern "C" {
@@ -1030,10 +1404,36 @@ int mi_writer_sink_scan(mi_writer* w, mi_scan* scan, int64_t* rows) {
   if (!w || !w->writer || !scan) return WrapC([] { throw InvalidInputException("mi_writer_sink_scan: bad argument"); });
   ArrowScan* single = SingleScanOf(scan);
   const int threads = SinkThreads();
-  if (single && single->HostConsumer() && threads > 1 && w->buffer->Count() == 0) {
+  if (single && single->HostConsumer() && w->buffer->Count() == 0 && !single->Initialized()) single->Init({});
+  if (single && single->HostConsumer() && w->buffer->Count() == 0 && (threads > 1 || FusedSinkPossible(w, single))) {
     return WrapC([&] {
-      if (!single->Initialized()) single->Init({});
-      PumpScanParallel(w, single, threads, rows);
+      // rows after which the one-thread sink flushes (row_group_size, or row_group_size_bytes at the staged row width)
+      int64_t row_bytes = 0;
+      for (auto& c : single->OutputColumns()) {
+        int32_t kind, wd, nb;
+        int64_t param;
+        row_bytes += (!c.is_filename && !c.is_hive && c.field.Plan(&kind, &param, &wd, &nb)) ? wd : 16;
+      }
+      row_bytes = std::max<int64_t>(1, row_bytes);
+      const int64_t group = std::max<int64_t>(1, std::min(w->opts.row_group_size, (w->opts.row_group_size_bytes + row_bytes - 1) / row_bytes));
+      // record batches at least one row group long are encoded where they lie in HBM; smaller ones go through the sink
+      // threads.  Decided on the first batch (the scan keeps its vectors on the device until then).
+      const bool fused = FusedSinkPossible(w, single);
+      single->EnsurePipelineDepth(std::max(1, threads) + 4);
+      single->KeepVectorsOnDevice(fused);
+      BatchRef first;
+      if (!single->AcquireBatch(&first)) {
+        single->KeepVectorsOnDevice(false);
+        if (rows) *rows = 0;
+        return;
+      }
+      if (fused && first.chunk_rows >= group) {
+        struct Restore { ArrowScan* s; ~Restore() { s->KeepVectorsOnDevice(false); } } restore{single};
+        PumpScanFused(w, single, first, group, rows);
+        return;
+      }
+      single->KeepVectorsOnDevice(false);
+      PumpScanParallel(w, single, std::max(1, threads), rows, &first);
     });
   }
   int64_t n = 0;

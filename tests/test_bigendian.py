@@ -61,9 +61,10 @@ def test_host_reader_swaps_big_endian_bodies(tool, golden_dir, tmp_path, rel):
 def test_scan_of_a_big_endian_stream_equals_the_little_endian_scan(tool, golden_dir, tmp_path, rel):
     be = _big(tool, golden_dir, rel, tmp_path)
     con = da.Connection(0)
-    want = con.read_arrow(os.path.join(golden_dir, rel), accept_dictionaries=True).fetch_columns()
-    assert con.read_arrow(be, accept_dictionaries=True).fetch_columns() == want
+    want = repr(con.read_arrow(os.path.join(golden_dir, rel), accept_dictionaries=True).fetch_columns())   # repr: NaN == NaN
+    assert repr(con.read_arrow(be, accept_dictionaries=True).fetch_columns()) == want
     data = np.fromfile(be, np.uint8)
-    assert con.scan_arrow_ipc([data], accept_dictionaries=True).fetch_columns() == want
+    assert repr(con.scan_arrow_ipc([data], accept_dictionaries=True).fetch_columns()) == want
     first = con.read_arrow(be, accept_dictionaries=True).columns[0]
-    assert con.read_arrow(be, accept_dictionaries=True).project([first]).fetch_columns() == [want[0]]
+    want_first = repr(con.read_arrow(os.path.join(golden_dir, rel), accept_dictionaries=True).project([first]).fetch_columns())
+    assert repr(con.read_arrow(be, accept_dictionaries=True).project([first]).fetch_columns()) == want_first

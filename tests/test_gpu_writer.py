@@ -515,17 +515,22 @@ def test_parallel_copy_pump_writes_the_one_thread_file(con, tmp_path, monkeypatc
                   "d": pa.array([__import__("decimal").Decimal(int(v)) for v in rng.integers(0, 1000, n)], pa.decimal128(15, 0)),
                   "s": pa.array(["str %d %s" % (i, "y" * int(k)) for i, k in enumerate(rng.integers(0, 40, n))], mask=rng.random(n) < 0.1),
                   "f": pa.array(rng.random(n) < 0.5, mask=rng.random(n) < 0.2)})
-    for chunk, rgs in ((9000, 9000), (25000, 8192), (3000, 10000), (7001, 5000)):
+    for chunk, rgs in ((9000, 9000), (25000, 8192), (3000, 10000), (7001, 5000), (70000, 20000)):
         src = str(tmp_path / ("src_%d.arrows" % chunk))
         with ipc.new_stream(src, t.schema) as w:
             w.write_table(t, max_chunksize=chunk)
         outs = []
-        for threads in ("1", "4"):
+        # the one-thread sink; four sink threads; the fused pump (record batches encoded where they lie in HBM)
+        for threads, fused in (("1", False), ("4", False), ("4", True)):
             monkeypatch.setenv("MI_WRITER_THREADS", threads)
-            out = str(tmp_path / ("out_%d_%s.arrows" % (chunk, threads)))
+            if fused:
+                monkeypatch.delenv("MI_WRITER_NO_FUSED", raising=False)
+            else:
+                monkeypatch.setenv("MI_WRITER_NO_FUSED", "1")
+            out = str(tmp_path / ("out_%d_%s_%d.arrows" % (chunk, threads, fused)))
             con.copy_to(con.read_arrow(src), out, row_group_size=rgs)
             outs.append(open(out, "rb").read())
-        assert outs[0] == outs[1], (chunk, rgs)
+        assert outs[0] == outs[1] and outs[0] == outs[2], (chunk, rgs)
         got = ipc.open_stream(pa.BufferReader(outs[1])).read_all()
         assert got.equals(t), (chunk, rgs)
         sizes = [b.num_rows for b in ipc.open_stream(pa.BufferReader(outs[1]))]

@@ -33,9 +33,17 @@ def main():
         os.close(fd)
         os.unlink(opath)
         out["raw_tmpfs_write_one_thread"] = {"GBps": 200 * len(piece) / dt / 1e9, "seconds_for_this_table": buf.size / (200 * len(piece) / dt)}
+        legs = [(opath, "fused_file", 0), ("/dev/null", "fused_null_sink", 0)]
         for target, tag in ((opath, "file"), ("/dev/null", "null_sink")):
-            for threads in [int(x) for x in args.threads.split(",")]:
-                os.environ["MI_WRITER_THREADS"] = str(threads)
+            legs += [(target, tag, t) for t in [int(x) for x in args.threads.split(",")]]
+        for target, tag, threads in legs:
+            for _once in (0,):
+                # threads 0: the fused pump (record batches encoded where the scan decoded them); else the sink-thread pump
+                if threads:
+                    os.environ["MI_WRITER_THREADS"] = str(threads)
+                    os.environ["MI_WRITER_NO_FUSED"] = "1"
+                else:
+                    os.environ.pop("MI_WRITER_NO_FUSED", None)
                 best = None
                 for _ in range(2):
                     if target == opath and os.path.exists(opath):
@@ -44,7 +52,7 @@ def main():
                     con.copy_to(con.read_arrow(path), target, row_group_size=122880)
                     dt = time.perf_counter() - t0
                     best = dt if best is None else min(best, dt)
-                out["%s_threads_%d" % (tag, threads)] = {"seconds": best, "rows_per_s": info["n_rows"] / best, "GBps_out": buf.size / best / 1e9}
+                out[("%s_threads_%d" % (tag, threads)) if threads else tag] = {"seconds": best, "rows_per_s": info["n_rows"] / best, "GBps_out": buf.size / best / 1e9}
                 print("%s threads %d: %.3f s" % (tag, threads, best), file=sys.stderr, flush=True)
     finally:
         for p in (path, opath):
