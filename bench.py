@@ -295,6 +295,22 @@ def main():
                 assert rows_all == info["n_rows"], (rows_all, info["n_rows"])
                 legs[leg] = {"seconds": best, "rows_per_s": rows_all / best, "rows": rows_all, "selected": sel_all,
                              "file_GBps": sum(os.path.getsize(p) for p in paths) / best / 1e9}
+            if world == 1:
+                # BASELINE config 4 through the operator: COPY (FROM read_arrow(files)) TO 'out.arrows' (row_group_size 122880);
+                # decode and encode both on the GPU, only the finished IPC bodies travel back (mi_writer_sink_scan)
+                opath = os.path.join(d, "copy_out.arrows")
+                for target, leg in ((opath, "config4_copy_to_file"), ("/dev/null", "config4_copy_to_null_sink")):
+                    best = None
+                    for _ in range(2):
+                        if target == opath and os.path.exists(opath):
+                            os.remove(opath)
+                        t1 = time.perf_counter()
+                        con.copy_to(con.read_arrow(paths), target, row_group_size=122880)
+                        dt = time.perf_counter() - t1
+                        best = dt if best is None else min(best, dt)
+                    legs[leg] = {"seconds": best, "rows_per_s": info["n_rows"] / best, "GBps_out": float(buf.size) / best / 1e9}
+                if os.path.exists(opath):
+                    os.remove(opath)
             con.close()
             operator_path = dict(legs, scaling="strong", files=n_files, table="TPC-H SF%g lineitem (%d rows) in %s" % (args.sf, info["n_rows"], args.shm_dir),
                                  rows_per_s=legs["full_scan_host_consumer"]["rows_per_s"],

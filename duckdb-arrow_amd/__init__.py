@@ -521,6 +521,12 @@ class Relation:
     def progress(self):
         return _ffi.lib().mi_scan_progress(self._h)
 
+    def stats(self):
+        """mi_scan_get_stats: record batches submitted, LZ4 bodies decompressed in HBM, bytes over PCIe, bytes decompressed."""
+        st = _ffi.ScanStats()
+        _ffi.check(_ffi.lib().mi_scan_get_stats(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k in ("record_batches", "lz4_batches_on_device", "h2d_bytes", "decompressed_bytes")}
+
     def close(self):
         if self._h:
             _ffi.lib().mi_scan_close(self._h)

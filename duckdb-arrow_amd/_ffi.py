@@ -157,6 +157,11 @@ class WriteOptions(C.Structure):
                 ("arrow_large_buffer_size", C.c_int32), ("_reserved", C.c_int32)]
 
 
+class ScanStats(C.Structure):
+    _fields_ = [("record_batches", C.c_int64), ("lz4_batches_on_device", C.c_int64), ("h2d_bytes", C.c_int64),
+                ("decompressed_bytes", C.c_int64), ("_reserved", C.c_int64 * 4)]
+
+
 class SynthOptions(C.Structure):
     _fields_ = [("scale_factor", C.c_double), ("seed", C.c_uint64), ("rows_per_batch", C.c_int64),
                 ("n_rows", C.c_int64), ("first_row", C.c_int64), ("with_validity", C.c_int32), ("n_threads", C.c_int32)]
@@ -219,6 +224,7 @@ SIGNATURES = {
     "mi_scan_count": (C.c_int, [P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "mi_scan_sum_product": (C.c_int, [P, C.c_char_p, C.c_char_p, C.POINTER(RangeFilter), C.c_int32, C.POINTER(SumProductResult)]),
     "mi_scan_progress": (C.c_double, [P]),
+    "mi_scan_get_stats": (C.c_int, [P, P]),
     "mi_write_options_init": (C.c_int, [C.POINTER(WriteOptions)]),
     "mi_write_options_set": (C.c_int, [C.POINTER(WriteOptions), C.c_char_p, C.c_char_p]),
     "mi_write_options_add_kv": (C.c_int, [C.POINTER(WriteOptions), C.c_char_p, C.c_char_p, C.c_int32]),

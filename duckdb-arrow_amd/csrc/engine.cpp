@@ -447,6 +447,8 @@ void ThrowForStatus(uint32_t bits) {
   if (bits & MI_ST_INDEX_RANGE) throw ConversionException("DuckDB only supports indices that fit on an uint32");
   if (bits & MI_ST_DICT_INDEX) throw InternalException("Arrow IPC validation failed: dictionary index out of range");
   if (bits & MI_ST_DECIMAL_RANGE) throw ConversionException("Decimal value does not fit the physical type of its declared precision");
+  if (bits & MI_ST_DECOMPRESS)
+    throw IOException("LZ4_FRAME compressed buffer is malformed or does not decompress to its declared size (Expected decompressed size mismatch)");
   if (bits & MI_ST_INTERNAL) throw InternalException("a kernel gave up waiting for another workgroup (bounded spin exceeded)");
   if (bits & MI_ST_OFFSET_OVERFLOW)
     throw InvalidInputException(

@@ -184,9 +184,16 @@ bool IPCStreamReader::GetNextBatch(DecodedBatch* out, bool accept_dictionaries, 
     out->body_file_offset = cur_body_offset;
     return true;
   }
+  cur_deferred.reset();
   if (meta.compression != -1 && cur_size > 0) DecompressBody(&meta);
   if (base_schema.endianness == 1 && cur_size > 0) SwapBodyEndianness(meta);
   SliceBatch(meta, out);
+  if (cur_deferred) {
+    out->deferred = cur_deferred;
+    out->body = nullptr;
+    out->compression = 0;
+    cur_deferred.reset();
+  }
   return true;
 }
 
@@ -392,6 +399,54 @@ void Lz4DecompressFrame(const Lz4Api& z, uint8_t* dst, int64_t n, const uint8_t*
 static void SubtreeBufferBounds(const ArrowField& f, const RecordBatchMeta& meta, size_t* node, size_t* variadic, bool value_only,
                                 std::vector<int64_t>* out);
 
+// list / map columns: the planner samples their offsets on the host (child windows of every chunk), so their record batches
+// need the decompressed body in host memory
+static bool HasListField(const ArrowField& f) {
+  if (f.type == MI_AT_LIST || f.type == MI_AT_LARGE_LIST || f.type == MI_AT_MAP) return true;
+  for (auto& c : f.children)
+    if (HasListField(c)) return true;
+  return false;
+}
+
+// Walks one LZ4 frame (lz4_Frame_format.md: magic, FLG, BD, [content size], [dict id], HC, blocks, end mark) without
+// touching the block data: appends its blocks to `blocks`.  false = something the GPU path does not take (skippable or
+// legacy frames, a dictionary id, a damaged header): the caller decompresses the record batch on the host instead, which
+// also produces the reference's error text for damaged input.
+static bool WalkLz4Frame(const uint8_t* body, int64_t frame_off, int64_t frame_len, uint32_t buffer_index,
+                         DeferredLz4Body::Buffer* buf, std::vector<DeferredLz4Body::Block>* blocks) {
+  const uint8_t* p = body + frame_off;
+  int64_t at = 0;
+  auto u32 = [&](int64_t o) { uint32_t v; std::memcpy(&v, p + o, 4); return v; };
+  if (frame_len < 7 || u32(0) != 0x184D2204u) return false;
+  const uint8_t flg = p[4], bd = p[5];
+  if ((flg >> 6) != 1 || (flg & 0x02) || (flg & 0x01)) return false;   // version 01; reserved bit; dictionary id
+  const bool block_checksum = (flg & 0x10) != 0, content_size = (flg & 0x08) != 0, content_checksum = (flg & 0x04) != 0;
+  const int bsid = (bd >> 4) & 7;
+  if (bsid < 4 || (bd & 0x8F)) return false;
+  buf->block_max = 1u << (8 + 2 * bsid);   // 4: 64 KiB, 5: 256 KiB, 6: 1 MiB, 7: 4 MiB
+  at = 6 + (content_size ? 8 : 0) + 1;     // + header checksum
+  if (at > frame_len) return false;
+  buf->first_block = static_cast<uint32_t>(blocks->size());
+  while (true) {
+    if (at + 4 > frame_len) return false;
+    const uint32_t word = u32(at);
+    at += 4;
+    if (word == 0) break;   // end mark
+    const uint32_t size = word & 0x7FFFFFFFu;
+    if (size > buf->block_max || at + size + (block_checksum ? 4 : 0) > frame_len) return false;
+    DeferredLz4Body::Block b;
+    b.comp_off = static_cast<uint32_t>(frame_off + at);
+    b.comp_size = size;
+    b.buffer = buffer_index;
+    b.stored = word >> 31;
+    blocks->push_back(b);
+    at += size + (block_checksum ? 4 : 0);
+  }
+  if (content_checksum && at + 4 > frame_len) return false;
+  buf->n_blocks = static_cast<uint32_t>(blocks->size()) - buf->first_block;
+  return true;
+}
+
 void IPCStreamReader::DecompressBody(RecordBatchMeta* meta) {
   if (meta->compression != 0 && meta->compression != 1) throw IOException("Unknown BodyCompression codec " + std::to_string(meta->compression));
   const bool lz4 = meta->compression == 0;
@@ -449,6 +504,43 @@ void IPCStreamReader::DecompressBody(RecordBatchMeta* meta) {
     }
     ulen[i] = n;
     total += (n + 63) & ~static_cast<int64_t>(63);
+  }
+  // GPU consumers (SetDeferLz4): keep the body compressed and hand out the frame / block tables instead
+  bool deferrable = lz4 && defer_lz4 && !meta->is_dictionary && base_schema.endianness == 0 && total < (int64_t(1) << 32) - 64 &&
+                    cur_size < (int64_t(1) << 32) - 64;
+  if (deferrable)
+    for (auto& f : (HasProjection() ? projected_schema.fields : base_schema.fields))
+      if (HasListField(f)) deferrable = false;
+  if (deferrable) {
+    auto d = std::make_shared<DeferredLz4Body>();
+    d->comp = cur_ptr;
+    d->comp_size = cur_size;
+    bool ok = true;
+    for (size_t i = 0; i < nbuf && ok; i++) {
+      const mi_buffer_span& b = meta->buffers[i];
+      if (b.length == 0 || ulen[i] == 0) continue;
+      DeferredLz4Body::Buffer f;
+      int64_t declared;
+      std::memcpy(&declared, cur_ptr + b.offset, 8);
+      f.raw = declared == -1;
+      f.comp_off = b.offset + 8;
+      f.comp_len = b.length - 8;
+      f.out_off = opos[i];
+      f.out_len = ulen[i];
+      if (!f.raw) ok = WalkLz4Frame(cur_ptr, f.comp_off, f.comp_len, static_cast<uint32_t>(d->buffers.size()), &f, &d->blocks);
+      d->buffers.push_back(f);
+    }
+    if (ok) {
+      for (size_t i = 0; i < nbuf; i++) {
+        mi_buffer_span& b = meta->buffers[i];
+        b.offset = opos[i];
+        b.length = (b.length == 0) ? 0 : ulen[i];
+      }
+      cur_deferred = d;
+      cur_size = total;          // SliceBatch checks the spans against the decompressed layout; it never reads the body
+      meta->compression = -1;
+      return;
+    }
   }
   uint8_t* out = nullptr;
   std::shared_ptr<void> owner = body_allocator ? body_allocator(static_cast<size_t>(total + 64), message.type, &out)

@@ -53,6 +53,24 @@ struct DecodedNode {
   std::vector<int32_t> children;         // indices into DecodedBatch::nodes
 };
 
+//! A record-batch body whose LZ4_FRAME buffers are still compressed (IPCStreamReader::SetDeferLz4): the frames were walked
+//! on the host (frame header, block headers), the bytes are decompressed in HBM by the K8 kernels (kernels_lz4.hip).
+struct DeferredLz4Body {
+  struct Buffer {
+    int64_t comp_off = 0, comp_len = 0;   // raw: the bytes themselves; else the frame, inside the compressed body
+    int64_t out_off = 0, out_len = 0;     // place in the decompressed body
+    bool raw = false;                     // stored uncompressed (length prefix -1)
+    uint32_t first_block = 0, n_blocks = 0, block_max = 0;
+  };
+  struct Block {
+    uint32_t comp_off = 0, comp_size = 0, buffer = 0, stored = 0;
+  };
+  const uint8_t* comp = nullptr;          // the compressed body as it was read (kept alive by DecodedBatch::owner)
+  int64_t comp_size = 0;
+  std::vector<Buffer> buffers;            // the needed, non-empty buffers of the message
+  std::vector<Block> blocks;              // every LZ4 block of every non-raw buffer, buffer by buffer
+};
+
 //! What GetNextBatch produces: the buffers of every (projected) top-level column of one message.
 struct DecodedBatch {
   int64_t length = 0;
@@ -71,6 +89,8 @@ struct DecodedBatch {
   std::vector<int32_t> column_node;      // per output column: its node
   //! Keeps the body alive (file reader: shared ownership like shared_ptr<AllocatedData>, base_stream_reader.cpp:286-294)
   std::shared_ptr<void> owner;
+  //! set: `body` is NULL, body_size and every span describe the DECOMPRESSED layout, the bytes are still compressed
+  std::shared_ptr<const DeferredLz4Body> deferred;
 };
 
 struct BatchIndexEntry {
@@ -121,6 +141,10 @@ class IPCStreamReader {
   using BodyAllocator = std::function<std::shared_ptr<void>(size_t bytes, MessageType type, uint8_t** ptr)>;
   void SetBodyAllocator(BodyAllocator a) { body_allocator = std::move(a); }
 
+  //! LZ4_FRAME record batches (not dictionary batches, not big-endian streams) are handed out still compressed, with the
+  //! frame / block tables a GPU decompressor needs (DecodedBatch::deferred); everything else is decompressed here as before
+  void SetDeferLz4(bool on) { defer_lz4 = on; }
+
   static int64_t CountFields(const ArrowField& field) { return field.CountFields(); }
   static constexpr uint32_t kContinuationToken = 0xFFFFFFFF;
 
@@ -141,6 +165,8 @@ class IPCStreamReader {
   //! Replaces cur_ptr/cur_size with the decompressed body and rewrites meta->buffers (ZSTD, per buffer; the CPU step the
   //! reference performs in DuckDBDecompressZstd, base_stream_reader.cpp:11-32)
   void DecompressBody(RecordBatchMeta* meta);
+  bool defer_lz4 = false;
+  std::shared_ptr<const DeferredLz4Body> cur_deferred;   // set by DecompressBody when the current body stays compressed
   //! Big-endian stream: every multi-byte number of the body is swapped in place (after decompression), so the rest of the
   //! path sees little-endian buffers (what nanoarrow's decoder does for the reference, base_stream_reader.cpp:68-69)
   void SwapBodyEndianness(const RecordBatchMeta& meta);

@@ -56,6 +56,39 @@ struct AggSumProductArgs {
 };
 hipError_t LaunchAggSumProduct(const AggSumProductArgs& args, unsigned long long* d_acc, int num_cus, hipStream_t stream);
 
+// K8: LZ4_FRAME buffers of one record batch, decompressed in HBM (kernels_lz4.hip).  Offsets are 32-bit: a compressed or
+// decompressed body of 4 GiB or more takes the host decompressor.
+struct Lz4BlockDev {
+  uint32_t comp_off, comp_size;   // the block's bytes inside the compressed body
+  uint32_t buffer;                // index into Lz4Args::buffers
+  uint32_t stored;                // 1 = the block holds its bytes uncompressed
+  uint32_t seq_base, seq_cap;     // its slice of the sequence-descriptor scratch (comp_size / 3 + 2 entries)
+};
+struct Lz4BufferDev {
+  uint64_t out_off, out_len;      // where the buffer lies in the decompressed body, and its declared length
+  uint32_t first_block, n_blocks;
+  uint32_t block_max, _pad;       // the frame's maximum block size (BD byte)
+};
+struct Lz4Args {
+  const uint8_t* comp;            // compressed body (device)
+  uint8_t* out;                   // decompressed body (device), out_size bytes
+  uint64_t out_size;
+  uint64_t max_buffer_len;        // longest decompressed LZ4 buffer: bounds the number of resolve rounds
+  const Lz4BlockDev* blocks;
+  const Lz4BufferDev* buffers;
+  uint32_t n_blocks, n_buffers;
+  void* seq;                      // 16 bytes per sequence
+  uint32_t* seq_off;              // 4 bytes per sequence
+  uint32_t* link[2];              // 4 bytes per decompressed byte, twice; link[0] preset to 0xFF
+  uint32_t* block_out_size;       // per block
+  uint32_t* block_nseq;
+  uint64_t* block_out_base;
+  uint32_t* buffer_ok;            // per buffer
+  uint32_t* round_left;           // 40 words, zeroed
+  uint32_t* status;               // MI_ST_DECOMPRESS
+};
+hipError_t LaunchLz4Decompress(const Lz4Args& args, int num_cus, hipStream_t stream);
+
 // Late materialisation: tasks with mi_col_task.sel decode only the selected rows, compacted per window (kernels_gather.hip)
 // d_window_base: total_tiles words of scratch (first output row of every window, filled by the launch)
 hipError_t LaunchGather(const mi_col_task* d_tasks, const uint32_t* d_tile_begin, const uint32_t* d_tile_task, int32_t n_tasks,

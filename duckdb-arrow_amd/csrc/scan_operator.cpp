@@ -86,6 +86,12 @@ ArrowScan::~ArrowScan() {
     if (s.h_counts) (void)hipHostFree(s.h_counts);
     if (s.h_aux) (void)hipHostFree(s.h_aux);
     if (s.d_aux) (void)hipFree(s.d_aux);
+    if (s.lz4_stream) (void)hipStreamSynchronize(s.lz4_stream);
+    if (s.d_comp) (void)hipFree(s.d_comp);
+    if (s.d_lz4) (void)hipFree(s.d_lz4);
+    if (s.h_lz4) (void)hipHostFree(s.h_lz4);
+    if (s.lz4_stream) (void)hipStreamDestroy(s.lz4_stream);
+    if (s.lz4_done) (void)hipEventDestroy(s.lz4_done);
     if (s.h2d_done) (void)hipEventDestroy(s.h2d_done);
     if (s.compute_done) (void)hipEventDestroy(s.compute_done);
     if (s.d2h_done) (void)hipEventDestroy(s.d2h_done);
@@ -115,6 +121,9 @@ void ArrowScan::OpenSource(size_t i) {
     s.reader = std::make_unique<IPCFileStreamReader>(s.path);
     if (opts.hive_partitioning) s.hive = ParseHive(s.path);
   }
+  // LZ4_FRAME bodies stay compressed until they are in HBM when the consumer is on the device too (host consumers need the
+  // decompressed string payloads in host memory: their record batches are decompressed by the reader's host threads)
+  s.reader->SetDeferLz4(opts.host_decompress == 0 && opts.device_resident != 0);
   s.reader->GetBaseSchema();
   s.opened = true;
 }
@@ -294,7 +303,7 @@ void ArrowScan::InitSlot(Slot& s) {
   s.plan = std::make_unique<Plan>(ctx);
   s.gather_plan = std::make_unique<Plan>(ctx);
   MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.h_status), 64, hipHostMallocDefault));
-  s.h_status[0] = s.h_status[1] = 0;
+  s.h_status[0] = s.h_status[1] = s.h_status[2] = 0;
 }
 
 // More record batches in flight / held by the caller at once (the COPY pump hands whole batches to several sink threads).
@@ -567,6 +576,10 @@ void ArrowScan::EnqueueBatch(Slot& s) {
   UploadAux(s, s.planner.aux);
   s.planner.Rebase(0, s.d_out, s.d_aux);
 
+  stats.record_batches++;
+  if (b.deferred) {
+    EnqueueLz4(s);   // compressed body -> HBM -> K8 kernels -> d_in; ctx->stream waits for them
+  } else {
   // ---- H2D of the body on the copy stream: only what the kernels read (projected columns; with zero_copy_direct not even
   // all of those): merge the buffer ranges, gaps below 64 KiB are cheaper to copy than to split.  A full scan is one copy.
   std::vector<std::pair<int64_t, int64_t>> upload = s.planner.upload;
@@ -588,6 +601,7 @@ void ArrowScan::EnqueueBatch(Slot& s) {
       if (lo < 0) return;
       hi = std::min<int64_t>((hi + 63) & ~int64_t(63), b.body_size);
       MI_HIP_CHECK(hipMemcpyAsync(s.d_in + lo, b.body + lo, static_cast<size_t>(hi - lo), hipMemcpyHostToDevice, ctx->h2d_stream));
+      stats.h2d_bytes += hi - lo;
     };
     for (const auto& r : upload) {
       if (lo >= 0 && r.first <= hi + (64 << 10)) {
@@ -599,6 +613,7 @@ void ArrowScan::EnqueueBatch(Slot& s) {
       hi = r.first + r.second;
     }
     flush();
+  }
   }
   MI_HIP_CHECK(hipEventRecord(s.h2d_done, ctx->h2d_stream));
   MI_HIP_CHECK(hipStreamWaitEvent(ctx->stream, s.h2d_done, 0));
@@ -713,6 +728,130 @@ void ArrowScan::EnqueueBatch(Slot& s) {
   MI_HIP_CHECK(hipMemcpyAsync(&s.h_status[0], s.plan->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->d2h_stream));
   s.h_status[1] = 0;
   MI_HIP_CHECK(hipEventRecord(s.d2h_done, ctx->d2h_stream));
+}
+
+// K8: the record batch arrived with its LZ4_FRAME buffers still compressed (DecodedBatch::deferred).  The compressed bytes
+// cross PCIe, the frames' blocks (tables built by the host reader from the block headers) are expanded into s.d_in at the
+// decompressed layout every span of the batch already refers to.
+void ArrowScan::EnqueueLz4(Slot& s) {
+  const DecodedBatch& b = s.batch;
+  const DeferredLz4Body& d = *b.deferred;
+  if (!s.lz4_stream) {
+    MI_HIP_CHECK(hipStreamCreateWithFlags(&s.lz4_stream, hipStreamNonBlocking));
+    MI_HIP_CHECK(hipEventCreateWithFlags(&s.lz4_done, hipEventDisableTiming));
+  }
+  const size_t out_size = static_cast<size_t>(b.body_size);
+  const size_t nb = d.blocks.size(), nf = d.buffers.size();
+  // scratch layout
+  size_t at = 0;
+  auto take = [&](size_t bytes) { const size_t o = at; at += RoundUp(bytes + 16, 256); return o; };
+  const size_t o_blocks = take(nb * sizeof(device::Lz4BlockDev)), o_buffers = take(nf * sizeof(device::Lz4BufferDev));
+  const size_t tables_bytes = at;
+  uint64_t total_seq = 0, max_len = 0;
+  for (auto& blk : d.blocks) total_seq += blk.comp_size / 3 + 2;
+  const size_t o_bsize = take(nb * 4), o_bnseq = take(nb * 4), o_bbase = take(nb * 8), o_bufok = take(nf * 4), o_round = take(40 * 4),
+               o_status = take(4);
+  const size_t counters_end = at;
+  const size_t o_seq = take(static_cast<size_t>(total_seq) * 16), o_seqoff = take(static_cast<size_t>(total_seq) * 4);
+  const size_t o_link0 = take(out_size * 4), o_link1 = take(out_size * 4);
+  if (at > s.d_lz4_cap) {
+    if (s.d_lz4) MI_HIP_CHECK(hipFree(s.d_lz4));
+    s.d_lz4 = nullptr;
+    s.d_lz4_cap = RoundUp(std::max(at, s.d_lz4_cap + s.d_lz4_cap / 2), 1 << 20);
+    MI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s.d_lz4), s.d_lz4_cap));
+  }
+  if (static_cast<size_t>(d.comp_size) + 64 > s.d_comp_cap) {
+    if (s.d_comp) MI_HIP_CHECK(hipFree(s.d_comp));
+    s.d_comp = nullptr;
+    s.d_comp_cap = RoundUp(std::max(static_cast<size_t>(d.comp_size) + 64, s.d_comp_cap + s.d_comp_cap / 2), 1 << 16);
+    MI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s.d_comp), s.d_comp_cap));
+  }
+  if (tables_bytes > s.h_lz4_cap) {
+    if (s.h_lz4) MI_HIP_CHECK(hipHostFree(s.h_lz4));
+    s.h_lz4 = nullptr;
+    s.h_lz4_cap = RoundUp(std::max(tables_bytes, s.h_lz4_cap * 2), 1 << 16);
+    MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.h_lz4), s.h_lz4_cap, hipHostMallocDefault));
+  }
+  auto* hb = reinterpret_cast<device::Lz4BlockDev*>(s.h_lz4 + o_blocks);
+  auto* hf = reinterpret_cast<device::Lz4BufferDev*>(s.h_lz4 + o_buffers);
+  uint32_t seq_at = 0;
+  for (size_t i = 0; i < nb; i++) {
+    const auto& blk = d.blocks[i];
+    hb[i].comp_off = blk.comp_off;
+    hb[i].comp_size = blk.comp_size;
+    hb[i].buffer = blk.buffer;
+    hb[i].stored = blk.stored;
+    hb[i].seq_base = seq_at;
+    hb[i].seq_cap = blk.comp_size / 3 + 2;
+    seq_at += hb[i].seq_cap;
+  }
+  for (size_t i = 0; i < nf; i++) {
+    const auto& f = d.buffers[i];
+    hf[i].out_off = static_cast<uint64_t>(f.out_off);
+    hf[i].out_len = static_cast<uint64_t>(f.out_len);
+    hf[i].first_block = f.first_block;
+    hf[i].n_blocks = f.raw ? 0 : f.n_blocks;
+    hf[i].block_max = f.block_max;
+    hf[i]._pad = 0;
+    if (!f.raw) max_len = std::max<uint64_t>(max_len, static_cast<uint64_t>(f.out_len));
+  }
+  // H2D on the copy stream: the compressed bytes of the needed buffers (neighbours closer than 64 KiB travel as one copy)
+  std::vector<std::pair<int64_t, int64_t>> ranges;
+  for (auto& f : d.buffers) ranges.emplace_back(f.comp_off, f.comp_len);
+  std::sort(ranges.begin(), ranges.end());
+  int64_t lo = -1, hi = -1;
+  auto flush = [&]() {
+    if (lo < 0) return;
+    MI_HIP_CHECK(hipMemcpyAsync(s.d_comp + lo, d.comp + lo, static_cast<size_t>(hi - lo), hipMemcpyHostToDevice, ctx->h2d_stream));
+    stats.h2d_bytes += hi - lo;
+  };
+  stats.lz4_batches_on_device++;
+  stats.decompressed_bytes += b.body_size;
+  for (const auto& r : ranges) {
+    if (lo >= 0 && r.first <= hi + (64 << 10)) {
+      hi = std::max(hi, r.first + r.second);
+      continue;
+    }
+    flush();
+    lo = r.first;
+    hi = r.first + r.second;
+  }
+  flush();
+  MI_HIP_CHECK(hipMemcpyAsync(s.d_lz4, s.h_lz4, tables_bytes, hipMemcpyHostToDevice, ctx->h2d_stream));
+  MI_HIP_CHECK(hipEventRecord(s.h2d_done, ctx->h2d_stream));
+  hipStream_t q = s.lz4_stream;
+  MI_HIP_CHECK(hipStreamWaitEvent(q, s.h2d_done, 0));
+  MI_HIP_CHECK(hipMemsetAsync(s.d_in, 0, out_size, q));                                        // padding between buffers
+  MI_HIP_CHECK(hipMemsetAsync(s.d_lz4 + tables_bytes, 0, counters_end - tables_bytes, q));      // counters, status
+  MI_HIP_CHECK(hipMemsetAsync(s.d_lz4 + o_link0, 0xFF, out_size * 4, q));                       // every link "done"
+  for (auto& f : d.buffers)
+    if (f.raw && f.out_len > 0)
+      MI_HIP_CHECK(hipMemcpyAsync(s.d_in + f.out_off, s.d_comp + f.comp_off, static_cast<size_t>(f.out_len), hipMemcpyDeviceToDevice, q));
+  device::Lz4Args a;
+  std::memset(&a, 0, sizeof(a));
+  a.comp = s.d_comp;
+  a.out = s.d_in;
+  a.out_size = out_size;
+  a.max_buffer_len = max_len;
+  a.blocks = reinterpret_cast<const device::Lz4BlockDev*>(s.d_lz4 + o_blocks);
+  a.buffers = reinterpret_cast<const device::Lz4BufferDev*>(s.d_lz4 + o_buffers);
+  a.n_blocks = static_cast<uint32_t>(nb);
+  a.n_buffers = static_cast<uint32_t>(nf);
+  a.seq = s.d_lz4 + o_seq;
+  a.seq_off = reinterpret_cast<uint32_t*>(s.d_lz4 + o_seqoff);
+  a.link[0] = reinterpret_cast<uint32_t*>(s.d_lz4 + o_link0);
+  a.link[1] = reinterpret_cast<uint32_t*>(s.d_lz4 + o_link1);
+  a.block_out_size = reinterpret_cast<uint32_t*>(s.d_lz4 + o_bsize);
+  a.block_nseq = reinterpret_cast<uint32_t*>(s.d_lz4 + o_bnseq);
+  a.block_out_base = reinterpret_cast<uint64_t*>(s.d_lz4 + o_bbase);
+  a.buffer_ok = reinterpret_cast<uint32_t*>(s.d_lz4 + o_bufok);
+  a.round_left = reinterpret_cast<uint32_t*>(s.d_lz4 + o_round);
+  a.status = reinterpret_cast<uint32_t*>(s.d_lz4 + o_status);
+  MI_HIP_CHECK(device::LaunchLz4Decompress(a, ctx->num_cus, q));
+  MI_HIP_CHECK(hipMemcpyAsync(&s.h_status[2], a.status, sizeof(uint32_t), hipMemcpyDeviceToHost, q));
+  MI_HIP_CHECK(hipEventRecord(s.lz4_done, q));
+  MI_HIP_CHECK(hipStreamWaitEvent(ctx->stream, s.lz4_done, 0));
+  MI_HIP_CHECK(hipStreamWaitEvent(ctx->d2h_stream, s.lz4_done, 0));
 }
 
 // Stage B of a compacted batch: the filter's counts are on the host, so the projected columns get a dense layout sized
@@ -1052,7 +1191,7 @@ bool ArrowScan::AcquireBatch(BatchRef* out) {
   MI_HIP_CHECK(hipEventSynchronize(s.d2h_done));
   inflight.pop_front();
   try {
-    ThrowForStatus(s.h_status[0] | s.h_status[1]);
+    ThrowForStatus(s.h_status[0] | s.h_status[1] | s.h_status[2]);
   } catch (...) {
     s.busy = false;
     s.batch.owner.reset();
@@ -1090,7 +1229,7 @@ void ArrowScan::EnsureHostVectors(const BatchRef& ref) {
 void ArrowScan::DeviceColumn(const BatchRef& ref, size_t c, DeviceColumnView* out) const {
   *out = DeviceColumnView();
   const Slot& s = slots[static_cast<size_t>(ref.slot)];
-  if (s.compact || c >= out_columns.size() || out_columns[c].is_filename || out_columns[c].is_hive || s.col_root[c] < 0) return;
+  if (s.compact || s.batch.deferred || c >= out_columns.size() || out_columns[c].is_filename || out_columns[c].is_hive || s.col_root[c] < 0) return;
   const PlannedNode& pn = s.planner.nodes[static_cast<size_t>(s.col_root[c])];
   if (!pn.children.empty() || pn.dict_id >= 0 || pn.source_node < 0) return;
   if (pn.alias_body_off >= 0 && !opts.device_resident) return;   // aliased into the HOST body: not in HBM at all
@@ -1386,6 +1525,17 @@ void MultiDeviceScan::SumProduct(const std::string& a, const std::string& b, con
   out->sum_hi = static_cast<int64_t>(static_cast<uint64_t>(sum >> 64));
 }
 
+void ArrowScan::Stats(mi_scan_stats* out) {
+  out->record_batches += stats.record_batches;
+  out->lz4_batches_on_device += stats.lz4_batches_on_device;
+  out->h2d_bytes += stats.h2d_bytes;
+  out->decompressed_bytes += stats.decompressed_bytes;
+}
+
+void MultiDeviceScan::Stats(mi_scan_stats* out) {
+  for (auto& s : subs) s->Stats(out);
+}
+
 double MultiDeviceScan::Progress() {
   double p = 0;
   for (auto& s : subs) p += s->Progress();
@@ -1541,5 +1691,13 @@ int mi_scan_sum_product(mi_scan* s, const char* column_a, const char* column_b, 
 }
 
 double mi_scan_progress(mi_scan* s) { return s ? s->scan->Progress() : 0; }
+
+int mi_scan_get_stats(mi_scan* s, mi_scan_stats* out) {
+  return WrapC([&] {
+    if (!s || !out) throw InvalidInputException("mi_scan_get_stats: NULL argument");
+    std::memset(out, 0, sizeof(*out));
+    s->scan->Stats(out);
+  });
+}
 
 }  // extern "C"

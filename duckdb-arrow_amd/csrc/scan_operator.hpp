@@ -98,6 +98,7 @@ class ScanBase {
   virtual void SumProduct(const std::string& a, const std::string& b, const std::vector<std::string>& filter_columns,
                           const std::vector<int64_t>& lo, const std::vector<int64_t>& hi, mi_sum_product_result* out) = 0;
   virtual double Progress() = 0;
+  virtual void Stats(mi_scan_stats* out) = 0;   // adds to *out
 };
 
 class ArrowScan : public ScanBase {
@@ -116,6 +117,7 @@ class ArrowScan : public ScanBase {
   void Next(mi_data_chunk* out) override;
   void Count(int64_t* rows, int64_t* selected, int64_t* chunks) override;
   double Progress() override;
+  void Stats(mi_scan_stats* out) override;
   //! sum(a * b) over rows passing the range filters, all on the GPU; drains the scan (mi_scan_sum_product)
   void SumProduct(const std::string& a, const std::string& b, const std::vector<std::string>& filter_columns,
                   const std::vector<int64_t>& lo, const std::vector<int64_t>& hi, mi_sum_product_result* out) override;
@@ -192,6 +194,12 @@ class ArrowScan : public ScanBase {
     size_t stage_a_bytes = 0;                          // arena bytes of the full-width arrays (+ sel, counts)
     bool compact = false;                              // chunks hold only the selected rows (dense arrays behind stage A's)
     bool host_vectors = false;                         // h_out holds the decoded vectors
+    // K8: a record batch whose LZ4 buffers are decompressed in HBM (kernels_lz4.hip)
+    uint8_t* d_comp = nullptr;  size_t d_comp_cap = 0; // the compressed body
+    uint8_t* d_lz4 = nullptr;   size_t d_lz4_cap = 0;  // block / buffer tables, sequence descriptors, links, counters
+    uint8_t* h_lz4 = nullptr;   size_t h_lz4_cap = 0;  // pinned copy of the tables
+    hipStream_t lz4_stream = nullptr;                  // decompression of this slot overlaps the other slots' copies and kernels
+    hipEvent_t lz4_done = nullptr;
     bool needs_stage_b = false;                        // compaction: the gather + copy back wait for the counts
     uint8_t* compact_region = nullptr;                 // device address of the dense arrays
   };
@@ -230,6 +238,7 @@ class ArrowScan : public ScanBase {
   void InitSlot(Slot& s);
   void EnqueueBatch(Slot& s);
   void EnqueueStageB(Slot& s);
+  void EnqueueLz4(Slot& s);
   void UploadAux(Slot& s, const std::vector<uint64_t>& aux);
   void BuildVector(const Slot& s, int32_t node, size_t window, int64_t compact_rows, uint8_t* base, ChunkStorage* st, mi_vector* out);
   void DecodeDictionary(Source& src, const DecodedBatch& b);
@@ -281,6 +290,7 @@ class ArrowScan : public ScanBase {
   std::vector<void*> d_in_lists;         // per leaf (clause order): its IN-list in HBM, or NULL
   bool compact = false;
   bool keep_on_device = false;
+  mi_scan_stats stats{};
 };
 
 //! read_arrow over several GPUs of one process: one ArrowScan per context, record batch k of the file list
@@ -297,6 +307,7 @@ class MultiDeviceScan : public ScanBase {
   void SumProduct(const std::string& a, const std::string& b, const std::vector<std::string>& filter_columns,
                   const std::vector<int64_t>& lo, const std::vector<int64_t>& hi, mi_sum_product_result* out) override;
   double Progress() override;
+  void Stats(mi_scan_stats* out) override;
 
  private:
   void ForEachParallel(const std::function<void(size_t)>& fn);

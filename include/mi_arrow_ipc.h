@@ -305,6 +305,8 @@ typedef struct mi_col_task {
 #define MI_ST_OFFSET_OVERFLOW 32u /* encode: int32 offsets exceed INT32_MAX ("SET arrow_large_buffer_size=true") */
 #define MI_ST_DICT_INDEX 64u      /* a valid row's dictionary index is >= the dictionary length (FULL validation) */
 #define MI_ST_INTERNAL 128u       /* a kernel gave up waiting for another workgroup (bounded spin): results are not valid */
+#define MI_ST_DECOMPRESS 256u     /* a compressed buffer is malformed or does not expand to its declared length (EIO,
+                                   * base_stream_reader.cpp:24-29) */
 
 /* Uploads the task table to HBM (descriptor table + tile index) and returns a reusable plan.  One plan =
  * any number of (batch, column) tasks = ONE fused kernel launch per mi_plan_launch. */
@@ -570,6 +572,15 @@ typedef struct mi_sum_product_result {
 int mi_scan_sum_product(mi_scan* s, const char* column_a, const char* column_b, const mi_range_filter* filters,
                         int32_t n_filters, mi_sum_product_result* out);
 double mi_scan_progress(mi_scan* s);
+/* What the scan has moved so far (summed over the devices of a multi-device scan). */
+typedef struct mi_scan_stats {
+  int64_t record_batches;           /* submitted to the GPU */
+  int64_t lz4_batches_on_device;    /* of those: LZ4_FRAME bodies decompressed in HBM (K8) instead of on host threads */
+  int64_t h2d_bytes;                /* body bytes copied host -> HBM (compressed bytes for the K8 batches) */
+  int64_t decompressed_bytes;       /* bytes the K8 kernels produced */
+  int64_t _reserved[4];
+} mi_scan_stats;
+int mi_scan_get_stats(mi_scan* s, mi_scan_stats* out);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Writer.  Replaces ColumnDataCollectionSerializer (src/writer/column_data_collection_serializer.cpp),

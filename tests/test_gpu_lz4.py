@@ -1,0 +1,175 @@
+"""K8: LZ4_FRAME bodies decompressed in HBM (kernels_lz4.hip).  The reference decompresses on the CPU before slicing the
+body (base_stream_reader.cpp:11-50, zstd only; LZ4_FRAME is what pyarrow / Feather V2 write by default).  The check at this
+boundary: a device-resident scan of an LZ4 stream -- compressed bytes over PCIe, the four K8 kernels, then the usual
+transcode kernels -- yields the vectors of the host-consumer scan of the same file, whose bodies the host reader
+decompresses with liblz4; and mi_scan_get_stats shows the GPU path was the one that ran."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.ipc as ipc
+import pytest
+
+import duckdb_arrow_amd as da
+from helpers import canon_python
+from test_gpu_scan_operator import _mirror_device_vector
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def con():
+    return da.Connection(0)
+
+
+def _device_scan(con, path, **kw):
+    hip = C.CDLL("libamdhip64.so")
+    rel = con.read_arrow(path, accept_dictionaries=True, device_resident=True, **kw)
+    types = [da.parse_duck_type(t) for t in rel.types]
+    got = [[] for _ in types]
+    for ch in rel.chunks():
+        keep = []
+        for ci, ty in enumerate(types):
+            hv = _mirror_device_vector(hip, ch.columns[ci], ty, ch.size, keep)
+            got[ci].extend(da._vector_values(hv, ty, ch.size))
+    st = rel.stats()
+    rel.close()
+    return [canon_python(c) for c in got], st
+
+
+def _write(path, table, chunk, codec="lz4"):
+    with ipc.new_stream(path, table.schema, options=ipc.IpcWriteOptions(compression=codec)) as w:
+        w.write_table(table, max_chunksize=chunk)
+
+
+def _tables():
+    rng = np.random.default_rng(77)
+    n = 300000
+    words = ["alpha", "beta", "gamma delta epsilon", "", "zeta " * 9, "x"]
+    yield "mixed", pa.table({
+        "k": pa.array(np.arange(n, dtype=np.int64) * 3),                                   # matches at a fixed short distance
+        "z": pa.array(np.zeros(n, np.int32)),                                              # one long overlapping run
+        "r": pa.array(rng.integers(0, 1 << 62, n, dtype=np.int64)),                        # incompressible: stored raw
+        "s": pa.array([words[i] for i in rng.integers(0, len(words), n)], mask=rng.random(n) < 0.05),
+        "d": pa.array(rng.integers(8000, 11000, n).astype(np.int32), pa.date32()),
+        "b": pa.array(rng.random(n) < 0.3, mask=rng.random(n) < 0.1),
+        "t": pa.array(["comment %d %s" % (i % 977, "lorem ipsum dolor sit amet"[: i % 27]) for i in range(n)]),
+    }), 131072
+    yield "small_batches", pa.table({"a": pa.array(rng.integers(0, 5, 5000, dtype=np.int64)), "s": pa.array(["v%d" % (i % 7) for i in range(5000)])}), 700
+    yield "empty", pa.table({"a": pa.array([], pa.int64()), "s": pa.array([], pa.string())}), 10
+    period = np.tile(np.arange(97, dtype=np.uint8), 40000)                                # chains through many earlier matches
+    yield "periodic", pa.table({"p": pa.array(period[:3000000].view(np.int32)[:700000])}), 700000
+
+
+@pytest.mark.parametrize("case", ["mixed", "small_batches", "empty", "periodic"])
+def test_lz4_bodies_decompressed_in_hbm_equal_the_host_decompressor(con, tmp_path, case):
+    name, table, chunk = next(t for t in _tables() if t[0] == case)
+    path = str(tmp_path / (name + ".arrows"))
+    _write(path, table, chunk)
+    want = [canon_python(c) for c in con.read_arrow(path, accept_dictionaries=True).fetch_columns()]   # liblz4 on host threads
+    got, st = _device_scan(con, path)
+    assert got == want
+    batches = len(list(ipc.open_stream(path)))
+    nonempty = sum(1 for b in ipc.open_stream(path) if b.num_rows > 0)
+    assert st["record_batches"] == batches
+    assert st["lz4_batches_on_device"] >= (nonempty if table.num_columns else 0), st
+    if nonempty:
+        assert 0 < st["h2d_bytes"] and st["decompressed_bytes"] > 0
+    got_host, st_host = _device_scan(con, path, host_decompress=True)                                   # same consumer, host decompression
+    assert got_host == want and st_host["lz4_batches_on_device"] == 0
+
+
+def test_lz4_golden_files_and_projection(con, golden_dir, tmp_path):
+    for rel_path in ("lineitem_sf0_01_head.arrows", "edge_types.arrows", "edge_nested.arrows", "edge_dict.arrows"):
+        t = ipc.open_stream(os.path.join(golden_dir, rel_path)).read_all()
+        path = str(tmp_path / ("lz4_" + rel_path))
+        _write(path, t, 4096)
+        want = [canon_python(c) for c in con.read_arrow(path, accept_dictionaries=True).fetch_columns()]
+        got, st = _device_scan(con, path)
+        assert got == want, rel_path
+        # list / map columns keep the host decompressor: the planner samples their offsets on the host
+        assert (st["lz4_batches_on_device"] > 0) == (rel_path != "edge_nested.arrows"), rel_path
+    # projection: only the projected columns' frames cross PCIe
+    t = ipc.open_stream(os.path.join(golden_dir, "lineitem_sf0_01_head.arrows")).read_all()
+    path = str(tmp_path / "lz4_proj.arrows")
+    _write(path, t, 4096)
+    hip = C.CDLL("libamdhip64.so")
+    rel = con.read_arrow(path, device_resident=True).project(["l_shipdate", "l_comment"])
+    want = con.read_arrow(path).project(["l_shipdate", "l_comment"]).fetch_columns()
+    types = [da.parse_duck_type(x) for x in rel.types]
+    got = [[] for _ in types]
+    for ch in rel.chunks():
+        keep = []
+        for ci, ty in enumerate(types):
+            got[ci].extend(da._vector_values(_mirror_device_vector(hip, ch.columns[ci], ty, ch.size, keep), ty, ch.size))
+    assert [canon_python(c) for c in got] == [canon_python(c) for c in want]
+    full = os.path.getsize(path)
+    assert 0 < rel.stats()["h2d_bytes"] < full * 0.6
+
+
+def test_lz4_fused_consumers_on_compressed_input(con, golden_dir, tmp_path):
+    """Count with a pushed-down filter and the fused Q6 aggregate read LZ4 input without the body ever being decompressed
+    on the host."""
+    t = ipc.open_stream(os.path.join(golden_dir, "lineitem_sf0_01_q6.arrows")).read_all()
+    path = str(tmp_path / "q6_lz4.arrows")
+    _write(path, t, 8192)
+    plain = os.path.join(golden_dir, "lineitem_sf0_01_q6.arrows")
+    rel = con.read_arrow(path, device_resident=True)
+    rel.filter_range("l_shipdate", 8766, 9130)
+    a = rel.count(detail=True)
+    assert rel.stats()["lz4_batches_on_device"] > 0
+    rel2 = con.read_arrow(plain)
+    rel2.filter_range("l_shipdate", 8766, 9130)
+    b = rel2.count(detail=True)
+    assert (a["rows"], a["selected"]) == (b["rows"], b["selected"])
+    s1 = con.read_arrow(path, device_resident=True).sum_product("l_extendedprice", "l_discount", [("l_shipdate", 8766, 9130)])
+    s2 = con.read_arrow(plain).sum_product("l_extendedprice", "l_discount", [("l_shipdate", 8766, 9130)])
+    assert s1 == s2
+
+
+def _frames(buf):
+    """(offset, length) of every compressed buffer's LZ4 frame in an IPC stream written by pyarrow (walks the messages)."""
+    out = []
+    for e in da.Reader(buffers=[np.frombuffer(buf, np.uint8)]).index():
+        if e["type"] == 3:
+            out.append((e["body_offset"], e["body_len"]))
+    return out
+
+
+def test_damaged_lz4_input_is_an_error_not_a_crash(con, tmp_path):
+    """Corrupt block data (a match offset that reaches in front of the buffer, a token chain that runs past the block, a wrong
+    declared length): the K8 kernels bound every read and write, the scan ends with the EIO of base_stream_reader.cpp:24-29."""
+    n = 200000
+    t = pa.table({"k": pa.array(np.arange(n, dtype=np.int64) % 1000), "s": pa.array(["row %d" % (i % 313) for i in range(n)])})
+    path = str(tmp_path / "ok.arrows")
+    _write(path, t, n)
+    good = bytearray(open(path, "rb").read())
+    (body_off, body_len), = _frames(bytes(good))
+    rng = np.random.default_rng(3)
+    outcomes = set()
+    for trial in range(24):
+        bad = bytearray(good)
+        if trial == 0:   # the declared uncompressed length of the first buffer that has one
+            for at in range(body_off, body_off + body_len - 8, 8):
+                v = struct.unpack_from("<q", bad, at)[0]
+                if 0 < v < (1 << 31) and bad[at + 8: at + 12] == b"\x04\x22\x4d\x18":
+                    struct.pack_into("<q", bad, at, v - 8)
+                    break
+        else:            # random bytes inside the block data
+            for _ in range(1 + trial % 5):
+                at = body_off + 64 + int(rng.integers(0, body_len - 128))
+                bad[at] = int(rng.integers(0, 256))
+        p = str(tmp_path / ("bad_%d.arrows" % trial))
+        open(p, "wb").write(bytes(bad))
+        try:
+            got, st = _device_scan(con, p)
+            outcomes.add("ok")          # the damage hit literal bytes or padding: wrong values, valid structure
+        except da.MiError as e:
+            outcomes.add("error")
+            assert e.code in (da._ffi.MI_EIO, da._ffi.MI_EINVAL), (trial, str(e))
+    assert "error" in outcomes
+    # the context still works
+    got, _ = _device_scan(con, path)
+    assert got == [canon_python(c) for c in con.read_arrow(path).fetch_columns()]
