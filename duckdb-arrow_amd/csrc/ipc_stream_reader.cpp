@@ -506,8 +506,8 @@ void IPCStreamReader::DecompressBody(RecordBatchMeta* meta) {
     total += (n + 63) & ~static_cast<int64_t>(63);
   }
   // GPU consumers (SetDeferLz4): keep the body compressed and hand out the frame / block tables instead
-  bool deferrable = lz4 && defer_lz4 && !meta->is_dictionary && base_schema.endianness == 0 && total < (int64_t(1) << 32) - 64 &&
-                    cur_size < (int64_t(1) << 32) - 64;
+  bool deferrable = lz4 && defer_lz4 && !meta->is_dictionary && base_schema.endianness == 0 && total < (int64_t(1) << 31) - 64 &&
+                    cur_size < (int64_t(1) << 31) - 64;
   if (deferrable)
     for (auto& f : (HasProjection() ? projected_schema.fields : base_schema.fields))
       if (HasListField(f)) deferrable = false;

@@ -56,13 +56,13 @@ struct AggSumProductArgs {
 };
 hipError_t LaunchAggSumProduct(const AggSumProductArgs& args, unsigned long long* d_acc, int num_cus, hipStream_t stream);
 
-// K8: LZ4_FRAME buffers of one record batch, decompressed in HBM (kernels_lz4.hip).  Offsets are 32-bit: a compressed or
-// decompressed body of 4 GiB or more takes the host decompressor.
+// K8: LZ4_FRAME buffers of one record batch, decompressed in HBM (kernels_lz4.hip).  Positions are 31-bit: a compressed or
+// decompressed body of 2 GiB or more takes the host decompressor.
 struct Lz4BlockDev {
   uint32_t comp_off, comp_size;   // the block's bytes inside the compressed body
   uint32_t buffer;                // index into Lz4Args::buffers
   uint32_t stored;                // 1 = the block holds its bytes uncompressed
-  uint32_t seq_base, seq_cap;     // its slice of the sequence-descriptor scratch (comp_size / 3 + 2 entries)
+  uint32_t seq_base, seq_cap;     // its slice of the sequence-descriptor scratch: 64 lanes x (ceil(comp_size / 64) / 3 + 2)
 };
 struct Lz4BufferDev {
   uint64_t out_off, out_len;      // where the buffer lies in the decompressed body, and its declared length
@@ -77,16 +77,21 @@ struct Lz4Args {
   const Lz4BlockDev* blocks;
   const Lz4BufferDev* buffers;
   uint32_t n_blocks, n_buffers;
-  void* seq;                      // 16 bytes per sequence
+  uint32_t max_block_comp, _pad;  // largest compressed block
+  void* seq;                      // 16 bytes per sequence: the lanes' slices ...
   uint32_t* seq_off;              // 4 bytes per sequence
-  uint32_t* link[2];              // 4 bytes per decompressed byte, twice; link[0] preset to 0xFF
+  void* cseq;                     // ... and the block's sequences in order (same capacity)
+  uint32_t* cseq_off;
+  uint32_t* link;                 // 4 bytes per decompressed byte (rounded up to 16 bytes), preset to 0xFF
   uint32_t* block_out_size;       // per block
   uint32_t* block_nseq;
   uint64_t* block_out_base;
   uint32_t* buffer_ok;            // per buffer
+  uint32_t* tile_done;            // one word per 16 KiB of the decompressed body, zeroed
   uint32_t* round_left;           // 40 words, zeroed
   uint32_t* status;               // MI_ST_DECOMPRESS
 };
+inline uint32_t Lz4SeqCapacity(uint32_t comp_size) { return 64u * (((comp_size + 63u) / 64u) / 3u + 2u); }
 hipError_t LaunchLz4Decompress(const Lz4Args& args, int num_cus, hipStream_t stream);
 
 // Late materialisation: tasks with mi_col_task.sel decode only the selected rows, compacted per window (kernels_gather.hip)

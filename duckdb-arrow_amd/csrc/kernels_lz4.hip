@@ -9,20 +9,23 @@
 // block, and inside a frame with linked blocks -- what LZ4F_compressFrame writes -- a match may reach back into the
 // previous block, so "one wave per block, copy as you parse" serialises a whole buffer.  The work is therefore cut the
 // other way round, into steps that are each data parallel and never wait for another workgroup:
-//   1. lz4_parse    one LANE per block walks the tokens only (no data is copied): one descriptor per sequence
+//   1. lz4_parse    one WAVE per block walks the tokens only (no data is copied): one descriptor per sequence
 //                   {output position in the block, literal source, literal length, match length, match offset} and the
-//                   block's decompressed size.  Every block of every buffer of the record batch at once.
+//                   block's decompressed size.  The 64 lanes walk 64 segments of the block speculatively and repeat until
+//                   their start positions agree (see the kernel).  Every block of every buffer of the batch at once.
 //   2. lz4_layout   one lane per buffer: first output byte of each of its blocks (running sum), and the check the
 //                   reference makes after decompressing: the sizes must add up to the declared uncompressed length.
-//   3. lz4_expand   one workgroup per block, one thread per sequence: literals are copied to their final place; every
-//                   byte of a match gets a LINK = the position it copies from (always an earlier byte of the buffer).
-//   4. lz4_resolve  pointer jumping over the links, all bytes in parallel: link[j] <- link[link[j]] until the chain ends
-//                   in a byte that is known, then the byte is fetched.  A chain of depth d needs ceil(log2 d) + 1 rounds
-//                   (an overlapping run "offset 1, length 60000" is 16 rounds); a round that finds nothing left to do
-//                   tells the next ones (launched blindly, no host round trip) to return at once.
-// HBM traffic per decompressed byte: 4 B memset + ~5 B expand + 8 B per resolve round; a record batch of lineitem
-// (21.5 MB) is ~1 GB of traffic for ~6 rounds.  The serial part is step 1: ~4000 sequences per 64 KiB block, two or three
-// dependent loads each.
+//   3. lz4_expand   one workgroup per block, one thread per sequence: every decompressed byte gets a 32-bit LINK word --
+//                   a literal's word holds the byte itself, a match byte's word the position it copies from (always an
+//                   earlier byte of the buffer).
+//   4. lz4_resolve  pointer jumping over the links, all bytes in parallel and in place: link[j] <- link[link[j]] until
+//                   the word read holds a byte.  A chain of depth d needs ceil(log2 d) + 1 rounds (an overlapping run
+//                   "offset 1, length 60000" is 17); a round that finds nothing left to do makes the later ones
+//                   (launched blindly, no host round trip) return at once.
+//   5. lz4_emit     the bytes leave the link words for the decompressed body.
+// HBM traffic per decompressed byte: 4 B memset + 4 B expand + 4 B read per resolve round (+ 4 B write where a word
+// changed) + 5 B emit.  The token walk of step 1 is the latency-bound part: a few thousand
+// sequences per 64 KiB block, three or four dependent loads each -- hence the 64 speculative lanes.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -34,79 +37,223 @@ namespace miarrow {
 namespace device {
 namespace {
 
-constexpr uint32_t kLinkDone = 0xFFFFFFFFu;
+// A link word: bit 31 set = the byte is known and sits in the low 8 bits (kLinkUntouched: nothing was decompressed here);
+// bit 31 clear = the position this byte copies from.  One word is one atomic message: no second array to keep in step.
+constexpr uint32_t kLinkKnown = 0x80000000u;
+constexpr uint32_t kLinkUntouched = 0xFFFFFFFFu;
+constexpr uint32_t kResolveTileQuads = 4096;   // 16 KiB of output = 64 KiB of link words per tile
 
 __device__ __forceinline__ void lz4_fail(uint32_t* status) { atomicOr(status, MI_ST_DECOMPRESS); }
 
-__global__ __launch_bounds__(64) void lz4_parse(Lz4Args a) {
-  const uint32_t bi = blockIdx.x * 64 + threadIdx.x;
-  if (bi >= a.n_blocks) return;
-  const Lz4BlockDev b = a.blocks[bi];
-  const uint32_t block_max = a.buffers[b.buffer].block_max;
-  if (b.stored) {  // the block holds its bytes as they are
-    a.block_out_size[bi] = b.comp_size <= block_max ? b.comp_size : 0u;
-    a.block_nseq[bi] = 0;
-    if (b.comp_size > block_max) lz4_fail(a.status);
-    return;
-  }
-  gptr<const uint8_t> in = GC<uint8_t>(a.comp);
-  gptr<u32x4> seq = GM<u32x4>(a.seq) + b.seq_base;
-  gptr<uint32_t> seq_off = GM<uint32_t>(a.seq_off) + b.seq_base;
-  uint32_t ip = b.comp_off;
-  const uint32_t end = b.comp_off + b.comp_size;
-  uint32_t op = 0, n = 0;
-  bool ok = true;
-  while (ip < end) {
+// Token walk of one lane: from `ip` (a token position, true or guessed) until the first token position >= stop (or the
+// end of the block).  Descriptors go to seq[0..cap): output positions are relative to the lane's first sequence.
+struct Lz4Walk {
+  uint32_t exit;    // where the next lane's first token is (== block end when the block ends here)
+  uint32_t nseq;
+  uint32_t olen;    // bytes these sequences produce
+  bool ok;
+};
+using lptr = const uint8_t __attribute__((address_space(3)))*;
+
+template <bool STORE, typename BYTES>   // BYTES: the compressed bytes in global memory, or the workgroup's LDS copy of the block
+__device__ __forceinline__ Lz4Walk lz4_walk(BYTES in, uint32_t ip, uint32_t stop, uint32_t end, uint32_t block_max,
+                                             gptr<u32x4> seq, gptr<uint32_t> seq_off, uint32_t cap, uint32_t lit_bias) {
+  Lz4Walk w;
+  w.nseq = 0;
+  w.olen = 0;
+  w.ok = true;
+  bool zero_offset = false;
+  while (ip < stop) {
     const uint32_t token = in[ip++];
     uint32_t ll = token >> 4;
     if (ll == 15) {
       uint32_t x;
       do {
-        if (ip >= end) { ok = false; break; }
+        if (ip >= end) { w.ok = false; break; }
         x = in[ip++];
         ll += x;
       } while (x == 255 && ll < (1u << 24));
-      if (!ok || ll >= (1u << 24)) { ok = false; break; }
+      if (!w.ok || ll >= (1u << 24)) { w.ok = false; break; }
     }
     const uint32_t lit_src = ip;
-    if (ll > end - ip) { ok = false; break; }
+    if (ll > end - ip) { w.ok = false; break; }
     ip += ll;
     uint32_t ml = 0, offset = 0;
     if (ip < end) {  // the last sequence of a block is literals only
-      if (end - ip < 2) { ok = false; break; }
+      if (end - ip < 2) { w.ok = false; break; }
       offset = static_cast<uint32_t>(in[ip]) | (static_cast<uint32_t>(in[ip + 1]) << 8);
       ip += 2;
       ml = token & 15u;
       if (ml == 15) {
         uint32_t x;
         do {
-          if (ip >= end) { ok = false; break; }
+          if (ip >= end) { w.ok = false; break; }
           x = in[ip++];
           ml += x;
         } while (x == 255 && ml < (1u << 24));
-        if (!ok || ml >= (1u << 24)) { ok = false; break; }
+        if (!w.ok || ml >= (1u << 24)) { w.ok = false; break; }
       }
       ml += 4;
-      if (offset == 0) { ok = false; break; }
+      if (offset == 0) zero_offset = true;   // an error of the true chain; a guessed walk keeps going until it falls in step
     }
-    if (n >= b.seq_cap || ll + ml > block_max - op) { ok = false; break; }
+    if (w.nseq >= cap || ll + ml > block_max - w.olen) { w.ok = false; break; }
     u32x4 d;
-    d.x = op;
-    d.y = lit_src;
+    d.x = w.olen;
+    d.y = lit_src + lit_bias;
     d.z = ll;
     d.w = ml;
-    seq[n] = d;
-    seq_off[n] = offset;
-    n++;
-    op += ll + ml;
+    if (STORE) {
+      seq[w.nseq] = d;
+      seq_off[w.nseq] = offset;
+    }
+    w.nseq++;
+    w.olen += ll + ml;
   }
-  if (!ok) {
+  // a walk that ran into nonsense knows nothing about where the next segment's chain begins: leave the next lane its own guess
+  w.exit = w.ok ? ip : stop;
+  if (zero_offset) w.ok = false;
+  return w;
+}
+
+// One WAVE per block.  The token chain of a block is serial, but LZ4 streams re-synchronise: a walk that starts at a wrong
+// position lands on a true token position after a few sequences and stays on the chain from there.  So the block is cut into
+// 64 segments; every lane walks its segment from a GUESSED start (the segment boundary), then from the position the lane
+// before it left its own segment at, and again while that position keeps changing.  Lane 0 starts at the true position 0, so
+// lane k is final after at most k + 1 rounds whatever the bytes are (the worst case is the serial walk); with
+// re-synchronisation everything is final after two or three rounds of ~1/64 of the block each.  Walk errors of a round that
+// gets repeated mean nothing; the errors of the last round are the block's.
+typedef u32x4 u32x4_any __attribute__((aligned(1)));
+
+template <bool IN_LDS>
+__global__ __launch_bounds__(64) void lz4_parse(Lz4Args a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_block[];
+  const uint32_t bi = blockIdx.x;
+  const uint32_t lane = threadIdx.x;
+  const Lz4BlockDev b = a.blocks[bi];
+  const uint32_t block_max = a.buffers[b.buffer].block_max;
+  if (b.stored) {  // the block holds its bytes as they are
+    if (lane == 0) {
+      a.block_out_size[bi] = b.comp_size <= block_max ? b.comp_size : 0u;
+      a.block_nseq[bi] = 0;
+      if (b.comp_size > block_max) lz4_fail(a.status);
+    }
+    return;
+  }
+  gptr<const uint8_t> in = GC<uint8_t>(a.comp);
+  if (IN_LDS) {
+    // the walk is a chain of dependent byte loads: from LDS they cost a fraction of an L2 round trip.  16 bytes per lane and
+    // step, whatever the alignment (the compressed body is followed by >= 64 readable bytes)
+    for (uint32_t i = lane * 16; i < b.comp_size; i += 64 * 16)
+      *reinterpret_cast<u32x4*>(s_block + i) = *(gptr<const u32x4_any>)(in + b.comp_off + i);
+    __syncthreads();
+  }
+  const uint32_t seg = (b.comp_size + 63) / 64;
+  const uint32_t cap = seg / 3 + 2;               // a sequence that is not the block's last takes >= 3 bytes
+  gptr<u32x4> seq = GM<u32x4>(a.seq) + b.seq_base + lane * cap;
+  gptr<uint32_t> seq_off = GM<uint32_t>(a.seq_off) + b.seq_base + lane * cap;
+  // positions are block-relative when the bytes come from LDS, body-relative otherwise
+  const uint32_t origin = IN_LDS ? 0u : b.comp_off;
+  const uint32_t end = origin + b.comp_size;
+  const uint32_t seg_end = origin + (lane + 1) * seg < end ? origin + (lane + 1) * seg : end;
+  uint32_t start = origin + lane * seg < end ? origin + lane * seg : end;
+  const uint32_t seg_start = start;
+  // Round 0, without storing anything: where does a walk leave this segment if it starts at the boundary, 1 byte later,
+  // ... 7 bytes later?  The chain enters a segment at its first token at or after the boundary, i.e. within one sequence
+  // length of it: for the short sequences of numeric columns (3-6 compressed bytes, and so regular that a guessed walk
+  // stays out of step for the whole block) that is one of these eight positions, and the rounds below become look-ups.
+  uint32_t known[8];
+#pragma unroll
+  for (uint32_t g = 0; g < 8; g++) {
+    const uint32_t from = seg_start + g;
+    known[g] = from;
+    if (from < seg_end) {
+      if (IN_LDS) known[g] = lz4_walk<false>((lptr)s_block, from, seg_end, end, block_max, seq, seq_off, cap, 0u).exit;
+      else known[g] = lz4_walk<false>(in, from, seg_end, end, block_max, seq, seq_off, cap, 0u).exit;
+    }
+  }
+  Lz4Walk w;
+  w.exit = known[0];
+  w.nseq = 0;
+  w.olen = 0;
+  w.ok = true;
+  uint32_t stored_from = 0xFFFFFFFFu;   // start of the walk whose descriptors are in this lane's slice
+  bool need = false;                    // the boundary guess is answered by known[0]
+  uint32_t rounds = 0;
+  for (int round = 0; round < 66; round++) {   // <= 65 rounds by construction; the bound is for the reader
+    rounds++;
+    if (need) {
+      const uint32_t delta = start - seg_start;
+      if (start >= seg_end) {
+        w.exit = start;   // the chain jumps over this segment
+      } else if (start >= seg_start && delta < 8) {
+        w.exit = delta == 0 ? known[0] : delta == 1 ? known[1] : delta == 2 ? known[2] : delta == 3 ? known[3] : delta == 4 ? known[4]
+                 : delta == 5 ? known[5] : delta == 6 ? known[6] : known[7];
+      } else {
+        if (IN_LDS) w = lz4_walk<true>((lptr)s_block, start, seg_end, end, block_max, seq, seq_off, cap, b.comp_off);
+        else w = lz4_walk<true>(in, start, seg_end, end, block_max, seq, seq_off, cap, 0u);
+        stored_from = start;
+      }
+    }
+    // the chain enters this lane's segment where the lanes before it left theirs: the furthest exit so far (a sequence
+    // that spans many segments leaves the lanes in between with nothing; taking the running maximum tells all of them in
+    // one round instead of one lane per round)
+    uint32_t reach = w.exit;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(reach, d, 64);
+      if (lane >= static_cast<uint32_t>(d) && o > reach) reach = o;
+    }
+    uint32_t from = __shfl_up(reach, 1, 64);
+    if (lane == 0) from = origin;
+    need = from != start;
+    start = from;
+    if (!__any(need)) break;
+  }
+  // the descriptors of the final walk (answers that came from the look-up table stored none)
+  if (start >= seg_end) {
+    w.nseq = 0;
+    w.olen = 0;
+    w.ok = true;
+  } else if (stored_from != start) {
+    if (IN_LDS) w = lz4_walk<true>((lptr)s_block, start, seg_end, end, block_max, seq, seq_off, cap, b.comp_off);
+    else w = lz4_walk<true>(in, start, seg_end, end, block_max, seq, seq_off, cap, 0u);
+  }
+  if (!w.ok) lz4_fail(a.status);
+  if (lane == 0) {   // how well the speculation worked (mi_scan_stats)
+    atomicMax(&a.round_left[38], rounds);
+    atomicAdd(&a.round_left[39], rounds);
+    atomicAdd(&a.round_left[37], 1u);
+  }
+  // the lanes' slices become one array (order = lane order), output positions relative to the block
+  uint32_t seq_before = w.nseq, out_before = w.olen;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t s1 = __shfl_up(seq_before, d, 64), s2 = __shfl_up(out_before, d, 64);
+    if (lane >= static_cast<uint32_t>(d)) {
+      seq_before += s1;
+      out_before += s2;
+    }
+  }
+  const uint32_t total_seq = __shfl(seq_before, 63, 64), total_out = __shfl(out_before, 63, 64);
+  const bool all_ok = !__any(!w.ok) && total_out <= block_max;
+  seq_before -= w.nseq;
+  out_before -= w.olen;
+  gptr<u32x4> cseq = GM<u32x4>(a.cseq) + b.seq_base;
+  gptr<uint32_t> cseq_off = GM<uint32_t>(a.cseq_off) + b.seq_base;
+  if (all_ok) {
+    for (uint32_t i = 0; i < w.nseq; i++) {
+      u32x4 d = seq[i];
+      d.x += out_before;
+      cseq[seq_before + i] = d;
+      cseq_off[seq_before + i] = seq_off[i];
+    }
+  } else if (total_out > block_max && lane == 0) {
     lz4_fail(a.status);
-    op = 0;
-    n = 0;
   }
-  a.block_out_size[bi] = op;
-  a.block_nseq[bi] = n;
+  if (lane == 0) {
+    a.block_out_size[bi] = all_ok ? total_out : 0u;
+    a.block_nseq[bi] = all_ok ? total_seq : 0u;
+  }
 }
 
 __global__ __launch_bounds__(64) void lz4_layout(Lz4Args a) {
@@ -123,82 +270,159 @@ __global__ __launch_bounds__(64) void lz4_layout(Lz4Args a) {
   if (!ok) lz4_fail(a.status);  // "Expected decompressed size of N bytes but got M bytes" (base_stream_reader.cpp:24-29)
 }
 
+typedef uint64_t u64_any __attribute__((aligned(1)));
+
+// Output-centric: a thread produces 4 consecutive link words (one 16-byte store, consecutive lanes = consecutive
+// addresses) and finds the sequence that covers its first byte by binary search over the block's descriptors (in order
+// of output position; the upper levels of the search are the same lines for every thread).  A thread per SEQUENCE was 3x
+// slower: its stores were scattered 4-byte words and every wave ran as long as its longest match.
 __global__ __launch_bounds__(kBlockThreads) void lz4_expand(Lz4Args a) {
   const uint32_t bi = blockIdx.x;
   const Lz4BlockDev b = a.blocks[bi];
   if (!a.buffer_ok[b.buffer]) return;  // uniform
   const uint64_t base = a.block_out_base[bi];      // offset in the decompressed body
   const uint64_t buffer_lo = a.buffers[b.buffer].out_off;
+  const uint32_t n_out = a.block_out_size[bi];
   gptr<const uint8_t> in = GC<uint8_t>(a.comp);
-  gptr<uint8_t> out = GM<uint8_t>(a.out);
-  gptr<uint32_t> link = GM<uint32_t>(a.link[0]);
+  gptr<uint32_t> link = GM<uint32_t>(a.link);
   if (b.stored) {
-    for (uint32_t i = threadIdx.x; i < b.comp_size; i += kBlockThreads) out[base + i] = in[b.comp_off + i];
-    return;  // links of the whole body start as "done"
-  }
-  const uint32_t nseq = a.block_nseq[bi];
-  gptr<const u32x4> seq = GC<u32x4>(a.seq) + b.seq_base;
-  gptr<const uint32_t> seq_off = GC<uint32_t>(a.seq_off) + b.seq_base;
-  for (uint32_t s = threadIdx.x; s < nseq; s += kBlockThreads) {
-    const u32x4 d = seq[s];
-    const uint64_t lit_at = base + d.x;
-    for (uint32_t i = 0; i < d.z; i++) out[lit_at + i] = in[d.y + i];
-    if (d.w) {
-      const uint64_t m_at = lit_at + d.z;
-      const uint32_t offset = seq_off[s];
-      if (offset > m_at - buffer_lo) {  // reaches in front of the buffer: not a frame an encoder writes
-        lz4_fail(a.status);
-        for (uint32_t i = 0; i < d.w; i++) out[m_at + i] = 0;
-      } else {
-        for (uint32_t i = 0; i < d.w; i++) link[m_at + i] = static_cast<uint32_t>(m_at + i - offset);
-      }
-    }
-  }
-}
-
-// One round of pointer jumping over bytes [0, n): reads link[from], writes link[to].
-__global__ __launch_bounds__(kBlockThreads) void lz4_resolve(Lz4Args a, int round) {
-  if (round > 0 && a.round_left[round - 1] == 0) {
-    // nothing was left after the previous round; pass the word on so that every later round sees it without a chain
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.round_left[round] = 0;
+    for (uint32_t i = threadIdx.x; i < b.comp_size; i += kBlockThreads) link[base + i] = kLinkKnown | in[b.comp_off + i];
     return;
   }
-  gptr<const uint32_t> from = GC<uint32_t>(a.link[round & 1]);
-  gptr<uint32_t> to = GM<uint32_t>(a.link[(round & 1) ^ 1]);
-  gptr<uint8_t> out = GM<uint8_t>(a.out);
-  bool left = false;
-  for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * kBlockThreads + threadIdx.x; j < a.out_size; j += static_cast<uint64_t>(gridDim.x) * kBlockThreads) {
-    const uint32_t s = from[j];
-    uint32_t next = kLinkDone;
-    if (s != kLinkDone) {
-      const uint32_t t = from[s];
-      if (t == kLinkDone) {
-        out[j] = out[s];   // out[s] was final before this launch began
+  const uint32_t nseq = a.block_nseq[bi];
+  if (nseq == 0) return;
+  gptr<const u32x4> seq = GC<u32x4>(a.cseq) + b.seq_base;
+  gptr<const uint32_t> seq_off = GC<uint32_t>(a.cseq_off) + b.seq_base;
+  const bool aligned = (base & 3u) == 0;
+  bool bad = false;
+  for (uint32_t p0 = threadIdx.x * 4; p0 < n_out; p0 += kBlockThreads * 4) {
+    // last sequence that starts at or before p0 (the first one starts at 0)
+    uint32_t lo = 0, hi = nseq;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (seq[mid].x <= p0) lo = mid; else hi = mid;
+    }
+    uint32_t si = lo;
+    u32x4 d = seq[si];
+    uint32_t offset = seq_off[si];
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t p = p0 + k;
+      w[k] = kLinkUntouched;
+      if (p >= n_out) continue;
+      while (p >= d.x + d.z + d.w && si + 1 < nseq) {   // sequences produce >= 1 byte, except a block's empty last one
+        si++;
+        d = seq[si];
+        offset = seq_off[si];
+      }
+      const uint32_t r = p - d.x;
+      if (r < d.z) {
+        w[k] = kLinkKnown | in[d.y + r];
       } else {
-        next = t;
-        left = true;
+        const uint64_t m_at = base + d.x + d.z;
+        const uint32_t i = r - d.z;
+        if (offset > m_at - buffer_lo) {   // reaches in front of the buffer: not a frame an encoder writes
+          bad = true;
+          w[k] = kLinkKnown;
+        } else {
+          // an overlapping match (offset < length: a run) repeats its first `offset` bytes: every byte links straight into
+          // that period instead of to the byte `offset` before it, or a run of n bytes would be a chain n / offset deep
+          w[k] = static_cast<uint32_t>(m_at - offset) + (i < offset ? i : i % offset);
+        }
       }
     }
-    to[j] = next;
+    if (aligned && p0 + 4 <= n_out) {
+      u32x4 v;
+      v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+      *(gptr<u32x4>)(link + base + p0) = v;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (p0 + k < n_out) link[base + p0 + k] = w[k];
+    }
   }
-  if (__syncthreads_or(left ? 1 : 0) && threadIdx.x == 0) atomicAdd(&a.round_left[round], 1u);
+  if (bad) lz4_fail(a.status);
+}
+
+// One round of pointer jumping, in place.  A thread owns 4 consecutive words; what it reads of OTHER words may be the value
+// from before this launch or one written during it -- both name a byte further back on the same chain (or the byte itself),
+// so either is right; a word is only ever written by its owner.
+__global__ __launch_bounds__(kBlockThreads) void lz4_resolve(Lz4Args a, int round) {
+  if (round > 0 && a.round_left[round - 1] == 0) return;  // the previous round left nothing (round_left[round] stays 0)
+  gptr<uint32_t> link = GM<uint32_t>(a.link);
+  const uint64_t nquads = (a.out_size + 3) / 4;
+  const uint32_t ntiles = static_cast<uint32_t>((nquads + kResolveTileQuads - 1) / kResolveTileQuads);
+  bool any_left = false;
+  // a tile (16 KiB of output) that held no open link at the end of a round is never read again: text resolves in two or
+  // three rounds, the deep chains of periodic data (each match copies the period before it) keep only their own tiles busy
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if (a.tile_done[tile]) continue;   // uniform
+    bool left = false;
+    const uint64_t q0 = static_cast<uint64_t>(tile) * kResolveTileQuads;
+    const uint64_t q1 = q0 + kResolveTileQuads < nquads ? q0 + kResolveTileQuads : nquads;
+    for (uint64_t q = q0 + threadIdx.x; q < q1; q += kBlockThreads) {
+      u32x4 v = *(gptr<const u32x4>)(link + 4 * q);   // the array is padded to whole quads
+      if ((v.x & v.y & v.z & v.w) >> 31) continue;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t s = k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
+        if (s >> 31) continue;
+        const uint32_t u = __builtin_nontemporal_load(link + s);
+        if (k == 0) v.x = u; else if (k == 1) v.y = u; else if (k == 2) v.z = u; else v.w = u;
+        if (!(u >> 31)) left = true;
+      }
+      *(gptr<u32x4>)(link + 4 * q) = v;
+    }
+    const bool tile_left = __syncthreads_or(left ? 1 : 0) != 0;
+    if (!tile_left && threadIdx.x == 0) a.tile_done[tile] = 1u;
+    any_left |= tile_left;
+  }
+  if (any_left && threadIdx.x == 0) atomicAdd(&a.round_left[round], 1u);
+}
+
+// The known bytes leave the link words for the decompressed body; words still holding kLinkUntouched belong to bytes the
+// K8 kernels did not produce (raw buffers were copied, padding was zeroed).
+__global__ __launch_bounds__(kBlockThreads) void lz4_emit(Lz4Args a) {
+  gptr<const uint32_t> link = GC<uint32_t>(a.link);
+  gptr<uint8_t> out = GM<uint8_t>(a.out);
+  const uint64_t nquads = (a.out_size + 3) / 4;
+  for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * kBlockThreads + threadIdx.x; q < nquads; q += static_cast<uint64_t>(gridDim.x) * kBlockThreads) {
+    const u32x4 v = *(gptr<const u32x4>)(link + 4 * q);
+    const bool t0 = v.x != kLinkUntouched, t1 = v.y != kLinkUntouched, t2 = v.z != kLinkUntouched, t3 = v.w != kLinkUntouched;
+    if (t0 && t1 && t2 && t3 && 4 * q + 4 <= a.out_size) {
+      *(gptr<uint32_t>)(out + 4 * q) = (v.x & 0xFFu) | ((v.y & 0xFFu) << 8) | ((v.z & 0xFFu) << 16) | ((v.w & 0xFFu) << 24);
+    } else {
+      if (t0 && 4 * q + 0 < a.out_size) out[4 * q + 0] = static_cast<uint8_t>(v.x);
+      if (t1 && 4 * q + 1 < a.out_size) out[4 * q + 1] = static_cast<uint8_t>(v.y);
+      if (t2 && 4 * q + 2 < a.out_size) out[4 * q + 2] = static_cast<uint8_t>(v.z);
+      if (t3 && 4 * q + 3 < a.out_size) out[4 * q + 3] = static_cast<uint8_t>(v.w);
+    }
+  }
 }
 
 }  // namespace
 
-// a.link[0] must hold 0xFF in every byte (all links "done"), a.round_left zeros, a.out zeros where padding is expected.
+// a.link must hold kLinkUntouched in every word (0xFF bytes), a.round_left zeros, a.out zeros where padding is expected.
 hipError_t LaunchLz4Decompress(const Lz4Args& a, int num_cus, hipStream_t stream) {
   MI_DROP_STALE_ERROR();
   if (a.n_blocks == 0) return hipSuccess;
-  hipLaunchKernelGGL(lz4_parse, dim3((a.n_blocks + 63) / 64), dim3(64), 0, stream, a);
+  // compressed blocks below 64 KiB (64 KiB is the default block size of every writer) are walked from an LDS copy
+  if (a.max_block_comp + 32u <= (64u << 10))   // 64 KiB of LDS per workgroup without opting in to more
+    hipLaunchKernelGGL(lz4_parse<true>, dim3(a.n_blocks), dim3(64), ((a.max_block_comp + 15u) & ~15u) + 16u, stream, a);
+  else
+    hipLaunchKernelGGL(lz4_parse<false>, dim3(a.n_blocks), dim3(64), 0, stream, a);
   hipLaunchKernelGGL(lz4_layout, dim3((a.n_buffers + 63) / 64), dim3(64), 0, stream, a);
   hipLaunchKernelGGL(lz4_expand, dim3(a.n_blocks), dim3(kBlockThreads), 0, stream, a);
   // chains only run backwards inside one buffer: depth < its length, rounds <= log2(length) + 1
   int rounds = 2;
-  while (rounds < 34 && (1ull << (rounds - 1)) < a.max_buffer_len) rounds++;
-  const uint64_t want = (a.out_size + kBlockThreads - 1) / kBlockThreads;
-  const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(want, static_cast<uint64_t>(num_cus) * 32));
-  for (int r = 0; r < rounds; r++) hipLaunchKernelGGL(lz4_resolve, dim3(grid ? grid : 1), dim3(kBlockThreads), 0, stream, a, r);
+  while (rounds < 33 && (1ull << (rounds - 1)) < a.max_buffer_len) rounds++;
+  const uint64_t want = ((a.out_size + 3) / 4 + kBlockThreads - 1) / kBlockThreads;
+  const uint32_t grid = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(want, static_cast<uint64_t>(num_cus) * 16)));
+  const uint64_t ntiles = ((a.out_size + 3) / 4 + kResolveTileQuads - 1) / kResolveTileQuads;
+  const uint32_t rgrid = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(ntiles, static_cast<uint64_t>(num_cus) * 8)));
+  for (int r = 0; r < rounds; r++) hipLaunchKernelGGL(lz4_resolve, dim3(rgrid), dim3(kBlockThreads), 0, stream, a, r);
+  hipLaunchKernelGGL(lz4_emit, dim3(grid), dim3(kBlockThreads), 0, stream, a);
   return hipGetLastError();
 }
 

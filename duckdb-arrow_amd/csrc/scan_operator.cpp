@@ -577,6 +577,7 @@ void ArrowScan::EnqueueBatch(Slot& s) {
   s.planner.Rebase(0, s.d_out, s.d_aux);
 
   stats.record_batches++;
+  s.h_status[2] = 0;
   if (b.deferred) {
     EnqueueLz4(s);   // compressed body -> HBM -> K8 kernels -> d_in; ctx->stream waits for them
   } else {
@@ -748,12 +749,13 @@ void ArrowScan::EnqueueLz4(Slot& s) {
   const size_t o_blocks = take(nb * sizeof(device::Lz4BlockDev)), o_buffers = take(nf * sizeof(device::Lz4BufferDev));
   const size_t tables_bytes = at;
   uint64_t total_seq = 0, max_len = 0;
-  for (auto& blk : d.blocks) total_seq += blk.comp_size / 3 + 2;
+  for (auto& blk : d.blocks) total_seq += device::Lz4SeqCapacity(blk.comp_size);
   const size_t o_bsize = take(nb * 4), o_bnseq = take(nb * 4), o_bbase = take(nb * 8), o_bufok = take(nf * 4), o_round = take(40 * 4),
-               o_status = take(4);
+               o_status = take(4), o_tiles = take((out_size / 16384 + 2) * 4);
   const size_t counters_end = at;
   const size_t o_seq = take(static_cast<size_t>(total_seq) * 16), o_seqoff = take(static_cast<size_t>(total_seq) * 4);
-  const size_t o_link0 = take(out_size * 4), o_link1 = take(out_size * 4);
+  const size_t o_cseq = take(static_cast<size_t>(total_seq) * 16), o_cseqoff = take(static_cast<size_t>(total_seq) * 4);
+  const size_t o_link = take(out_size * 4 + 16);
   if (at > s.d_lz4_cap) {
     if (s.d_lz4) MI_HIP_CHECK(hipFree(s.d_lz4));
     s.d_lz4 = nullptr;
@@ -782,7 +784,7 @@ void ArrowScan::EnqueueLz4(Slot& s) {
     hb[i].buffer = blk.buffer;
     hb[i].stored = blk.stored;
     hb[i].seq_base = seq_at;
-    hb[i].seq_cap = blk.comp_size / 3 + 2;
+    hb[i].seq_cap = device::Lz4SeqCapacity(blk.comp_size);
     seq_at += hb[i].seq_cap;
   }
   for (size_t i = 0; i < nf; i++) {
@@ -823,7 +825,7 @@ void ArrowScan::EnqueueLz4(Slot& s) {
   MI_HIP_CHECK(hipStreamWaitEvent(q, s.h2d_done, 0));
   MI_HIP_CHECK(hipMemsetAsync(s.d_in, 0, out_size, q));                                        // padding between buffers
   MI_HIP_CHECK(hipMemsetAsync(s.d_lz4 + tables_bytes, 0, counters_end - tables_bytes, q));      // counters, status
-  MI_HIP_CHECK(hipMemsetAsync(s.d_lz4 + o_link0, 0xFF, out_size * 4, q));                       // every link "done"
+  MI_HIP_CHECK(hipMemsetAsync(s.d_lz4 + o_link, 0xFF, out_size * 4 + 16, q));                   // every link word "untouched"
   for (auto& f : d.buffers)
     if (f.raw && f.out_len > 0)
       MI_HIP_CHECK(hipMemcpyAsync(s.d_in + f.out_off, s.d_comp + f.comp_off, static_cast<size_t>(f.out_len), hipMemcpyDeviceToDevice, q));
@@ -837,18 +839,24 @@ void ArrowScan::EnqueueLz4(Slot& s) {
   a.buffers = reinterpret_cast<const device::Lz4BufferDev*>(s.d_lz4 + o_buffers);
   a.n_blocks = static_cast<uint32_t>(nb);
   a.n_buffers = static_cast<uint32_t>(nf);
+  for (auto& blk : d.blocks)
+    if (!blk.stored) a.max_block_comp = std::max(a.max_block_comp, blk.comp_size);
   a.seq = s.d_lz4 + o_seq;
   a.seq_off = reinterpret_cast<uint32_t*>(s.d_lz4 + o_seqoff);
-  a.link[0] = reinterpret_cast<uint32_t*>(s.d_lz4 + o_link0);
-  a.link[1] = reinterpret_cast<uint32_t*>(s.d_lz4 + o_link1);
+  a.cseq = s.d_lz4 + o_cseq;
+  a.cseq_off = reinterpret_cast<uint32_t*>(s.d_lz4 + o_cseqoff);
+  a.link = reinterpret_cast<uint32_t*>(s.d_lz4 + o_link);
   a.block_out_size = reinterpret_cast<uint32_t*>(s.d_lz4 + o_bsize);
   a.block_nseq = reinterpret_cast<uint32_t*>(s.d_lz4 + o_bnseq);
   a.block_out_base = reinterpret_cast<uint64_t*>(s.d_lz4 + o_bbase);
   a.buffer_ok = reinterpret_cast<uint32_t*>(s.d_lz4 + o_bufok);
   a.round_left = reinterpret_cast<uint32_t*>(s.d_lz4 + o_round);
+  a.tile_done = reinterpret_cast<uint32_t*>(s.d_lz4 + o_tiles);
   a.status = reinterpret_cast<uint32_t*>(s.d_lz4 + o_status);
   MI_HIP_CHECK(device::LaunchLz4Decompress(a, ctx->num_cus, q));
   MI_HIP_CHECK(hipMemcpyAsync(&s.h_status[2], a.status, sizeof(uint32_t), hipMemcpyDeviceToHost, q));
+  MI_HIP_CHECK(hipMemcpyAsync(&s.h_status[4], a.round_left + 37, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, q));
+  s.lz4_counted = false;
   MI_HIP_CHECK(hipEventRecord(s.lz4_done, q));
   MI_HIP_CHECK(hipStreamWaitEvent(ctx->stream, s.lz4_done, 0));
   MI_HIP_CHECK(hipStreamWaitEvent(ctx->d2h_stream, s.lz4_done, 0));
@@ -1191,6 +1199,12 @@ bool ArrowScan::AcquireBatch(BatchRef* out) {
   MI_HIP_CHECK(hipEventSynchronize(s.d2h_done));
   inflight.pop_front();
   try {
+    if (s.batch.deferred && !s.lz4_counted) {
+      s.lz4_counted = true;
+      stats.lz4_blocks += s.h_status[4];
+      stats.lz4_parse_rounds += s.h_status[6];
+      stats.lz4_parse_rounds_max = std::max<int64_t>(stats.lz4_parse_rounds_max, s.h_status[5]);
+    }
     ThrowForStatus(s.h_status[0] | s.h_status[1] | s.h_status[2]);
   } catch (...) {
     s.busy = false;
@@ -1530,6 +1544,9 @@ void ArrowScan::Stats(mi_scan_stats* out) {
   out->lz4_batches_on_device += stats.lz4_batches_on_device;
   out->h2d_bytes += stats.h2d_bytes;
   out->decompressed_bytes += stats.decompressed_bytes;
+  out->lz4_blocks += stats.lz4_blocks;
+  out->lz4_parse_rounds += stats.lz4_parse_rounds;
+  out->lz4_parse_rounds_max = std::max(out->lz4_parse_rounds_max, stats.lz4_parse_rounds_max);
 }
 
 void MultiDeviceScan::Stats(mi_scan_stats* out) {

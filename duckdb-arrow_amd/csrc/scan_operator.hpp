@@ -200,6 +200,7 @@ class ArrowScan : public ScanBase {
     uint8_t* h_lz4 = nullptr;   size_t h_lz4_cap = 0;  // pinned copy of the tables
     hipStream_t lz4_stream = nullptr;                  // decompression of this slot overlaps the other slots' copies and kernels
     hipEvent_t lz4_done = nullptr;
+    bool lz4_counted = true;
     bool needs_stage_b = false;                        // compaction: the gather + copy back wait for the counts
     uint8_t* compact_region = nullptr;                 // device address of the dense arrays
   };

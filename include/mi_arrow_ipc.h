@@ -578,7 +578,11 @@ typedef struct mi_scan_stats {
   int64_t lz4_batches_on_device;    /* of those: LZ4_FRAME bodies decompressed in HBM (K8) instead of on host threads */
   int64_t h2d_bytes;                /* body bytes copied host -> HBM (compressed bytes for the K8 batches) */
   int64_t decompressed_bytes;       /* bytes the K8 kernels produced */
-  int64_t _reserved[4];
+  int64_t lz4_blocks;               /* compressed LZ4 blocks walked by the K8 parse kernel ... */
+  int64_t lz4_parse_rounds;         /* ... rounds of its 64 speculative lanes, summed over the blocks (2-3 when the guesses
+                                     * fall in step, 65 = the serial walk) ... */
+  int64_t lz4_parse_rounds_max;     /* ... and the worst block */
+  int64_t _reserved[1];
 } mi_scan_stats;
 int mi_scan_get_stats(mi_scan* s, mi_scan_stats* out);
 

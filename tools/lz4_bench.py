@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""K8 end to end: the lineitem table as an LZ4_FRAME-compressed IPC stream (what pyarrow / Feather V2 write), scanned by a
+device-resident consumer with the bodies decompressed (a) by the reader's host threads, (b) in HBM by the K8 kernels,
+beside the uncompressed file.  usage: python tools/lz4_bench.py [--sf 10] [--dir /dev/shm]"""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sf", type=float, default=10.0)
+    ap.add_argument("--dir", default="/dev/shm")
+    ap.add_argument("--depth", type=int, default=8)
+    args = ap.parse_args()
+    import pyarrow as pa
+    import pyarrow.ipc as ipc
+    import duckdb_arrow_amd as da
+    buf, info = da.synth_lineitem_stream(scale_factor=args.sf, seed=42)
+    plain = os.path.join(args.dir, "mi_lz4_plain_sf%g.arrows" % args.sf)
+    packed = os.path.join(args.dir, "mi_lz4_packed_sf%g.arrows" % args.sf)
+    out = {"rows": info["n_rows"], "plain_bytes": int(buf.size)}
+    try:
+        buf.tofile(plain)
+        t0 = time.perf_counter()
+        reader = ipc.open_stream(pa.py_buffer(buf))
+        with ipc.new_stream(packed, reader.schema, options=ipc.IpcWriteOptions(compression="lz4")) as w:
+            for b in reader:
+                w.write_batch(b)
+        out["pyarrow_compress_seconds"] = time.perf_counter() - t0
+        out["lz4_bytes"] = os.path.getsize(packed)
+        del buf
+        con = da.Connection(0)
+        for tag, path, kw in (("plain", plain, {}), ("lz4_host_threads", packed, {"host_decompress": True}), ("lz4_in_hbm", packed, {})):
+            best, st = None, None
+            for _ in range(2):
+                rel = con.read_arrow(path, device_resident=True, pipeline_depth=args.depth, **kw)
+                t0 = time.perf_counter()
+                got = rel.count(detail=True)
+                dt = time.perf_counter() - t0
+                st = rel.stats()
+                rel.close()
+                assert got["rows"] == info["n_rows"]
+                best = dt if best is None else min(best, dt)
+            out[tag] = {"seconds": best, "rows_per_s": info["n_rows"] / best, "stats": st}
+            print(tag, "%.3f s" % best, file=sys.stderr, flush=True)
+    finally:
+        for p in (plain, packed):
+            if os.path.exists(p):
+                os.unlink(p)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
