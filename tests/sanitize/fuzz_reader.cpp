@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <fstream>
 #include <random>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -70,12 +71,99 @@ static int DrainStream(const std::vector<uint8_t>& buf) {
   return batches;
 }
 
+// What the K8 kernels compute from a deferred body (DecodedBatch::deferred: LZ4 frames still compressed, block tables built
+// by the reader), restated serially with every access checked: the tables are the host half of the GPU decompressor.
+static std::vector<uint8_t> DecodeDeferred(const DecodedBatch& b) {
+  const DeferredLz4Body& d = *b.deferred;
+  std::vector<uint8_t> out(static_cast<size_t>(b.body_size), 0);
+  auto need = [](bool ok) { if (!ok) throw std::runtime_error("deferred LZ4 body is malformed"); };
+  for (auto& f : d.buffers) {
+    need(f.comp_off >= 0 && f.comp_len >= 0 && f.comp_off + f.comp_len <= d.comp_size);
+    need(f.out_off >= 0 && f.out_len >= 0 && f.out_off + f.out_len <= b.body_size);
+    if (f.raw) {
+      need(f.comp_len >= f.out_len);
+      std::memcpy(out.data() + f.out_off, d.comp + f.comp_off, static_cast<size_t>(f.out_len));
+      continue;
+    }
+    need(static_cast<size_t>(f.first_block) + f.n_blocks <= d.blocks.size());
+    int64_t op = f.out_off;
+    const int64_t out_end = f.out_off + f.out_len;
+    for (uint32_t k = 0; k < f.n_blocks; k++) {
+      const auto& blk = d.blocks[f.first_block + k];
+      need(static_cast<int64_t>(blk.comp_off) >= f.comp_off && static_cast<int64_t>(blk.comp_off) + blk.comp_size <= f.comp_off + f.comp_len);
+      const uint8_t* ip = d.comp + blk.comp_off;
+      const uint8_t* const iend = ip + blk.comp_size;
+      if (blk.stored) {
+        need(op + blk.comp_size <= out_end);
+        std::memcpy(out.data() + op, ip, blk.comp_size);
+        op += blk.comp_size;
+        continue;
+      }
+      while (ip < iend) {
+        const uint32_t token = *ip++;
+        uint64_t ll = token >> 4;
+        if (ll == 15) {
+          uint8_t x;
+          do { need(ip < iend); x = *ip++; ll += x; } while (x == 255);
+        }
+        need(ll <= static_cast<uint64_t>(iend - ip) && op + static_cast<int64_t>(ll) <= out_end);
+        std::memcpy(out.data() + op, ip, ll);
+        ip += ll;
+        op += static_cast<int64_t>(ll);
+        if (ip >= iend) break;
+        need(iend - ip >= 2);
+        const uint32_t offset = ip[0] | (ip[1] << 8);
+        ip += 2;
+        uint64_t ml = token & 15;
+        if (ml == 15) {
+          uint8_t x;
+          do { need(ip < iend); x = *ip++; ml += x; } while (x == 255);
+        }
+        ml += 4;
+        need(offset != 0 && static_cast<int64_t>(offset) <= op - f.out_off && op + static_cast<int64_t>(ml) <= out_end);
+        for (uint64_t i = 0; i < ml; i++, op++) out[static_cast<size_t>(op)] = out[static_cast<size_t>(op - offset)];
+      }
+    }
+    need(op == out_end);
+  }
+  return out;
+}
+
+// An intact LZ4 stream read twice -- bodies decompressed by the reader (liblz4), and deferred + the restatement above:
+// every buffer span must hold the same bytes.  Returns the number of record batches that were deferred.
+static int CompareDeferredWithHost(const std::vector<uint8_t>& buf) {
+  std::vector<ArrowIPCBuffer> bufs;
+  bufs.push_back(ArrowIPCBuffer{reinterpret_cast<uint64_t>(buf.data()), static_cast<uint64_t>(buf.size())});
+  IPCBufferStreamReader host(bufs), gpu(bufs);
+  gpu.SetDeferLz4(true);
+  DecodedBatch a, b;
+  int deferred = 0;
+  while (true) {
+    const bool more_a = host.GetNextBatch(&a, true), more_b = gpu.GetNextBatch(&b, true);
+    if (more_a != more_b) std::abort();
+    if (!more_a) break;
+    if (!b.deferred) continue;
+    deferred++;
+    const std::vector<uint8_t> body = DecodeDeferred(b);
+    if (a.nodes.size() != b.nodes.size() || a.body_size != b.body_size) std::abort();
+    for (size_t n = 0; n < a.nodes.size(); n++)
+      for (size_t k = 0; k < a.nodes[n].spans.size(); k++) {
+        const auto& x = a.nodes[n].spans[k];
+        const auto& y = b.nodes[n].spans[k];
+        if (x.length != y.length || x.offset != y.offset) std::abort();
+        if (x.length > 0 && std::memcmp(a.body + x.offset, body.data() + y.offset, static_cast<size_t>(x.length)) != 0) std::abort();
+      }
+  }
+  return deferred;
+}
+
 static int Drain(const std::vector<uint8_t>& buf, bool project, std::mt19937_64& rng) {
   int batches = 0;
   try {
     std::vector<ArrowIPCBuffer> bufs;
     bufs.push_back(ArrowIPCBuffer{reinterpret_cast<uint64_t>(buf.data()), static_cast<uint64_t>(buf.size())});
     IPCBufferStreamReader rd(bufs);
+    rd.SetDeferLz4(rng() % 2 == 0);   // LZ4 bodies handed out compressed, with the block tables of the GPU decompressor
     const ArrowSchemaModel& schema = rd.GetBaseSchema();
     {  // the flatbuffer builder under the sanitizers too: re-encode the schema, read it back, same top-level shape
       const std::vector<uint8_t> msg = EncodeSchemaMessage(schema);
@@ -100,9 +188,19 @@ static int Drain(const std::vector<uint8_t>& buf, bool project, std::mt19937_64&
       batches++;
       // touch every byte the reader says belongs to a buffer
       uint64_t sum = 0;
+      std::vector<uint8_t> expanded;
+      const uint8_t* body = b.body;
+      if (b.deferred) {
+        try {
+          expanded = DecodeDeferred(b);
+        } catch (const std::runtime_error&) {
+          continue;   // damaged block data: the device reports MI_ST_DECOMPRESS for it
+        }
+        body = expanded.data();
+      }
       for (auto& nd : b.nodes)
         for (auto& sp : nd.spans)
-          for (int64_t i = 0; i < sp.length; i += 61) sum += b.body[sp.offset + i];
+          for (int64_t i = 0; i < sp.length; i += 61) sum += body[sp.offset + i];
       (void)sum;
     }
   } catch (const std::exception&) {
@@ -152,11 +250,15 @@ int main(int argc, char** argv) {
   }
   const int iters = std::atoi(argv[1]);
   std::mt19937_64 rng(12345);
-  long errors = 0, clean = 0;
+  long errors = 0, clean = 0, deferred_batches = 0;
   for (int a = 2; a < argc; a++) {
     std::ifstream in(argv[a], std::ios::binary);
     std::vector<uint8_t> src((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
     if (src.empty()) continue;
+    try {
+      deferred_batches += CompareDeferredWithHost(src);
+    } catch (const std::exception&) {
+    }
     const size_t head = std::min<size_t>(src.size(), 1 << 16);
     for (int it = 0; it < iters; it++) {
       std::vector<uint8_t> buf = src;
@@ -198,6 +300,7 @@ int main(int argc, char** argv) {
       if (r < 0) errors++; else clean++;
     }
   }
-  std::printf("fuzz_reader: %ld clean, %ld rejected, no sanitizer report\n", clean, errors);
+  std::printf("fuzz_reader: %ld clean, %ld rejected, %ld deferred LZ4 batches equal to the host decompressor, no sanitizer report\n", clean,
+              errors, deferred_batches);
   return 0;
 }

@@ -40,8 +40,18 @@ def test_host_reader_is_clean_under_asan_and_ubsan(tmp_path, golden_dir):
         with ipc.new_file(p2, t.schema, options=ipc.IpcWriteOptions(compression=codec)) as w:
             w.write_table(t, max_chunksize=5000)
         files += [p1, p2]
+    # a flat LZ4 table whose buffers span several linked 64 KiB blocks: these record batches are DEFERRED (handed out
+    # compressed with the block tables of the GPU decompressor); the harness restates the K8 kernels and compares with liblz4
+    flat = pa.table({"k": np.arange(60000, dtype=np.int64) * 7, "z": np.zeros(60000, np.int32), "r": rng.integers(0, 1 << 60, 60000),
+                     "s": ["comment %d %s" % (i % 311, "lorem ipsum"[: i % 11]) for i in range(60000)]})
+    p3 = str(tmp_path / "flat_lz4.arrows")
+    with ipc.new_stream(p3, flat.schema, options=ipc.IpcWriteOptions(compression="lz4")) as w:
+        w.write_table(flat, max_chunksize=40000)
+    files.append(p3)
     run = subprocess.run([exe, os.environ.get("MI_SANITIZE_ITERS", "400")] + files, capture_output=True, text=True,
                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:allocator_may_return_null=1", MI_IO_THREADS="2",
                                   TMPDIR=str(tmp_path)))
     assert run.returncode == 0, (run.stdout[-1000:], run.stderr[-3000:])
+    import re
+    assert int(re.search(r"(\d+) deferred LZ4 batches", run.stdout).group(1)) >= 2, run.stdout
     assert "no sanitizer report" in run.stdout and "runtime error" not in run.stderr and "AddressSanitizer" not in run.stderr

@@ -3,11 +3,12 @@
 # Per workload three separate rocprofv3 runs of the SAME command: kernel stats, then one PMC pass per counter (counters are
 # never combined with hip/hsa/sys tracing).  Outputs land under gpurun_out/<tag>_<workload>_*; tools/profile_summary.py
 # turns them into profiles/<tag>/<workload>/.  Workloads: decode (bench.py, the headline), encode (tools/encode_bench.py,
-# BASELINE config 4), commits (tools/commits_bench.py, config 5), filter (tools/filter_bench.py, K6 + gather).
+# BASELINE config 4), commits (tools/commits_bench.py, config 5), filter (tools/filter_bench.py, K6 + gather), lz4
+# (tools/lz4_bench.py, K8 through the scan operator).
 set -eo pipefail
 tag=${1:-r02}
 shift || true
-workloads=${@:-decode encode commits filter}
+workloads=${@:-decode encode commits filter lz4}
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 for w in $workloads; do
@@ -16,6 +17,7 @@ for w in $workloads; do
     encode)  full="tools/encode_bench.py --sf 10 --per-column"; short="tools/encode_bench.py --sf 10 --rounds 3" ;;
     commits) full="tools/commits_bench.py"; short="tools/commits_bench.py" ;;
     filter)  full="tools/filter_bench.py"; short="tools/filter_bench.py" ;;
+    lz4)     full="tools/lz4_bench.py --sf 10"; short="tools/lz4_bench.py --sf 2" ;;
     *) echo "unknown workload $w"; exit 2 ;;
   esac
   p=gpurun_out/${tag}_${w}
