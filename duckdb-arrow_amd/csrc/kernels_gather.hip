@@ -1,11 +1,14 @@
-// kernels_gather.hip -- late materialisation through the selection vector (K6 + K1-K5): when a pushed-down filter has
-// produced a selection vector per 2048-row window, the projected columns are decoded for the SELECTED rows only and land
-// densely packed, in row order, at the start of the column's output array (output row of window w, selected row i =
-// sum of the counts of the windows before w + i): the chunks of the batch are then ordinary flat 2048-row vectors of
-// the surviving rows, with no selection vector.  DuckDB reaches the same vectors by slicing the scan's output with the filter's selection
-// (src/scanner/read_arrow.cpp:47-48: filter_pushdown = false, the filter runs above the scan); here the rows that fail
-// the predicate are never written (lineitem, 16 % selectivity: 158 B/row of vectors shrink to 25 B/row, and so does the
-// D2H that follows for a host consumer).
+// kernels_gather.hip -- late materialisation through the selection vector (K6 + K1-K5).
+//
+// When a pushed-down filter has produced a selection vector per 2048-row window, the projected columns are decoded for the
+// SELECTED rows only.  They land densely packed, in row order, at the start of the column's output array: output row of
+// window w, selected row i = (sum of the counts of the windows before w) + i.  The chunks of the batch are then ordinary
+// flat 2048-row vectors of the surviving rows, without a selection vector.
+//
+// DuckDB reaches the same vectors by slicing the scan's output with the filter's selection: the reference declares
+// filter_pushdown = false (src/scanner/read_arrow.cpp:47-48), so the filter runs above the scan.  Here the rows that fail
+// the predicate are never written.  lineitem at 16 % selectivity: 158 B/row of vectors shrink to 25 B/row, and so does
+// the D2H that follows for a host consumer.
 //
 // One workgroup per window (tile).  Lane r handles selected row r: source row = sel[r] (window relative, ascending), so
 // loads are monotone gathers inside a 2048-row window (every 64-byte line is touched at most once per wave pass) and
