@@ -319,7 +319,7 @@ __device__ __forceinline__ void string_bytes_to_lds(uint8_t* dst, const u32x4& s
 // tile_state[total_tiles + 1 + tile] = 0, or (1 << 63 | first output byte) of a tile left to encode_string_slow: list offsets
 // (no payload) and tiles holding a string of >= 8 MiB (32-bit positions inside a sub-block could wrap).
 constexpr uint32_t kEncBigLen = 1u << 23;
-constexpr int kEncStage5 = 8 * 1024;       // bytes per stage buffer
+constexpr int kEncStage5 = 6 * 1024;       // bytes per stage buffer
 constexpr int kEncStageBuf = kEncStage5 + 64;
 constexpr uint64_t kStateMask = (1ull << 62) - 1ull;
 
@@ -331,7 +331,9 @@ __global__ __launch_bounds__(kBlockThreads, 6) void encode_string_1p(const mi_co
   constexpr int kWaves = kBlockThreads / 64;
   static_assert(kWaves == 4, "wave totals travel as one 16-byte LDS row");
   __shared__ uint64_t s_valid[kTileRows / 64];
-  __shared__ __attribute__((aligned(16))) uint32_t s_tot[2][kWaves];
+  __shared__ uint32_t s_ex[kTileRows];          // a row's bytes after the start of its (sub-block, wave) group
+  __shared__ uint32_t s_wtot[kTileRows / 64];         // bytes of every (sub-block, wave) group: 32 of them
+  __shared__ uint32_t s_wbase[kTileRows / 64 + 1];     // ... and their exclusive prefix (+ the tile total)
   __shared__ unsigned long long s_sum[kWaves];
   __shared__ uint32_t s_tiny[kWaves];
   __shared__ int64_t s_prefix;
@@ -354,14 +356,18 @@ __global__ __launch_bounds__(kBlockThreads, 6) void encode_string_1p(const mi_co
     gptr<const uint32_t> lens = GC<uint32_t>(t.buf1) + 4 * row0 + (is_list ? 2 : 0);
     unsigned long long local = 0;
     uint32_t longest = 0;
+    // ... and, in the same pass, where every row's bytes go inside the tile: one DPP wave scan per 64 rows now, so that the
+    // encode loop below neither scans nor waits for the other waves' totals (32-bit: tiles that could wrap take the slow path)
 #pragma unroll
     for (int k = 0; k < kTileRows / kBlockThreads; k++) {
       const int r = static_cast<int>(threadIdx.x) + k * kBlockThreads;
-      if (r < n && ((s_valid[r >> 6] >> (r & 63)) & 1)) {
-        const uint32_t l = lens[4 * r];
-        local += l;
-        longest = longest > l ? longest : l;
-      }
+      uint32_t l = 0;
+      if (r < n && ((s_valid[r >> 6] >> (r & 63)) & 1)) l = lens[4 * r];
+      local += l;
+      longest = longest > l ? longest : l;
+      const uint32_t incl = wave_inclusive_scan_u32(l);
+      s_ex[r] = incl - l;
+      if (lane == 63) s_wtot[k * kWaves + wave] = incl;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) local += __shfl_down(local, d, 64);
@@ -373,13 +379,19 @@ __global__ __launch_bounds__(kBlockThreads, 6) void encode_string_1p(const mi_co
   }
   __syncthreads();
   const unsigned long long packed = s_sum[0] | s_sum[1] | s_sum[2] | s_sum[3];
-  const bool slow = is_list || (packed >> 63) != 0;  // uniform
+  const int64_t tile_total = static_cast<int64_t>((s_sum[0] & kStateMask) + (s_sum[1] & kStateMask) + (s_sum[2] & kStateMask) + (s_sum[3] & kStateMask));
+  const bool slow = is_list || (packed >> 63) != 0 || tile_total >= (int64_t(1) << 31);  // uniform
   // every string of the tile is at most 4 bytes (flags, codes): its payload is the low bytes of string_t dword 1
   const bool tiny = (s_tiny[0] & s_tiny[1] & s_tiny[2] & s_tiny[3]) != 0;  // uniform
-  const int64_t tile_total = static_cast<int64_t>((s_sum[0] & kStateMask) + (s_sum[1] & kStateMask) + (s_sum[2] & kStateMask) + (s_sum[3] & kStateMask));
   // ---- decoupled look-back over the tiles of this column (wave 0; one window = the 64 tiles before the current point)
   const uint32_t first_tile = tile_begin[ti];
   if (wave == 0) {
+    {  // exclusive prefix of the 32 group totals
+      const uint32_t v = lane < 32 ? s_wtot[lane] : 0u;
+      const uint32_t inc = wave_inclusive_scan_u32(v);
+      if (lane < 32) s_wbase[lane] = inc - v;
+      if (lane == 31) s_wbase[32] = inc;
+    }
     if (lane == 0) {
       const unsigned long long mine = (tile == first_tile ? (2ull << 62) : (1ull << 62)) | (static_cast<unsigned long long>(tile_total) & kStateMask);
       __hip_atomic_store(&tile_state[tile], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -452,14 +464,10 @@ __global__ __launch_bounds__(kBlockThreads, 6) void encode_string_1p(const mi_co
       const uint64_t p = static_cast<uint64_t>(s.z) | (static_cast<uint64_t>(s.w) << 32);
       heap_load13(heap + (p - t.ptr_base), len, W);
     }
-    // exclusive scan of the sub-block's lengths (every length is < 8 MiB here: 256 of them fit 32 bits)
-    const uint32_t incl = wave_inclusive_scan_u32(len);
-    if (lane == 63) s_tot[k & 1][wave] = incl;
-    __syncthreads();
-    const u32x4 tot = *reinterpret_cast<const u32x4*>(&s_tot[k & 1][0]);
-    const uint32_t before = (wave > 0 ? tot.x : 0u) + (wave > 1 ? tot.y : 0u) + (wave > 2 ? tot.z : 0u);
-    const uint32_t total = tot.x + tot.y + tot.z + tot.w;
-    const uint32_t ex = before + incl - len;
+    // the row's place inside the sub-block, and the sub-block's size, from the tile-wide scan above
+    const uint32_t sub0 = s_wbase[k * kWaves];
+    const uint32_t ex = s_wbase[k * kWaves + wave] - sub0 + s_ex[r];
+    const uint32_t total = s_wbase[k * kWaves + kWaves] - sub0;
     if (r < n) {
       if (large) offp64[r] = base + ex + len;
       else offp[r] = static_cast<int32_t>(base + ex + len);

@@ -108,9 +108,16 @@ __global__ __launch_bounds__(kBlockThreads) void gather_window_bases(const mi_co
     const uint32_t first = tile_begin[ti], last = tile_begin[ti + 1];
     gptr<const uint32_t> counts = GC<uint32_t>(tasks[ti].sel_count);
     int64_t carry = 0;
-    for (uint32_t base = first; base < last; base += kBlockThreads) {  // uniform
-      const uint32_t i = base + threadIdx.x;
-      const int64_t v = i < last ? static_cast<int64_t>(counts[i - first]) : 0;
+    constexpr uint32_t kPer = 8;   // consecutive windows per thread and step
+    for (uint32_t base = first; base < last; base += kBlockThreads * kPer) {  // uniform
+      const uint32_t i0 = base + threadIdx.x * kPer;
+      uint32_t c[kPer];
+      int64_t v = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < kPer; k++) {
+        c[k] = i0 + k < last ? counts[i0 + k - first] : 0u;
+        v += c[k];
+      }
       int64_t incl = v;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
@@ -126,7 +133,12 @@ __global__ __launch_bounds__(kBlockThreads) void gather_window_bases(const mi_co
         if (w < wave) before += s_wave[w];
         total += s_wave[w];
       }
-      if (i < last) window_base[i] = carry + before + incl - v;
+      int64_t at = carry + before + incl - v;
+#pragma unroll
+      for (uint32_t k = 0; k < kPer; k++) {
+        if (i0 + k < last) window_base[i0 + k] = at;
+        at += c[k];
+      }
       carry += total;
     }
   }

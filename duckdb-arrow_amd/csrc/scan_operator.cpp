@@ -307,11 +307,12 @@ void ArrowScan::InitSlot(Slot& s) {
 }
 
 // More record batches in flight / held by the caller at once (the COPY pump hands whole batches to several sink threads).
-// Only before the first batch has been requested: the read-ahead thread sizes its staging ring from the slot count.
+// Takes effect only before the first batch has been requested: the read-ahead thread sizes its staging ring from the slot
+// count (a pump that asks later works with the slots there are: it waits for a release when all of them are held).
 void ArrowScan::EnsurePipelineDepth(int depth) {
   depth = std::min(depth, 16);
   if (static_cast<int>(slots.size()) >= depth) return;
-  if (producer_started || !inflight.empty()) throw InvalidInputException("the pipeline depth can only grow before the scan has started");
+  if (producer_started || !inflight.empty()) return;   // a scan that has started keeps the depth it has
   std::vector<Slot> bigger(static_cast<size_t>(depth));
   for (size_t i = 0; i < slots.size(); i++) bigger[i] = std::move(slots[i]);
   slots = std::move(bigger);

@@ -1420,15 +1420,15 @@ int mi_writer_sink_scan(mi_writer* w, mi_scan* scan, int64_t* rows) {
       // threads.  Decided on the first batch (the scan keeps its vectors on the device until then).
       const bool fused = FusedSinkPossible(w, single);
       single->EnsurePipelineDepth(std::max(1, threads) + 4);
+      // whatever happens below, the scan hands out host vectors again afterwards
+      struct Restore { ArrowScan* s; ~Restore() { s->KeepVectorsOnDevice(false); } } restore{single};
       single->KeepVectorsOnDevice(fused);
       BatchRef first;
       if (!single->AcquireBatch(&first)) {
-        single->KeepVectorsOnDevice(false);
         if (rows) *rows = 0;
         return;
       }
       if (fused && first.chunk_rows >= group) {
-        struct Restore { ArrowScan* s; ~Restore() { s->KeepVectorsOnDevice(false); } } restore{single};
         PumpScanFused(w, single, first, group, rows);
         return;
       }
