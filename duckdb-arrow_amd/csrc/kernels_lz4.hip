@@ -42,6 +42,7 @@ namespace {
 constexpr uint32_t kLinkKnown = 0x80000000u;
 constexpr uint32_t kLinkUntouched = 0xFFFFFFFFu;
 constexpr uint32_t kResolveTileQuads = 4096;   // 16 KiB of output = 64 KiB of link words per tile
+constexpr uint32_t kLocalTileQuads = 2048;     // lz4_resolve_local: 8 KiB of output = 32 KiB of LDS per workgroup
 
 __device__ __forceinline__ void lz4_fail(uint32_t* status) { atomicOr(status, MI_ST_DECOMPRESS); }
 
@@ -345,6 +346,46 @@ __global__ __launch_bounds__(kBlockThreads) void lz4_expand(Lz4Args a) {
   if (bad) lz4_fail(a.status);
 }
 
+// Before the global rounds: every tile (8 KiB of output = 32 KiB of link words in a workgroup's LDS) follows the links
+// that stay INSIDE the tile, in LDS, until nothing moves.  The deep chains of columnar data are local -- a value copies its
+// high bytes from the value before it, thousands of times in a row -- and a hop in LDS costs a fraction of a hop through
+// L2 (three hops per global round instead of one made the rounds slower, not fewer: the gathers are what a round costs).
+// Afterwards a chain crosses at least one tile boundary per hop, so the global rounds see depths of tiles, not of bytes.
+__global__ __launch_bounds__(kBlockThreads) void lz4_resolve_local(Lz4Args a) {
+  __shared__ uint32_t s_link[4 * kLocalTileQuads];
+  gptr<uint32_t> link = GM<uint32_t>(a.link);
+  const uint64_t nquads = (a.out_size + 3) / 4;
+  const uint32_t ntiles = static_cast<uint32_t>((nquads + kLocalTileQuads - 1) / kLocalTileQuads);
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const uint64_t q0 = static_cast<uint64_t>(tile) * kLocalTileQuads;
+    const uint32_t nq = static_cast<uint32_t>(q0 + kLocalTileQuads < nquads ? kLocalTileQuads : nquads - q0);
+    const uint32_t lo = static_cast<uint32_t>(4 * q0);          // first byte position of the tile
+    bool open = false;
+    for (uint32_t q = threadIdx.x; q < nq; q += kBlockThreads) {
+      const u32x4 v = *(gptr<const u32x4>)(link + 4 * (q0 + q));
+      *reinterpret_cast<u32x4*>(&s_link[4 * q]) = v;
+      open |= !((v.x & v.y & v.z & v.w) >> 31);
+    }
+    if (!__syncthreads_or(open ? 1 : 0)) continue;   // nothing but known bytes (or untouched words): uniform
+    for (int round = 0; round < 20; round++) {        // chain depth inside a tile < 8192: 14 rounds at most
+      bool moved = false;
+      for (uint32_t i = threadIdx.x; i < 4 * nq; i += kBlockThreads) {
+        const uint32_t s = s_link[i];
+        if ((s >> 31) || s < lo) continue;            // known, or the source lies in an earlier tile
+        const uint32_t u = s_link[s - lo];             // s < position of i: inside this tile
+        if (u != s) {
+          s_link[i] = u;
+          moved = true;
+        }
+      }
+      if (!__syncthreads_or(moved ? 1 : 0)) break;
+    }
+    for (uint32_t q = threadIdx.x; q < nq; q += kBlockThreads)
+      *(gptr<u32x4>)(link + 4 * (q0 + q)) = *reinterpret_cast<const u32x4*>(&s_link[4 * q]);
+    __syncthreads();
+  }
+}
+
 // One round of pointer jumping, in place.  A thread owns 4 consecutive words; what it reads of OTHER words may be the value
 // from before this launch or one written during it -- both name a byte further back on the same chain (or the byte itself),
 // so either is right; a word is only ever written by its owner.
@@ -421,6 +462,9 @@ hipError_t LaunchLz4Decompress(const Lz4Args& a, int num_cus, hipStream_t stream
   const uint32_t grid = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(want, static_cast<uint64_t>(num_cus) * 16)));
   const uint64_t ntiles = ((a.out_size + 3) / 4 + kResolveTileQuads - 1) / kResolveTileQuads;
   const uint32_t rgrid = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(ntiles, static_cast<uint64_t>(num_cus) * 8)));
+  const uint64_t nlocal = ((a.out_size + 3) / 4 + kLocalTileQuads - 1) / kLocalTileQuads;
+  hipLaunchKernelGGL(lz4_resolve_local, dim3(static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(nlocal, static_cast<uint64_t>(num_cus) * 16)))),
+                     dim3(kBlockThreads), 0, stream, a);
   for (int r = 0; r < rounds; r++) hipLaunchKernelGGL(lz4_resolve, dim3(rgrid), dim3(kBlockThreads), 0, stream, a, r);
   hipLaunchKernelGGL(lz4_emit, dim3(grid), dim3(kBlockThreads), 0, stream, a);
   return hipGetLastError();
