@@ -173,3 +173,42 @@ def test_damaged_lz4_input_is_an_error_not_a_crash(con, tmp_path):
     # the context still works
     got, _ = _device_scan(con, path)
     assert got == [canon_python(c) for c in con.read_arrow(path).fetch_columns()]
+
+
+def test_lz4_file_list_sharded_filtered_and_compacted(con, golden_dir, tmp_path):
+    """K8 under the rest of the operator: a list of LZ4 files, record batches dealt to two ranks, a pushed-down predicate
+    with late materialisation (the gather kernels read the body the K8 kernels produced) -- equal to the same scan of the
+    uncompressed files."""
+    t = ipc.open_stream(os.path.join(golden_dir, "lineitem_sf0_01_head.arrows")).read_all()
+    packed, plain = [], []
+    third = t.num_rows // 3
+    for i in range(3):
+        part = t.slice(i * third, third if i < 2 else t.num_rows - 2 * third)
+        p1, p2 = str(tmp_path / ("part%d_lz4.arrows" % i)), str(tmp_path / ("part%d.arrows" % i))
+        _write(p1, part, 3000)
+        with ipc.new_stream(p2, part.schema) as w:
+            w.write_table(part, max_chunksize=3000)
+        packed.append(p1)
+        plain.append(p2)
+    hip = C.CDLL("libamdhip64.so")
+
+    def scan(paths, **kw):
+        rel = con.read_arrow(paths, device_resident=True, filter_compact=True, **kw).project(["l_orderkey", "l_shipdate", "l_comment", "l_quantity"])
+        rel.filter_range("l_shipdate", 8766, 9130)
+        types = [da.parse_duck_type(x) for x in rel.types]
+        got = [[] for _ in types]
+        for ch in rel.chunks():
+            keep = []
+            for ci, ty in enumerate(types):
+                got[ci].extend(da._vector_values(_mirror_device_vector(hip, ch.columns[ci], ty, ch.size, keep), ty, ch.size))
+        st = rel.stats()
+        rel.close()
+        return [canon_python(c) for c in got], st
+
+    want, _ = scan(plain)
+    assert len(want[0]) > 0
+    got, st = scan(packed)
+    assert got == want and st["lz4_batches_on_device"] == st["record_batches"] > 3
+    halves = [scan(packed, rank=r, world=2) for r in (0, 1)]
+    assert sorted(halves[0][0][0] + halves[1][0][0]) == sorted(want[0])
+    assert halves[0][1]["record_batches"] + halves[1][1]["record_batches"] == st["record_batches"]
