@@ -455,9 +455,11 @@ hipError_t LaunchLz4Decompress(const Lz4Args& a, int num_cus, hipStream_t stream
     hipLaunchKernelGGL(lz4_parse<false>, dim3(a.n_blocks), dim3(64), 0, stream, a);
   hipLaunchKernelGGL(lz4_layout, dim3((a.n_buffers + 63) / 64), dim3(64), 0, stream, a);
   hipLaunchKernelGGL(lz4_expand, dim3(a.n_blocks), dim3(kBlockThreads), 0, stream, a);
-  // chains only run backwards inside one buffer: depth < its length, rounds <= log2(length) + 1
+  // chains only run backwards inside one buffer, and after lz4_resolve_local every hop that is left crosses a boundary of
+  // its 8 KiB tiles: depth <= tiles the longest buffer touches, rounds <= log2(depth) + 1 (10 for a 3 MB buffer)
+  const uint64_t depth = a.max_buffer_len / (4 * kLocalTileQuads) + 2;
   int rounds = 2;
-  while (rounds < 33 && (1ull << (rounds - 1)) < a.max_buffer_len) rounds++;
+  while (rounds < 33 && (1ull << (rounds - 1)) < depth) rounds++;
   const uint64_t want = ((a.out_size + 3) / 4 + kBlockThreads - 1) / kBlockThreads;
   const uint32_t grid = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(want, static_cast<uint64_t>(num_cus) * 16)));
   const uint64_t ntiles = ((a.out_size + 3) / 4 + kResolveTileQuads - 1) / kResolveTileQuads;
