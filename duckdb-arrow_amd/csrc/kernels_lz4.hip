@@ -116,24 +116,28 @@ __device__ __forceinline__ Lz4Walk lz4_walk(BYTES in, uint32_t ip, uint32_t stop
   return w;
 }
 
-// One WAVE per block.  The token chain of a block is serial, but LZ4 streams re-synchronise: a walk that starts at a wrong
+// One workgroup per block.  The token chain of a block is serial, but LZ4 streams re-synchronise: a walk that starts at a wrong
 // position lands on a true token position after a few sequences and stays on the chain from there.  So the block is cut into
-// 64 segments; every lane walks its segment from a GUESSED start (the segment boundary), then from the position the lane
+// 256 segments; every lane walks its segment from a GUESSED start (the segment boundary), then from the position the lane
 // before it left its own segment at, and again while that position keeps changing.  Lane 0 starts at the true position 0, so
 // lane k is final after at most k + 1 rounds whatever the bytes are (the worst case is the serial walk); with
-// re-synchronisation everything is final after two or three rounds of ~1/64 of the block each.  Walk errors of a round that
+// re-synchronisation everything is final after two or three rounds of ~1/256 of the block each.  Walk errors of a round that
 // gets repeated mean nothing; the errors of the last round are the block's.
 typedef u32x4 u32x4_any __attribute__((aligned(1)));
 
+constexpr uint32_t kParseLanes = 256;   // segments (= threads) per block: 4 waves (512: slower, the exchange rounds cost more than the shorter walks save)
+
 template <bool IN_LDS>
-__global__ __launch_bounds__(64) void lz4_parse(Lz4Args a) {
+__global__ __launch_bounds__(kParseLanes) void lz4_parse(Lz4Args a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_block[];
+  __shared__ uint32_t s_wave[kParseLanes / 64];     // per-wave maximum / sum of the exchange in progress
+  __shared__ uint32_t s_wave2[kParseLanes / 64];
   const uint32_t bi = blockIdx.x;
-  const uint32_t lane = threadIdx.x;
+  const uint32_t L = threadIdx.x, lane = L & 63u, wave = L >> 6;
   const Lz4BlockDev b = a.blocks[bi];
   const uint32_t block_max = a.buffers[b.buffer].block_max;
-  if (b.stored) {  // the block holds its bytes as they are
-    if (lane == 0) {
+  if (b.stored) {  // the block holds its bytes as they are (uniform)
+    if (L == 0) {
       a.block_out_size[bi] = b.comp_size <= block_max ? b.comp_size : 0u;
       a.block_nseq[bi] = 0;
       if (b.comp_size > block_max) lz4_fail(a.status);
@@ -144,19 +148,19 @@ __global__ __launch_bounds__(64) void lz4_parse(Lz4Args a) {
   if (IN_LDS) {
     // the walk is a chain of dependent byte loads: from LDS they cost a fraction of an L2 round trip.  16 bytes per lane and
     // step, whatever the alignment (the compressed body is followed by >= 64 readable bytes)
-    for (uint32_t i = lane * 16; i < b.comp_size; i += 64 * 16)
+    for (uint32_t i = L * 16; i < b.comp_size; i += kParseLanes * 16)
       *reinterpret_cast<u32x4*>(s_block + i) = *(gptr<const u32x4_any>)(in + b.comp_off + i);
     __syncthreads();
   }
-  const uint32_t seg = (b.comp_size + 63) / 64;
+  const uint32_t seg = (b.comp_size + kParseLanes - 1) / kParseLanes;
   const uint32_t cap = seg / 3 + 2;               // a sequence that is not the block's last takes >= 3 bytes
-  gptr<u32x4> seq = GM<u32x4>(a.seq) + b.seq_base + lane * cap;
-  gptr<uint32_t> seq_off = GM<uint32_t>(a.seq_off) + b.seq_base + lane * cap;
+  gptr<u32x4> seq = GM<u32x4>(a.seq) + b.seq_base + L * cap;
+  gptr<uint32_t> seq_off = GM<uint32_t>(a.seq_off) + b.seq_base + L * cap;
   // positions are block-relative when the bytes come from LDS, body-relative otherwise
   const uint32_t origin = IN_LDS ? 0u : b.comp_off;
   const uint32_t end = origin + b.comp_size;
-  const uint32_t seg_end = origin + (lane + 1) * seg < end ? origin + (lane + 1) * seg : end;
-  uint32_t start = origin + lane * seg < end ? origin + lane * seg : end;
+  const uint32_t seg_end = origin + (L + 1) * seg < end ? origin + (L + 1) * seg : end;
+  uint32_t start = origin + L * seg < end ? origin + L * seg : end;
   const uint32_t seg_start = start;
   // Round 0, without storing anything: where does a walk leave this segment if it starts at the boundary, 1 byte later,
   // ... 7 bytes later?  The chain enters a segment at its first token at or after the boundary, i.e. within one sequence
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(64) void lz4_parse(Lz4Args a) {
   uint32_t stored_from = 0xFFFFFFFFu;   // start of the walk whose descriptors are in this lane's slice
   bool need = false;                    // the boundary guess is answered by known[0]
   uint32_t rounds = 0;
-  for (int round = 0; round < 66; round++) {   // <= 65 rounds by construction; the bound is for the reader
+  for (uint32_t round = 0; round < kParseLanes + 2; round++) {   // lane k is final after <= k + 1 rounds
     rounds++;
     if (need) {
       const uint32_t delta = start - seg_start;
@@ -197,18 +201,22 @@ __global__ __launch_bounds__(64) void lz4_parse(Lz4Args a) {
     }
     // the chain enters this lane's segment where the lanes before it left theirs: the furthest exit so far (a sequence
     // that spans many segments leaves the lanes in between with nothing; taking the running maximum tells all of them in
-    // one round instead of one lane per round)
+    // one round instead of one lane per round).  Inclusive maximum inside the wave, the waves before it through LDS.
     uint32_t reach = w.exit;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       const uint32_t o = __shfl_up(reach, d, 64);
       if (lane >= static_cast<uint32_t>(d) && o > reach) reach = o;
     }
+    if (lane == 63) s_wave[wave] = reach;
+    __syncthreads();
+    uint32_t before = origin;
+    for (uint32_t v = 0; v < wave; v++) before = s_wave[v] > before ? s_wave[v] : before;
     uint32_t from = __shfl_up(reach, 1, 64);
-    if (lane == 0) from = origin;
+    if (lane == 0 || before > from) from = before;
     need = from != start;
     start = from;
-    if (!__any(need)) break;
+    if (!__syncthreads_or(need ? 1 : 0)) break;   // also: s_wave may be written again
   }
   // the descriptors of the final walk (answers that came from the look-up table stored none)
   if (start >= seg_end) {
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(64) void lz4_parse(Lz4Args a) {
     else w = lz4_walk<true>(in, start, seg_end, end, block_max, seq, seq_off, cap, 0u);
   }
   if (!w.ok) lz4_fail(a.status);
-  if (lane == 0) {   // how well the speculation worked (mi_scan_stats)
+  if (L == 0) {   // how well the speculation worked (mi_scan_stats)
     atomicMax(&a.round_left[38], rounds);
     atomicAdd(&a.round_left[39], rounds);
     atomicAdd(&a.round_left[37], 1u);
@@ -235,23 +243,44 @@ __global__ __launch_bounds__(64) void lz4_parse(Lz4Args a) {
       out_before += s2;
     }
   }
-  const uint32_t total_seq = __shfl(seq_before, 63, 64), total_out = __shfl(out_before, 63, 64);
-  const bool all_ok = !__any(!w.ok) && total_out <= block_max;
+  if (lane == 63) {
+    s_wave[wave] = seq_before;
+    s_wave2[wave] = out_before;
+  }
+  const bool any_bad = __syncthreads_or(w.ok ? 0 : 1) != 0;
+  uint32_t total_seq = 0, total_out = 0;
+  for (uint32_t v = 0; v < kParseLanes / 64; v++) {
+    if (v < wave) {
+      seq_before += s_wave[v];
+      out_before += s_wave2[v];
+    }
+    total_seq += s_wave[v];
+    total_out += s_wave2[v];
+  }
+  const bool all_ok = !any_bad && total_out <= block_max;
   seq_before -= w.nseq;
   out_before -= w.olen;
   gptr<u32x4> cseq = GM<u32x4>(a.cseq) + b.seq_base;
   gptr<uint32_t> cseq_off = GM<uint32_t>(a.cseq_off) + b.seq_base;
   if (all_ok) {
-    for (uint32_t i = 0; i < w.nseq; i++) {
+    uint32_t i = 0;
+    for (; i + 4 <= w.nseq; i += 4) {   // four independent loads in flight: the slice was written moments ago, it is an L2 round trip each
+      u32x4 d0 = seq[i], d1 = seq[i + 1], d2 = seq[i + 2], d3 = seq[i + 3];
+      const uint32_t o0 = seq_off[i], o1 = seq_off[i + 1], o2 = seq_off[i + 2], o3 = seq_off[i + 3];
+      d0.x += out_before; d1.x += out_before; d2.x += out_before; d3.x += out_before;
+      cseq[seq_before + i] = d0; cseq[seq_before + i + 1] = d1; cseq[seq_before + i + 2] = d2; cseq[seq_before + i + 3] = d3;
+      cseq_off[seq_before + i] = o0; cseq_off[seq_before + i + 1] = o1; cseq_off[seq_before + i + 2] = o2; cseq_off[seq_before + i + 3] = o3;
+    }
+    for (; i < w.nseq; i++) {
       u32x4 d = seq[i];
       d.x += out_before;
       cseq[seq_before + i] = d;
       cseq_off[seq_before + i] = seq_off[i];
     }
-  } else if (total_out > block_max && lane == 0) {
+  } else if (total_out > block_max && L == 0) {
     lz4_fail(a.status);
   }
-  if (lane == 0) {
+  if (L == 0) {
     a.block_out_size[bi] = all_ok ? total_out : 0u;
     a.block_nseq[bi] = all_ok ? total_seq : 0u;
   }
@@ -450,9 +479,9 @@ hipError_t LaunchLz4Decompress(const Lz4Args& a, int num_cus, hipStream_t stream
   if (a.n_blocks == 0) return hipSuccess;
   // compressed blocks below 64 KiB (64 KiB is the default block size of every writer) are walked from an LDS copy
   if (a.max_block_comp + 32u <= (64u << 10))   // 64 KiB of LDS per workgroup without opting in to more
-    hipLaunchKernelGGL(lz4_parse<true>, dim3(a.n_blocks), dim3(64), ((a.max_block_comp + 15u) & ~15u) + 16u, stream, a);
+    hipLaunchKernelGGL(lz4_parse<true>, dim3(a.n_blocks), dim3(kParseLanes), ((a.max_block_comp + 15u) & ~15u) + 16u, stream, a);
   else
-    hipLaunchKernelGGL(lz4_parse<false>, dim3(a.n_blocks), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(lz4_parse<false>, dim3(a.n_blocks), dim3(kParseLanes), 0, stream, a);
   hipLaunchKernelGGL(lz4_layout, dim3((a.n_buffers + 63) / 64), dim3(64), 0, stream, a);
   hipLaunchKernelGGL(lz4_expand, dim3(a.n_blocks), dim3(kBlockThreads), 0, stream, a);
   // chains only run backwards inside one buffer, and after lz4_resolve_local every hop that is left crosses a boundary of
