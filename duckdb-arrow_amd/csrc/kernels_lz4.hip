@@ -325,9 +325,28 @@ __global__ __launch_bounds__(kBlockThreads) void lz4_expand(Lz4Args a) {
   gptr<const uint32_t> seq_off = GC<uint32_t>(a.cseq_off) + b.seq_base;
   const bool aligned = (base & 3u) == 0;
   bool bad = false;
+  // every 16th sequence's output position in LDS: the search runs there (LDS latency) and finishes with <= 4 probes of the
+  // descriptors themselves (L2 latency) instead of 13 of those
+  constexpr uint32_t kCoarse = 16;
+  __shared__ uint32_t s_pos[(64u << 10) / 3 / kCoarse + 8];   // a 64 KiB block holds < 21846 sequences
+  const uint32_t ncoarse = (nseq + kCoarse - 1) / kCoarse;
+  const bool use_lds = ncoarse <= sizeof(s_pos) / sizeof(s_pos[0]);   // uniform; larger blocks (4 MiB frames) search the descriptors
+  if (use_lds) {
+    for (uint32_t i = threadIdx.x; i < ncoarse; i += kBlockThreads) s_pos[i] = seq[i * kCoarse].x;
+    __syncthreads();
+  }
   for (uint32_t p0 = threadIdx.x * 4; p0 < n_out; p0 += kBlockThreads * 4) {
     // last sequence that starts at or before p0 (the first one starts at 0)
     uint32_t lo = 0, hi = nseq;
+    if (use_lds) {
+      uint32_t clo = 0, chi = ncoarse;
+      while (chi - clo > 1) {
+        const uint32_t mid = (clo + chi) >> 1;
+        if (s_pos[mid] <= p0) clo = mid; else chi = mid;
+      }
+      lo = clo * kCoarse;
+      hi = lo + kCoarse < nseq ? lo + kCoarse : nseq;
+    }
     while (hi - lo > 1) {
       const uint32_t mid = (lo + hi) >> 1;
       if (seq[mid].x <= p0) lo = mid; else hi = mid;
