@@ -712,7 +712,7 @@ class Connection:
                                 # None = the library's default (on for device-resident consumers), False = never
                                 zero_copy_direct=0 if zero_copy_direct is None else (1 if zero_copy_direct else -1),
                                 unset_all_valid=int(unset_all_valid), filter_compact=int(filter_compact),
-                                pipeline_depth=int(pipeline_depth), host_decompress=int(host_decompress))
+                                pipeline_depth=int(pipeline_depth), host_decompress=(-1 if host_decompress == "gpu" else int(bool(host_decompress))))
 
     def read_arrow(self, paths, contexts=None, **options):
         """FROM read_arrow('file') / read_arrow(['a', 'b']) / read_arrow('dir/*.arrow') (globs expanded here).

@@ -90,7 +90,8 @@ ArrowScan::~ArrowScan() {
     if (s.d_comp) (void)hipFree(s.d_comp);
     if (s.d_lz4) (void)hipFree(s.d_lz4);
     if (s.h_lz4) (void)hipHostFree(s.h_lz4);
-    if (s.lz4_stream) (void)hipStreamDestroy(s.lz4_stream);
+    if (s.h_mirror) (void)hipHostFree(s.h_mirror);
+    if (s.lz4_stream && !s.lz4_stream_shared) (void)hipStreamDestroy(s.lz4_stream);
     if (s.lz4_done) (void)hipEventDestroy(s.lz4_done);
     if (s.h2d_done) (void)hipEventDestroy(s.h2d_done);
     if (s.compute_done) (void)hipEventDestroy(s.compute_done);
@@ -121,9 +122,11 @@ void ArrowScan::OpenSource(size_t i) {
     s.reader = std::make_unique<IPCFileStreamReader>(s.path);
     if (opts.hive_partitioning) s.hive = ParseHive(s.path);
   }
-  // LZ4_FRAME bodies stay compressed until they are in HBM when the consumer is on the device too (host consumers need the
-  // decompressed string payloads in host memory: their record batches are decompressed by the reader's host threads)
-  s.reader->SetDeferLz4(opts.host_decompress == 0 && opts.device_resident != 0);
+  // LZ4_FRAME bodies stay compressed until they are in HBM (K8) when the consumer is on the device too.  A host consumer can
+  // ask for it (host_decompress = -1: the string payloads come back beside the vectors, Slot::h_mirror), but by default its
+  // bodies are decompressed by the reader's host threads: on this platform D2H copies run as copy kernels, which then
+  // queue up with the K8 kernels instead of overlapping them (SF10: 0.85 s against 0.68 s, tools/lz4_bench.py)
+  s.reader->SetDeferLz4(opts.host_decompress < 0 || (opts.host_decompress == 0 && opts.device_resident != 0));
   s.reader->GetBaseSchema();
   s.opened = true;
 }
@@ -490,7 +493,15 @@ void ArrowScan::EnqueueBatch(Slot& s) {
   PlannerOptions po;
   po.array_align = kAlign;
   const bool zero_copy = opts.zero_copy_direct > 0 || (opts.zero_copy_direct == 0 && opts.device_resident);
-  po.zero_copy_direct = zero_copy && !agg.on && !s.compact;
+  // a host consumer of a body that only exists decompressed in HBM: string_t rows point into a pinned mirror of the body
+  const bool mirror = b.deferred && !opts.device_resident;
+  po.zero_copy_direct = zero_copy && !agg.on && !s.compact && !mirror;
+  if (mirror && static_cast<size_t>(b.body_size) + 64 > s.h_mirror_cap) {
+    if (s.h_mirror) MI_HIP_CHECK(hipHostFree(s.h_mirror));
+    s.h_mirror = nullptr;
+    s.h_mirror_cap = RoundUp(std::max(static_cast<size_t>(b.body_size) + 64, s.h_mirror_cap + s.h_mirror_cap / 2), 1 << 16);
+    MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.h_mirror), s.h_mirror_cap, hipHostMallocDefault));
+  }
   po.unset_all_valid = opts.unset_all_valid != 0;
   s.planner.opts = po;
   s.planner.Clear();
@@ -502,7 +513,8 @@ void ArrowScan::EnqueueBatch(Slot& s) {
   BatchPlacement where;
   where.batch = &b;
   where.in_base = s.d_in;
-  where.consumer_base = opts.device_resident ? reinterpret_cast<uint64_t>(s.d_in) : reinterpret_cast<uint64_t>(b.body);
+  where.consumer_base = opts.device_resident ? reinterpret_cast<uint64_t>(s.d_in)
+                                             : reinterpret_cast<uint64_t>(mirror ? s.h_mirror : b.body);
   where.dict_len = [&](int64_t id) -> int64_t {
     auto it = dicts.find(id);
     if (it == dicts.end()) throw IOException("RecordBatch uses dictionary id " + std::to_string(id) + " before its DictionaryBatch");
@@ -581,6 +593,22 @@ void ArrowScan::EnqueueBatch(Slot& s) {
   s.h_status[2] = 0;
   if (b.deferred) {
     EnqueueLz4(s);   // compressed body -> HBM -> K8 kernels -> d_in; ctx->stream waits for them
+    if (mirror) {    // the payload of every string-like buffer goes back to the host as soon as it is decompressed
+      for (const DecodedNode& nd : b.nodes) {
+        if (!nd.field) continue;
+        size_t first = 0, last = 0;   // spans [first, last) hold bytes that string_t rows point at
+        switch (nd.field->type) {
+          case MI_AT_UTF8: case MI_AT_BINARY: case MI_AT_LARGE_UTF8: case MI_AT_LARGE_BINARY: first = 2; last = 3; break;
+          case MI_AT_FIXED_BINARY: first = 1; last = 2; break;
+          case MI_AT_UTF8_VIEW: case MI_AT_BINARY_VIEW: first = 2; last = nd.spans.size(); break;
+          default: break;
+        }
+        for (size_t k = first; k < last && k < nd.spans.size(); k++)
+          if (nd.spans[k].length > 0)
+            MI_HIP_CHECK(hipMemcpyAsync(s.h_mirror + nd.spans[k].offset, s.d_in + nd.spans[k].offset, static_cast<size_t>(nd.spans[k].length),
+                                        hipMemcpyDeviceToHost, ctx->d2h_stream));
+      }
+    }
   } else {
   // ---- H2D of the body on the copy stream: only what the kernels read (projected columns; with zero_copy_direct not even
   // all of those): merge the buffer ranges, gaps below 64 KiB are cheaper to copy than to split.  A full scan is one copy.
@@ -739,7 +767,19 @@ void ArrowScan::EnqueueLz4(Slot& s) {
   const DecodedBatch& b = s.batch;
   const DeferredLz4Body& d = *b.deferred;
   if (!s.lz4_stream) {
-    MI_HIP_CHECK(hipStreamCreateWithFlags(&s.lz4_stream, hipStreamNonBlocking));
+    // the slots share kLz4Streams streams (slot i uses stream i mod 3): the K8 kernels of neighbouring record batches overlap
+    // -- the token walk is latency-bound and leaves the chip idle -- without every slot holding a hardware queue of its own
+    // (one stream: 0.65 s for SF10, two 0.42, three 0.39, one per slot (8) 0.46)
+    constexpr int kLz4Streams = 3;
+    const int idx = static_cast<int>(&s - slots.data());
+    if (idx >= kLz4Streams) {
+      Slot& owner = slots[static_cast<size_t>(idx % kLz4Streams)];
+      if (!owner.lz4_stream) MI_HIP_CHECK(hipStreamCreateWithFlags(&owner.lz4_stream, hipStreamNonBlocking));
+      s.lz4_stream = owner.lz4_stream;
+      s.lz4_stream_shared = true;
+    } else {
+      MI_HIP_CHECK(hipStreamCreateWithFlags(&s.lz4_stream, hipStreamNonBlocking));
+    }
     MI_HIP_CHECK(hipEventCreateWithFlags(&s.lz4_done, hipEventDisableTiming));
   }
   const size_t out_size = static_cast<size_t>(b.body_size);
@@ -881,7 +921,8 @@ void ArrowScan::EnqueueStageB(Slot& s) {
   BatchPlacement where;
   where.batch = &b;
   where.in_base = s.d_in;
-  where.consumer_base = opts.device_resident ? reinterpret_cast<uint64_t>(s.d_in) : reinterpret_cast<uint64_t>(b.body);
+  where.consumer_base = opts.device_resident ? reinterpret_cast<uint64_t>(s.d_in)
+                                             : reinterpret_cast<uint64_t>(b.deferred ? s.h_mirror : b.body);
   where.alloc_rows = total;
   where.dict_len = [&](int64_t id) -> int64_t {
     auto it = dicts.find(id);

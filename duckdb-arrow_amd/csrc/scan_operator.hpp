@@ -200,7 +200,10 @@ class ArrowScan : public ScanBase {
     uint8_t* h_lz4 = nullptr;   size_t h_lz4_cap = 0;  // pinned copy of the tables
     hipStream_t lz4_stream = nullptr;                  // decompression of this slot overlaps the other slots' copies and kernels
     hipEvent_t lz4_done = nullptr;
+    uint8_t* h_mirror = nullptr; size_t h_mirror_cap = 0;   // host consumers: pinned image of the decompressed body; only the
+                                                            // string payload buffers are filled (D2H), string_t rows point into it
     bool lz4_counted = true;
+    bool lz4_stream_shared = false;
     bool needs_stage_b = false;                        // compaction: the gather + copy back wait for the counts
     uint8_t* compact_region = nullptr;                 // device address of the dense arrays
   };

@@ -460,8 +460,11 @@ typedef struct mi_scan_options {
                                  * predicate are never decoded or copied back); 0 = full vectors + a selection vector.
                                  * Needs flat projected columns (no nested types, no string views). */
   int32_t pipeline_depth;       /* record batches in flight on the GPU (pinned + HBM slots); 0 = 3 */
-  int32_t host_decompress;      /* compressed bodies: 1 = decompress on host threads before the H2D; 0 = ship the compressed
-                                 * body over PCIe and decompress it in HBM where a GPU decoder exists (LZ4_FRAME), else host */
+  int32_t host_decompress;      /* LZ4_FRAME bodies: 0 = auto: a device-resident consumer gets the compressed body shipped over
+                                 * PCIe and decompressed in HBM (K8), a host consumer has it decompressed by the reader's host
+                                 * threads; 1 = host threads always; -1 = K8 also for host consumers (string payloads are copied
+                                 * back beside the vectors).  ZSTD bodies, dictionary batches, big-endian streams and record
+                                 * batches with list columns always take the host threads. */
   int32_t _reserved[3];
 } mi_scan_options;
 

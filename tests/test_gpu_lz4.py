@@ -68,9 +68,15 @@ def test_lz4_bodies_decompressed_in_hbm_equal_the_host_decompressor(con, tmp_pat
     name, table, chunk = next(t for t in _tables() if t[0] == case)
     path = str(tmp_path / (name + ".arrows"))
     _write(path, table, chunk)
-    want = [canon_python(c) for c in con.read_arrow(path, accept_dictionaries=True).fetch_columns()]   # liblz4 on host threads
+    want = [canon_python(c) for c in con.read_arrow(path, accept_dictionaries=True, host_decompress=True).fetch_columns()]   # liblz4 on host threads
     got, st = _device_scan(con, path)
     assert got == want
+    # a host consumer can take the K8 path too (host_decompress = -1): vectors and the string payloads (a pinned mirror of the
+    # body) come back; by default its bodies are decompressed by the reader's host threads
+    assert con.read_arrow(path, accept_dictionaries=True).count(detail=True)["rows"] == table.num_rows
+    rel = con.read_arrow(path, accept_dictionaries=True, host_decompress="gpu")
+    assert [canon_python(c) for c in rel.fetch_columns()] == want
+    assert (rel.stats()["lz4_batches_on_device"] > 0) == (st["lz4_batches_on_device"] > 0)
     batches = len(list(ipc.open_stream(path)))
     nonempty = sum(1 for b in ipc.open_stream(path) if b.num_rows > 0)
     assert st["record_batches"] == batches
@@ -86,9 +92,10 @@ def test_lz4_golden_files_and_projection(con, golden_dir, tmp_path):
         t = ipc.open_stream(os.path.join(golden_dir, rel_path)).read_all()
         path = str(tmp_path / ("lz4_" + rel_path))
         _write(path, t, 4096)
-        want = [canon_python(c) for c in con.read_arrow(path, accept_dictionaries=True).fetch_columns()]
+        want = [canon_python(c) for c in con.read_arrow(path, accept_dictionaries=True, host_decompress=True).fetch_columns()]
         got, st = _device_scan(con, path)
         assert got == want, rel_path
+        assert [canon_python(c) for c in con.read_arrow(path, accept_dictionaries=True, host_decompress="gpu").fetch_columns()] == want, rel_path
         # list / map columns keep the host decompressor: the planner samples their offsets on the host
         assert (st["lz4_batches_on_device"] > 0) == (rel_path != "edge_nested.arrows"), rel_path
     # projection: only the projected columns' frames cross PCIe
@@ -97,7 +104,7 @@ def test_lz4_golden_files_and_projection(con, golden_dir, tmp_path):
     _write(path, t, 4096)
     hip = C.CDLL("libamdhip64.so")
     rel = con.read_arrow(path, device_resident=True).project(["l_shipdate", "l_comment"])
-    want = con.read_arrow(path).project(["l_shipdate", "l_comment"]).fetch_columns()
+    want = con.read_arrow(path, host_decompress=True).project(["l_shipdate", "l_comment"]).fetch_columns()
     types = [da.parse_duck_type(x) for x in rel.types]
     got = [[] for _ in types]
     for ch in rel.chunks():
@@ -172,7 +179,7 @@ def test_damaged_lz4_input_is_an_error_not_a_crash(con, tmp_path):
     assert "error" in outcomes
     # the context still works
     got, _ = _device_scan(con, path)
-    assert got == [canon_python(c) for c in con.read_arrow(path).fetch_columns()]
+    assert got == [canon_python(c) for c in con.read_arrow(path, host_decompress=True).fetch_columns()]
 
 
 def test_lz4_file_list_sharded_filtered_and_compacted(con, golden_dir, tmp_path):
