@@ -437,7 +437,8 @@ class Relation:
         """Pushed-down predicate tree (mi_scan_set_filter).  `expr` is nested tuples:
             ("and", e1, e2, ...) | ("or", e1, e2, ...) | (column, op, value) with op in = <> != < <= > >= |
             (column, "in", [values]) | (column, "is null") | (column, "is not null")
-        Constants are the stored integers.  NULL semantics are SQL's: a comparison with NULL is not true."""
+        Constants are the stored integers, or str / bytes for VARCHAR / BLOB columns (= <> in only).  NULL semantics are
+        SQL's: a comparison with NULL is not true."""
         ops = {"=": _ffi.F_EQ, "==": _ffi.F_EQ, "<>": _ffi.F_NE, "!=": _ffi.F_NE, "<": _ffi.F_LT, "<=": _ffi.F_LE,
                ">": _ffi.F_GT, ">=": _ffi.F_GE, "is null": _ffi.F_IS_NULL, "is not null": _ffi.F_IS_NOT_NULL, "in": _ffi.F_IN}
         nodes, keep = [None], []
@@ -453,10 +454,21 @@ class Relation:
                 return
             col, op = e[0], e[1].lower()
             n = _ffi.FilterNode(op=ops[op], column=col.encode())
-            if op == "in":
+            as_bytes = lambda v: v.encode() if isinstance(v, str) else bytes(v)
+            if op == "in" and len(e[2]) > 0 and isinstance(e[2][0], (str, bytes)):
+                vals = [as_bytes(v) for v in e[2]]
+                ptrs = (C.c_char_p * len(vals))(*vals)
+                lens = (C.c_int32 * len(vals))(*[len(v) for v in vals])
+                keep.extend([vals, ptrs, lens])
+                n.str_values, n.str_lens, n.n_values = ptrs, lens, len(vals)
+            elif op == "in":
                 arr = (C.c_int64 * max(len(e[2]), 1))(*[int(v) for v in e[2]])
                 keep.append(arr)
                 n.values, n.n_values = arr, len(e[2])
+            elif op not in ("is null", "is not null") and isinstance(e[2], (str, bytes)):
+                v = as_bytes(e[2])
+                keep.append(v)
+                n.str_value, n.str_len = v, len(v)
             elif op not in ("is null", "is not null"):
                 n.value = int(e[2])
             nodes[at] = n

@@ -83,7 +83,9 @@ class RangeFilter(C.Structure):
 
 class FilterNode(C.Structure):
     _fields_ = [("op", C.c_int32), ("first_child", C.c_int32), ("n_children", C.c_int32), ("n_values", C.c_int32),
-                ("column", C.c_char_p), ("value", C.c_int64), ("values", C.POINTER(C.c_int64))]
+                ("column", C.c_char_p), ("value", C.c_int64), ("values", C.POINTER(C.c_int64)),
+                ("str_value", C.c_char_p), ("str_len", C.c_int32), ("_pad", C.c_int32),
+                ("str_values", C.POINTER(C.c_char_p)), ("str_lens", C.POINTER(C.c_int32))]
 
 
 F_EQ, F_NE, F_LT, F_LE, F_GT, F_GE, F_IS_NULL, F_IS_NOT_NULL, F_IN, F_AND, F_OR = 1, 2, 3, 4, 5, 6, 7, 8, 9, 16, 17

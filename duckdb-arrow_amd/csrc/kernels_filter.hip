@@ -74,6 +74,48 @@ __device__ __forceinline__ void leaf_compare(const FilterLeafDev& L, int64_t fir
   }
 }
 
+// kLeafStrIn: the column is a decoded string_t vector (16 bytes per row; strings of <= 12 bytes sit inline, zero padded, longer
+// ones hold a 4-byte prefix and a pointer into the Arrow data buffer).  A row equals a constant of <= 12 bytes exactly when
+// the four dwords are equal; a longer constant needs equal length and prefix, then the bytes behind the pointer (L.lo = the
+// device copy of the data buffer, L.hi = the pointer value of its byte 0).  One window at a time: 8 rows are 32 registers.
+__device__ __forceinline__ void leaf_strin(const FilterLeafDev& L, int64_t first_window, int64_t nrows, int r, uint32_t (&m)[kFilterWindows]) {
+  gptr<const u32x4> rows = GC<u32x4>(L.data);
+  gptr<const uint8_t> heap = GC<uint8_t>(reinterpret_cast<const void*>(static_cast<uintptr_t>(L.lo)));
+  const uint64_t ptr_base = static_cast<uint64_t>(L.hi);
+#pragma clang loop unroll(disable)
+  for (int w = 0; w < kFilterWindows; w++) {
+    const int64_t row0 = (first_window + w) * kTileRows;
+    const int64_t left = nrows - row0;
+    const int n = left < kTileRows ? static_cast<int>(left < 0 ? 0 : left) : kTileRows;
+    u32x4 s[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const u32x4 zero = {0u, 0u, 0u, 0u};
+      s[k] = r + k < n ? __builtin_nontemporal_load(rows + row0 + r + k) : zero;
+    }
+    uint32_t mm = 0;
+    for (int j = 0; j < L.n_in; j++) {   // uniform: the constants arrive through scalar loads
+      const uint64_t c0 = static_cast<uint64_t>(L.in_values[3 * j]), c1 = static_cast<uint64_t>(L.in_values[3 * j + 1]);
+      const uint32_t clen = static_cast<uint32_t>(c0), cw1 = static_cast<uint32_t>(c0 >> 32), cw2 = static_cast<uint32_t>(c1),
+                     cw3 = static_cast<uint32_t>(c1 >> 32);
+      gptr<const uint8_t> cbytes = GC<uint8_t>(reinterpret_cast<const void*>(static_cast<uintptr_t>(L.in_values[3 * j + 2])));
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        bool eq = s[k].x == clen && s[k].y == cw1;
+        if (clen <= 12) {
+          eq = eq && s[k].z == cw2 && s[k].w == cw3;
+        } else if (eq) {
+          const uint64_t p = static_cast<uint64_t>(s[k].z) | (static_cast<uint64_t>(s[k].w) << 32);
+          gptr<const uint8_t> a = heap + (p - ptr_base);
+          for (uint32_t i = 4; i < clen && eq; i++) eq = a[i] == cbytes[i];
+        }
+        mm |= eq ? (1u << k) : 0u;
+      }
+    }
+    m[w] = mm;
+  }
+}
+
 __global__ __launch_bounds__(kBlockThreads) void filter_program(const FilterProgram prog, int64_t nrows,
                                                                 mi_sel_t* __restrict__ sel_out_p,
                                                                 uint32_t* __restrict__ count_out_p) {
@@ -104,7 +146,8 @@ __global__ __launch_bounds__(kBlockThreads) void filter_program(const FilterProg
 #pragma unroll
       for (int w = 0; w < kFilterWindows; w++) m[w] = L.op == kLeafIsNull ? (~vb[w] & 0xFFu) : vb[w];
     } else {
-      switch (L.width) {
+      if (L.op == kLeafStrIn) leaf_strin(L, first_window, nrows, r, m);
+      else switch (L.width) {
         case 1: leaf_compare<int8_t>(L, first_window, nrows, r, m); break;
         case 2: leaf_compare<int16_t>(L, first_window, nrows, r, m); break;
         case 4: leaf_compare<int32_t>(L, first_window, nrows, r, m); break;

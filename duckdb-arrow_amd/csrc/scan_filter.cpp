@@ -24,6 +24,28 @@ FilterLeaf LeafOf(const mi_filter_node& n) {
   l.hi = kMax;
   const int64_t c = n.value;
   auto closed = [&](int64_t lo, int64_t hi) { l.lo = lo; l.hi = hi; l.lo_open = l.hi_open = false; };
+  if (n.str_value || n.str_values) {   // byte-string constants: a VARCHAR / BLOB column
+    l.is_string = true;
+    l.op = device::kLeafStrIn;
+    auto add = [&](const char* p, int32_t len) {
+      if (!p || len < 0) throw InvalidInputException("string filter constant without bytes");
+      l.str_values.emplace_back(p, static_cast<size_t>(len));
+    };
+    switch (n.op) {
+      case MI_F_EQ: add(n.str_value, n.str_len); break;
+      case MI_F_NE: add(n.str_value, n.str_len); l.negate = true; break;
+      case MI_F_IN:
+        if (n.n_values < 0 || (n.n_values > 0 && (!n.str_values || !n.str_lens))) throw InvalidInputException("IN filter without values");
+        if (n.n_values > 256) throw NotImplementedException("IN-list with more than 256 values is not pushed down");
+        for (int32_t k = 0; k < n.n_values; k++) add(n.str_values[k], n.str_lens[k]);
+        break;
+      default:
+        throw NotImplementedException("only =, <> and IN are pushed down on VARCHAR / BLOB columns (column '" + l.column + "')");
+    }
+    std::sort(l.str_values.begin(), l.str_values.end());
+    l.str_values.erase(std::unique(l.str_values.begin(), l.str_values.end()), l.str_values.end());
+    return l;
+  }
   switch (n.op) {
     case MI_F_EQ: closed(c, c); break;
     case MI_F_NE: closed(c, c); l.negate = true; break;

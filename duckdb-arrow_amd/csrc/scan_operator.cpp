@@ -257,6 +257,13 @@ void ArrowScan::Init(const std::vector<std::string>& projected) {
         }
         int32_t kind, w, nb;
         int64_t param;
+        if (leaf.is_string) {
+          // byte-string constants: the column must decode to string_t rows that point into ONE data buffer
+          if (!(sc.field.Plan(&kind, &param, &w, &nb) && !sc.field.has_dictionary && (kind == MI_K_STR32 || kind == MI_K_STR64 || kind == MI_K_FIXED_BINARY)))
+            throw NotImplementedException("string filter pushdown on column '" + sc.name + "' (" + sc.field.DuckType() +
+                                          ") needs a utf8 / large_utf8 / binary / fixed_size_binary column");
+          continue;
+        }
         const bool ok = sc.field.Plan(&kind, &param, &w, &nb) && !sc.field.has_dictionary &&
                         (kind == MI_K_COPY || kind == MI_K_DEC128 || kind == MI_K_DATE64 || kind == MI_K_MUL_I32 || kind == MI_K_MUL_I64 ||
                          kind == MI_K_DIV_I64 || kind == MI_K_NARROW || kind == MI_K_BOOL) &&
@@ -276,6 +283,29 @@ void ArrowScan::Init(const std::vector<std::string>& projected) {
         if (leaf.op == device::kLeafIn) {
           MI_HIP_CHECK(hipMalloc(&p, leaf.in_values.size() * 8));
           MI_HIP_CHECK(hipMemcpy(p, leaf.in_values.data(), leaf.in_values.size() * 8, hipMemcpyHostToDevice));
+        } else if (leaf.op == device::kLeafStrIn && !leaf.str_values.empty()) {
+          // 3 words per constant (its string_t image + the device address of its bytes), the bytes behind the table
+          const size_t nc = leaf.str_values.size();
+          size_t bytes = 0;
+          for (auto& v : leaf.str_values) bytes += RoundUp(v.size() + 1, 8);
+          std::vector<uint8_t> img(nc * 24 + bytes, 0);
+          MI_HIP_CHECK(hipMalloc(&p, img.size()));
+          size_t at = nc * 24;
+          for (size_t k = 0; k < nc; k++) {
+            const std::string& v = leaf.str_values[k];
+            if (v.size() > 0xFFFFFFFFull) throw InvalidInputException("string filter constant too long");
+            uint32_t dw[3] = {0, 0, 0};
+            std::memcpy(dw, v.data(), std::min<size_t>(v.size(), v.size() <= 12 ? 12 : 4));
+            const uint64_t w0 = static_cast<uint64_t>(v.size()) | (static_cast<uint64_t>(dw[0]) << 32);
+            const uint64_t w1 = v.size() <= 12 ? (static_cast<uint64_t>(dw[1]) | (static_cast<uint64_t>(dw[2]) << 32)) : 0;
+            const uint64_t w2 = reinterpret_cast<uint64_t>(static_cast<uint8_t*>(p) + at);
+            std::memcpy(&img[k * 24], &w0, 8);
+            std::memcpy(&img[k * 24 + 8], &w1, 8);
+            std::memcpy(&img[k * 24 + 16], &w2, 8);
+            std::memcpy(&img[at], v.data(), v.size());
+            at += RoundUp(v.size() + 1, 8);
+          }
+          MI_HIP_CHECK(hipMemcpy(p, img.data(), img.size(), hipMemcpyHostToDevice));
         }
         d_in_lists.push_back(p);
       }
@@ -676,7 +706,7 @@ void ArrowScan::EnqueueBatch(Slot& s) {
         L.lo = leaf.lo;
         L.hi = leaf.hi;
         L.in_values = static_cast<const int64_t*>(d_in_lists[li]);
-        L.n_in = static_cast<int32_t>(leaf.in_values.size());
+        L.n_in = static_cast<int32_t>(leaf.is_string ? leaf.str_values.size() : leaf.in_values.size());
         L.width = 1;
         if (root < 0) {
           // the column is absent from this file (union_by_name): every row is NULL -- IS NULL keeps every row, everything
@@ -697,6 +727,15 @@ void ArrowScan::EnqueueBatch(Slot& s) {
         L.data = pn.alias_body_off >= 0 ? static_cast<const void*>(s.d_in + pn.alias_body_off) : static_cast<const void*>(s.d_out + pn.data_off);
         L.validity = pn.valid_off >= 0 ? reinterpret_cast<const uint64_t*>(s.d_out + pn.valid_off) : nullptr;
         L.width = std::max(pn.width, 1);
+        if (leaf.is_string) {
+          // the rows' long-string pointers are consumer addresses (pn.ptr_base = byte 0 of the Arrow data buffer as the
+          // consumer sees it); the kernel reads the bytes from the HBM copy of that buffer
+          const DecodedNode& dn = b.nodes[static_cast<size_t>(pn.source_node)];
+          const size_t data_span = pn.kind == MI_K_FIXED_BINARY ? 1 : 2;
+          L.lo = static_cast<int64_t>(reinterpret_cast<uintptr_t>(s.d_in + (dn.spans.size() > data_span ? dn.spans[data_span].offset : 0)));
+          L.hi = static_cast<int64_t>(pn.ptr_base);
+          continue;
+        }
         if (sc.field.type == MI_AT_INT && !sc.field.is_signed) {
           L.flags |= device::kLeafUnsigned;
           if (pn.width == 8 && leaf.op != device::kLeafIsNull && leaf.op != device::kLeafIsNotNull) {

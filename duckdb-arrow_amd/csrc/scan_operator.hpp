@@ -49,6 +49,8 @@ struct FilterLeaf {
   bool lo_open = true, hi_open = true;  // ... where an open end has no bound at all (uint64 columns reach past INT64_MAX)
   bool negate = false;
   std::vector<int64_t> in_values;
+  bool is_string = false;         // kLeafStrIn: the column is VARCHAR / BLOB, the row passes when it equals one of ...
+  std::vector<std::string> str_values;   // ... these byte strings (negate: none of them)
   int32_t out_col = -1;           // resolved at Init: index into the scan's filter columns
 };
 //! Conjunctive normal form: every clause is an OR of leaves, the filter is the AND of its clauses.

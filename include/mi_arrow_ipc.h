@@ -530,7 +530,7 @@ typedef struct mi_data_chunk {
  * hands a scan: col <op> constant with = <> < <= > >=, IS NULL, IS NOT NULL, IN (list), combined
  * by AND / OR trees over any number of columns.  Comparison columns are fixed-width integer-like after the scan
  * (integers, BOOLEAN, DATE, TIME / TIMESTAMP, DECIMAL(<=18)) and constants are the stored integers (DECIMAL(15,2) 0.05
- * is 5); IS [NOT] NULL takes any column.  SQL semantics: a comparison with NULL is not true, so the row is dropped
+ * is 5), or VARCHAR / BLOB columns with = <> IN against byte strings; IS [NOT] NULL takes any column.  SQL semantics: a comparison with NULL is not true, so the row is dropped
  * unless another branch of an OR keeps it.  A filter column need not be projected.  The tree is normalised to at most
  * 24 leaves in conjunctive normal form; larger ones are refused with MI_ENOTSUP (DuckDB then keeps the filter above the
  * scan).  Chunks carry a selection vector (or only the selected rows: mi_scan_options.filter_compact).  Call between
@@ -547,6 +547,14 @@ typedef struct mi_filter_node {
   const char* column;     /* leaves */
   int64_t value;          /* comparison constant */
   const int64_t* values;  /* MI_F_IN */
+  /* VARCHAR / BLOB columns (utf8, large_utf8, binary, fixed_size_binary): MI_F_EQ / MI_F_NE take str_value (str_len bytes, no
+   * terminator needed), MI_F_IN takes str_values / str_lens; byte-wise equality like DuckDB's.  Leave NULL for the
+   * integer forms above.  Ordering comparisons on strings are not pushed down (MI_ENOTSUP). */
+  const char* str_value;
+  int32_t str_len;
+  int32_t _pad;
+  const char* const* str_values;
+  const int32_t* str_lens;
 } mi_filter_node;
 int mi_scan_set_filter(mi_scan* s, const mi_filter_node* nodes, int32_t n_nodes, int32_t root);
 /* Shorthand for lo <= column < hi. */

@@ -455,7 +455,37 @@ _FILTER_OPS = {"=": 1, "<>": 2, "!=": 2, "<": 3, "<=": 4, ">": 5, ">=": 6, "is n
 
 def filter_cnf(clauses, columns, n):
     """The rows [0, n) that pass AND-of-ORs `clauses` = [[(column, op, value), ...], ...] over `columns` =
-    {name: (data ndarray of the stored integers, validity uint64 words or None)} -> ascending row indices (orc_filter_cnf)."""
+    {name: (data ndarray of the stored integers, validity uint64 words or None)} -> ascending row indices (orc_filter_cnf).
+    A column may also be a python list of bytes / str / None (VARCHAR, BLOB): then the whole predicate is evaluated here,
+    row by row, with SQL's rules (a comparison with NULL is not true; = <> IN compare bytes)."""
+    if any(isinstance(columns[leaf[0]], list) or isinstance(columns[leaf[0]][0], list) for clause in clauses for leaf in clause):
+        def value(col, i):
+            c = columns[col]
+            if isinstance(c, list):
+                v = c[i]
+                return v.encode() if isinstance(v, str) else v
+            data, valid = c
+            if isinstance(data, list):
+                v = data[i]
+                return v.encode() if isinstance(v, str) else v
+            if valid is not None and not ((int(valid[i >> 6]) >> (i & 63)) & 1):
+                return None
+            return int(data[i])
+        norm = lambda c: c.encode() if isinstance(c, str) else c
+
+        def leaf_true(leaf, i):
+            v, op = value(leaf[0], i), leaf[1].lower()
+            if op == "is null":
+                return v is None
+            if op == "is not null":
+                return v is not None
+            if v is None:
+                return False
+            if op == "in":
+                return v in [norm(c) for c in leaf[2]]
+            c = norm(leaf[2])
+            return {"=": v == c, "==": v == c, "<>": v != c, "!=": v != c, "<": v < c, "<=": v <= c, ">": v > c, ">=": v >= c}[op]
+        return np.array([i for i in range(n) if all(any(leaf_true(l, i) for l in clause) for clause in clauses)], np.uint32)
     leaves, keep = [], []
     for clause in clauses:
         for j, leaf in enumerate(clause):

@@ -1,0 +1,124 @@
+"""K6 on VARCHAR / BLOB columns: =, <>, IN against byte strings, alone and inside AND / OR trees with integer leaves, with
+selection vectors and with late materialisation.  The reference pushes no filters (filter_pushdown = false,
+src/scanner/read_arrow.cpp:47-48), DuckDB's filter above the scan keeps the same rows: the check is python's own evaluation
+of the predicate over pyarrow's values, and the oracle's scalar CNF evaluator (SQL rules: a comparison with NULL is not
+true)."""
+import numpy as np
+import pyarrow as pa
+import pyarrow.ipc as ipc
+import pytest
+
+import duckdb_arrow_amd as da
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+MODES = ["MAIL", "SHIP", "AIR", "REG AIR", "TRUCK", "RAIL", "FOB"]
+INSTR = ["DELIVER IN PERSON", "COLLECT COD", "NONE", "TAKE BACK RETURN"]          # 17 / 11 / 4 / 16 bytes: inline and heap
+LONG = ["a string that is much longer than the inline twelve bytes %d" % i for i in range(5)]
+
+
+@pytest.fixture(scope="module")
+def con():
+    return da.Connection(0)
+
+
+@pytest.fixture(scope="module")
+def table():
+    rng = np.random.default_rng(12)
+    n = 30000
+    pick = lambda xs, p_null: pa.array([None if rng.random() < p_null else xs[int(rng.integers(0, len(xs)))] for _ in range(n)])
+    return pa.table({
+        "k": pa.array(np.arange(n, dtype=np.int64)),
+        "mode": pick(MODES, 0.05),
+        "instr": pick(INSTR, 0.1),
+        "flag": pa.array([None if rng.random() < 0.02 else "ANR"[int(rng.integers(0, 3))] for _ in range(n)]),
+        "long": pick(LONG + ["a string that is much longer than the inline twelve bytes X", ""], 0.1).cast(pa.large_string()),
+        "blob": pa.array([None if rng.random() < 0.1 else bytes(rng.integers(0, 3, 3, dtype=np.uint8)) for _ in range(n)], pa.binary(3)),
+        "q": pa.array(rng.integers(0, 50, n).astype(np.int32)),
+    })
+
+
+def _eval(expr, cols, i):
+    if expr[0] in ("and", "or") and isinstance(expr[1], tuple):
+        rs = [_eval(e, cols, i) for e in expr[1:]]
+        return all(rs) if expr[0] == "and" else any(rs)
+    v, op = cols[expr[0]][i], expr[1]
+    if op == "is null":
+        return v is None
+    if op == "is not null":
+        return v is not None
+    if v is None:
+        return False
+    norm = lambda c: c.encode() if isinstance(c, str) else c
+    v = norm(v)
+    if op == "in":
+        return v in [norm(c) for c in expr[2]]
+    c = norm(expr[2])
+    return {"=": v == c, "<>": v != c, "<": v < c, ">=": v >= c}[op]
+
+
+EXPRS = [
+    ("mode", "=", "MAIL"), ("mode", "<>", "MAIL"), ("mode", "in", ["MAIL", "SHIP"]), ("mode", "in", ["REG AIR", "nothing", ""]),
+    ("instr", "=", "DELIVER IN PERSON"), ("instr", "<>", "DELIVER IN PERSON"), ("instr", "in", ["TAKE BACK RETURN", "NONE", "DELIVER IN PERSO"]),
+    ("flag", "=", "R"), ("flag", "in", ["A", "N"]), ("flag", "=", ""), ("long", "=", LONG[3]), ("long", "in", [LONG[0], LONG[4], ""]),
+    ("long", "<>", "a string that is much longer than the inline twelve bytes X"), ("long", "=", "a string that is much longer"),
+    ("blob", "=", b"\x00\x01\x02"), ("blob", "in", [b"\x00\x00\x00", b"\x02\x02\x02"]),
+    ("and", ("mode", "in", ["MAIL", "SHIP"]), ("q", "<", 24), ("instr", "=", "DELIVER IN PERSON")),          # TPC-H Q12 / Q19 shapes
+    ("or", ("flag", "=", "R"), ("and", ("mode", "=", "AIR"), ("q", ">=", 40)), ("instr", "is null")),
+    ("and", ("or", ("mode", "=", "FOB"), ("mode", "is null")), ("long", "<>", LONG[1])),
+]
+
+
+@pytest.mark.parametrize("expr", EXPRS, ids=[str(e)[:70] for e in EXPRS])
+@pytest.mark.parametrize("compact", [False, True])
+def test_string_predicates_equal_python_and_the_oracle(con, table, tmp_path_factory, expr, compact):
+    path = str(tmp_path_factory.mktemp("sflt") / "t.arrows")
+    with ipc.new_stream(path, table.schema) as w:
+        w.write_table(table, max_chunksize=7000)
+    cols = {name: table.column(name).to_pylist() for name in table.column_names}
+    want = [i for i in range(table.num_rows) if _eval(expr, cols, i)]
+    rel = con.read_arrow(path, filter_compact=compact).project(["k", "instr", "long"]).filter(expr)
+    got_k, got_instr, got_long = rel.fetch_columns()
+    assert got_k == want
+    assert got_instr == [cols["instr"][i] for i in want] and got_long == [cols["long"][i] for i in want]
+    # the oracle's evaluator over the same values, for trees that are already AND-of-ORs
+    def cnf(e):
+        if e[0] == "and" and isinstance(e[1], tuple):
+            return [c for kid in e[1:] for c in cnf(kid)]
+        if e[0] == "or" and isinstance(e[1], tuple):
+            if all(not (k[0] in ("and", "or") and isinstance(k[1], tuple)) for k in e[1:]):
+                return [list(e[1:])]
+            raise ValueError
+        return [[e]]
+    try:
+        clauses = cnf(expr)
+    except ValueError:
+        clauses = None
+    if clauses is not None:
+        assert po.filter_cnf(clauses, {name: cols[name] for name in table.column_names}, table.num_rows).tolist() == want
+    # count without projecting the filter columns
+    rel = con.read_arrow(path).filter(expr)
+    assert rel.count(detail=True)["selected"] == len(want)
+
+
+def test_string_filter_errors_and_other_consumers(con, table, tmp_path):
+    path = str(tmp_path / "t.arrows")
+    with ipc.new_stream(path, table.schema) as w:
+        w.write_table(table, max_chunksize=9000)
+    with pytest.raises(da.MiError) as e:      # a byte string against an integer column
+        con.read_arrow(path).filter(("q", "=", "five")).count()
+    assert e.value.code == da._ffi.MI_ENOTSUP
+    with pytest.raises(da.MiError) as e:      # an integer against a VARCHAR column
+        con.read_arrow(path).filter(("mode", "=", 5)).count()
+    assert e.value.code == da._ffi.MI_ENOTSUP
+    # device-resident consumer and an LZ4 file: the filter kernel reads the bytes the K8 kernels produced
+    packed = str(tmp_path / "t_lz4.arrows")
+    with ipc.new_stream(packed, table.schema, options=ipc.IpcWriteOptions(compression="lz4")) as w:
+        w.write_table(table, max_chunksize=9000)
+    cols = {name: table.column(name).to_pylist() for name in table.column_names}
+    expr = ("and", ("instr", "=", "DELIVER IN PERSON"), ("long", "in", [LONG[2], LONG[3]]))
+    want = sum(1 for i in range(table.num_rows) if _eval(expr, cols, i))
+    for kw in ({}, {"device_resident": True}):
+        rel = con.read_arrow(packed, **kw).filter(expr)
+        assert rel.count(detail=True)["selected"] == want
