@@ -107,7 +107,10 @@ __device__ __forceinline__ void leaf_strin(const FilterLeafDev& L, int64_t first
         } else if (eq) {
           const uint64_t p = static_cast<uint64_t>(s[k].z) | (static_cast<uint64_t>(s[k].w) << 32);
           gptr<const uint8_t> a = heap + (p - ptr_base);
-          for (uint32_t i = 4; i < clen && eq; i++) eq = a[i] == cbytes[i];
+          typedef uint32_t u32_any __attribute__((aligned(1)));
+          uint32_t i = 4;
+          for (; i + 4 <= clen && eq; i += 4) eq = *(gptr<const u32_any>)(a + i) == *(gptr<const u32_any>)(cbytes + i);
+          for (; i < clen && eq; i++) eq = a[i] == cbytes[i];
         }
         mm |= eq ? (1u << k) : 0u;
       }
