@@ -87,7 +87,8 @@ struct Lz4Args {
   uint32_t* block_nseq;
   uint64_t* block_out_base;
   uint32_t* buffer_ok;            // per buffer
-  uint32_t* tile_done;            // one word per 16 KiB of the decompressed body, zeroed
+  uint8_t* mark;                  // one byte per decompressed byte (rounded up to 16), zeroed: 1 = an open word of another tile points here
+  uint32_t* skel;                 // the skeleton list: up to one entry per decompressed byte
   uint32_t* round_left;           // 40 words, zeroed
   uint32_t* status;               // MI_ST_DECOMPRESS
 };

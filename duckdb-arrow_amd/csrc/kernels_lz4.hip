@@ -41,7 +41,7 @@ namespace {
 // bit 31 clear = the position this byte copies from.  One word is one atomic message: no second array to keep in step.
 constexpr uint32_t kLinkKnown = 0x80000000u;
 constexpr uint32_t kLinkUntouched = 0xFFFFFFFFu;
-constexpr uint32_t kResolveTileQuads = 4096;   // 16 KiB of output = 64 KiB of link words per tile
+constexpr uint32_t kSkelCount = 36;            // round_left[36]: entries of the skeleton list
 constexpr uint32_t kLocalTileQuads = 2048;     // lz4_resolve_local: 8 KiB of output = 32 KiB of LDS per workgroup
 
 __device__ __forceinline__ void lz4_fail(uint32_t* status) { atomicOr(status, MI_ST_DECOMPRESS); }
@@ -428,46 +428,72 @@ __global__ __launch_bounds__(kBlockThreads) void lz4_resolve_local(Lz4Args a) {
       }
       if (!__syncthreads_or(moved ? 1 : 0)) break;
     }
-    for (uint32_t q = threadIdx.x; q < nq; q += kBlockThreads)
-      *(gptr<u32x4>)(link + 4 * (q0 + q)) = *reinterpret_cast<const u32x4*>(&s_link[4 * q]);
+    gptr<uint8_t> mark = GM<uint8_t>(a.mark);
+    for (uint32_t q = threadIdx.x; q < nq; q += kBlockThreads) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(&s_link[4 * q]);
+      *(gptr<u32x4>)(link + 4 * (q0 + q)) = v;
+      // what is still open points into an earlier tile: those target words are the SKELETON the global rounds work on
+      if (!(v.x >> 31)) mark[v.x] = 1;
+      if (!(v.y >> 31)) mark[v.y] = 1;
+      if (!(v.z >> 31)) mark[v.z] = 1;
+      if (!(v.w >> 31)) mark[v.w] = 1;
+    }
     __syncthreads();
   }
 }
 
-// One round of pointer jumping, in place.  A thread owns 4 consecutive words; what it reads of OTHER words may be the value
-// from before this launch or one written during it -- both name a byte further back on the same chain (or the byte itself),
-// so either is right; a word is only ever written by its owner.
-__global__ __launch_bounds__(kBlockThreads) void lz4_resolve(Lz4Args a, int round) {
+// The marked words that are themselves still open, as a list.  A marked word's own target was marked by it (it is an open
+// word of its tile), so the list is closed under "follow the link": pointer jumping over the list alone resolves it.
+__global__ __launch_bounds__(kBlockThreads) void lz4_collect(Lz4Args a) {
+  // a workgroup gathers the entries of one 8 KiB tile in LDS and claims its slice of the list with ONE atomic: the counter is
+  // one address for the whole launch, and same-address atomics are served one after the other (~20 ns each)
+  __shared__ uint32_t s_pos[4 * kLocalTileQuads];
+  __shared__ uint32_t s_n, s_base;
+  gptr<const uint32_t> link = GC<uint32_t>(a.link);
+  gptr<const uint32_t> mark4 = GC<uint32_t>(a.mark);   // four marks per word
+  gptr<uint32_t> skel = GM<uint32_t>(a.skel);
+  const uint64_t nquads = (a.out_size + 3) / 4;
+  const uint32_t ntiles = static_cast<uint32_t>((nquads + kLocalTileQuads - 1) / kLocalTileQuads);
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const uint64_t q0 = static_cast<uint64_t>(tile) * kLocalTileQuads;
+    const uint32_t nq = static_cast<uint32_t>(q0 + kLocalTileQuads < nquads ? kLocalTileQuads : nquads - q0);
+    for (uint32_t q = threadIdx.x; q < nq; q += kBlockThreads) {
+      const uint32_t m = mark4[q0 + q];
+      if (!m) continue;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (((m >> (8 * k)) & 0xFFu) && !(link[4 * (q0 + q) + k] >> 31)) s_pos[atomicAdd(&s_n, 1u)] = static_cast<uint32_t>(4 * (q0 + q) + k);
+    }
+    __syncthreads();
+    const uint32_t n = s_n;
+    if (n) {   // uniform
+      if (threadIdx.x == 0) s_base = atomicAdd(&a.round_left[kSkelCount], n);
+      __syncthreads();
+      const uint32_t base = s_base;
+      for (uint32_t i = threadIdx.x; i < n; i += kBlockThreads) skel[base + i] = s_pos[i];
+    }
+    __syncthreads();
+  }
+}
+
+// One round of pointer jumping over the skeleton.
+__global__ __launch_bounds__(kBlockThreads) void lz4_resolve_skeleton(Lz4Args a, int round) {
   if (round > 0 && a.round_left[round - 1] == 0) return;  // the previous round left nothing (round_left[round] stays 0)
   gptr<uint32_t> link = GM<uint32_t>(a.link);
-  const uint64_t nquads = (a.out_size + 3) / 4;
-  const uint32_t ntiles = static_cast<uint32_t>((nquads + kResolveTileQuads - 1) / kResolveTileQuads);
-  bool any_left = false;
-  // a tile (16 KiB of output) that held no open link at the end of a round is never read again: text resolves in two or
-  // three rounds, the deep chains of periodic data (each match copies the period before it) keep only their own tiles busy
-  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    if (a.tile_done[tile]) continue;   // uniform
-    bool left = false;
-    const uint64_t q0 = static_cast<uint64_t>(tile) * kResolveTileQuads;
-    const uint64_t q1 = q0 + kResolveTileQuads < nquads ? q0 + kResolveTileQuads : nquads;
-    for (uint64_t q = q0 + threadIdx.x; q < q1; q += kBlockThreads) {
-      u32x4 v = *(gptr<const u32x4>)(link + 4 * q);   // the array is padded to whole quads
-      if ((v.x & v.y & v.z & v.w) >> 31) continue;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const uint32_t s = k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
-        if (s >> 31) continue;
-        const uint32_t u = __builtin_nontemporal_load(link + s);
-        if (k == 0) v.x = u; else if (k == 1) v.y = u; else if (k == 2) v.z = u; else v.w = u;
-        if (!(u >> 31)) left = true;
-      }
-      *(gptr<u32x4>)(link + 4 * q) = v;
-    }
-    const bool tile_left = __syncthreads_or(left ? 1 : 0) != 0;
-    if (!tile_left && threadIdx.x == 0) a.tile_done[tile] = 1u;
-    any_left |= tile_left;
+  gptr<const uint32_t> skel = GC<uint32_t>(a.skel);
+  const uint32_t n = a.round_left[kSkelCount];
+  bool left = false;
+  for (uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x; i < n; i += gridDim.x * kBlockThreads) {
+    const uint32_t j = skel[i];
+    const uint32_t s = link[j];
+    if (s >> 31) continue;
+    const uint32_t u = __builtin_nontemporal_load(link + s);   // before this launch or during it: both are on the chain
+    link[j] = u;
+    if (!(u >> 31)) left = true;
   }
-  if (any_left && threadIdx.x == 0) atomicAdd(&a.round_left[round], 1u);
+  if (__syncthreads_or(left ? 1 : 0) && threadIdx.x == 0) atomicAdd(&a.round_left[round], 1u);
 }
 
 // The known bytes leave the link words for the decompressed body; words still holding kLinkUntouched belong to bytes the
@@ -476,8 +502,15 @@ __global__ __launch_bounds__(kBlockThreads) void lz4_emit(Lz4Args a) {
   gptr<const uint32_t> link = GC<uint32_t>(a.link);
   gptr<uint8_t> out = GM<uint8_t>(a.out);
   const uint64_t nquads = (a.out_size + 3) / 4;
+  bool bad = false;
   for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * kBlockThreads + threadIdx.x; q < nquads; q += static_cast<uint64_t>(gridDim.x) * kBlockThreads) {
-    const u32x4 v = *(gptr<const u32x4>)(link + 4 * q);
+    u32x4 v = *(gptr<const u32x4>)(link + 4 * q);
+    // a word that is still open names a skeleton word, and those are all known by now: the last hop happens here
+    if (!(v.x >> 31)) v.x = link[v.x];
+    if (!(v.y >> 31)) v.y = link[v.y];
+    if (!(v.z >> 31)) v.z = link[v.z];
+    if (!(v.w >> 31)) v.w = link[v.w];
+    bad |= !((v.x & v.y & v.z & v.w) >> 31);
     const bool t0 = v.x != kLinkUntouched, t1 = v.y != kLinkUntouched, t2 = v.z != kLinkUntouched, t3 = v.w != kLinkUntouched;
     if (t0 && t1 && t2 && t3 && 4 * q + 4 <= a.out_size) {
       *(gptr<uint32_t>)(out + 4 * q) = (v.x & 0xFFu) | ((v.y & 0xFFu) << 8) | ((v.z & 0xFFu) << 16) | ((v.w & 0xFFu) << 24);
@@ -488,6 +521,7 @@ __global__ __launch_bounds__(kBlockThreads) void lz4_emit(Lz4Args a) {
       if (t3 && 4 * q + 3 < a.out_size) out[4 * q + 3] = static_cast<uint8_t>(v.w);
     }
   }
+  if (bad) lz4_fail(a.status);   // never silently: a chain the rounds did not finish is an internal error, not data
 }
 
 }  // namespace
@@ -510,12 +544,12 @@ hipError_t LaunchLz4Decompress(const Lz4Args& a, int num_cus, hipStream_t stream
   while (rounds < 33 && (1ull << (rounds - 1)) < depth) rounds++;
   const uint64_t want = ((a.out_size + 3) / 4 + kBlockThreads - 1) / kBlockThreads;
   const uint32_t grid = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(want, static_cast<uint64_t>(num_cus) * 16)));
-  const uint64_t ntiles = ((a.out_size + 3) / 4 + kResolveTileQuads - 1) / kResolveTileQuads;
-  const uint32_t rgrid = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(ntiles, static_cast<uint64_t>(num_cus) * 8)));
   const uint64_t nlocal = ((a.out_size + 3) / 4 + kLocalTileQuads - 1) / kLocalTileQuads;
   hipLaunchKernelGGL(lz4_resolve_local, dim3(static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(nlocal, static_cast<uint64_t>(num_cus) * 16)))),
                      dim3(kBlockThreads), 0, stream, a);
-  for (int r = 0; r < rounds; r++) hipLaunchKernelGGL(lz4_resolve, dim3(rgrid), dim3(kBlockThreads), 0, stream, a, r);
+  hipLaunchKernelGGL(lz4_collect, dim3(static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(nlocal, static_cast<uint64_t>(num_cus) * 16)))),
+                     dim3(kBlockThreads), 0, stream, a);
+  for (int r = 0; r < rounds; r++) hipLaunchKernelGGL(lz4_resolve_skeleton, dim3(static_cast<uint32_t>(num_cus) * 4), dim3(kBlockThreads), 0, stream, a, r);
   hipLaunchKernelGGL(lz4_emit, dim3(grid), dim3(kBlockThreads), 0, stream, a);
   return hipGetLastError();
 }

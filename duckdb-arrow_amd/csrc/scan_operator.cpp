@@ -831,11 +831,11 @@ void ArrowScan::EnqueueLz4(Slot& s) {
   uint64_t total_seq = 0, max_len = 0;
   for (auto& blk : d.blocks) total_seq += device::Lz4SeqCapacity(blk.comp_size);
   const size_t o_bsize = take(nb * 4), o_bnseq = take(nb * 4), o_bbase = take(nb * 8), o_bufok = take(nf * 4), o_round = take(40 * 4),
-               o_status = take(4), o_tiles = take((out_size / 16384 + 2) * 4);
+               o_status = take(4), o_mark = take(out_size + 16);
   const size_t counters_end = at;
   const size_t o_seq = take(static_cast<size_t>(total_seq) * 16), o_seqoff = take(static_cast<size_t>(total_seq) * 4);
   const size_t o_cseq = take(static_cast<size_t>(total_seq) * 16), o_cseqoff = take(static_cast<size_t>(total_seq) * 4);
-  const size_t o_link = take(out_size * 4 + 16);
+  const size_t o_link = take(out_size * 4 + 16), o_skel = take(out_size * 4 + 16);
   if (at > s.d_lz4_cap) {
     if (s.d_lz4) MI_HIP_CHECK(hipFree(s.d_lz4));
     s.d_lz4 = nullptr;
@@ -931,7 +931,8 @@ void ArrowScan::EnqueueLz4(Slot& s) {
   a.block_out_base = reinterpret_cast<uint64_t*>(s.d_lz4 + o_bbase);
   a.buffer_ok = reinterpret_cast<uint32_t*>(s.d_lz4 + o_bufok);
   a.round_left = reinterpret_cast<uint32_t*>(s.d_lz4 + o_round);
-  a.tile_done = reinterpret_cast<uint32_t*>(s.d_lz4 + o_tiles);
+  a.mark = s.d_lz4 + o_mark;
+  a.skel = reinterpret_cast<uint32_t*>(s.d_lz4 + o_skel);
   a.status = reinterpret_cast<uint32_t*>(s.d_lz4 + o_status);
   MI_HIP_CHECK(device::LaunchLz4Decompress(a, ctx->num_cus, q));
   MI_HIP_CHECK(hipMemcpyAsync(&s.h_status[2], a.status, sizeof(uint32_t), hipMemcpyDeviceToHost, q));
