@@ -132,6 +132,8 @@ __global__ __launch_bounds__(kParseLanes) void lz4_parse(Lz4Args a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_block[];
   __shared__ uint32_t s_wave[kParseLanes / 64];     // per-wave maximum / sum of the exchange in progress
   __shared__ uint32_t s_wave2[kParseLanes / 64];
+  __shared__ uint16_t s_known[kParseLanes][8];      // every lane's look-up table, as distances from its segment boundary
+  __shared__ uint32_t s_true[kParseLanes];          // chain follow: where the chain enters each segment (or `end`)
   const uint32_t bi = blockIdx.x;
   const uint32_t L = threadIdx.x, lane = L & 63u, wave = L >> 6;
   const Lz4BlockDev b = a.blocks[bi];
@@ -176,6 +178,11 @@ __global__ __launch_bounds__(kParseLanes) void lz4_parse(Lz4Args a) {
       else known[g] = lz4_walk<false>(in, from, seg_end, end, block_max, seq, seq_off, cap, 0u).exit;
     }
   }
+#pragma unroll
+  for (uint32_t g = 0; g < 8; g++) {   // exits are < 64 KiB past the boundary (the block is), 0xFFFF = not representable
+    const uint32_t d = known[g] - seg_start;
+    s_known[L][g] = static_cast<uint16_t>(d < 0xFFFFu ? d : 0xFFFFu);
+  }
   Lz4Walk w;
   w.exit = known[0];
   w.nseq = 0;
@@ -186,6 +193,34 @@ __global__ __launch_bounds__(kParseLanes) void lz4_parse(Lz4Args a) {
   uint32_t rounds = 0;
   for (uint32_t round = 0; round < kParseLanes + 2; round++) {   // lane k is final after <= k + 1 rounds
     rounds++;
+    if (round % 6 == 5) {
+      // Still not settled: on regular numeric data the guessed walks never fall in step and the truth advances one lane per
+      // round, each round an exchange with two barriers.  But then (nearly) every answer is in the look-up tables: ONE lane
+      // follows the chain through them, a hop per segment and no barrier, as far as the tables reach.
+      s_true[L] = end;
+      __syncthreads();
+      if (L == 0) {
+        uint32_t pos = origin;
+        while (pos < end) {
+          const uint32_t k = (pos - origin) / seg;
+          s_true[k] = pos;
+          const uint32_t k0 = origin + k * seg, delta = pos - k0;
+          if (delta >= 8) break;                       // a real walk is needed from here: the rounds take over again
+          const uint32_t d = s_known[k][delta];
+          if (d == 0xFFFFu) break;
+          pos = k0 + d;
+        }
+      }
+      __syncthreads();
+      const uint32_t t = s_true[L];
+      if (t != end || start >= seg_end) {
+        // a segment the chain was followed into (or one it provably skips: nothing to do there)
+        if (t != start && t != end) {
+          start = t;
+          need = true;
+        }
+      }
+    }
     if (need) {
       const uint32_t delta = start - seg_start;
       if (start >= seg_end) {
@@ -531,7 +566,7 @@ hipError_t LaunchLz4Decompress(const Lz4Args& a, int num_cus, hipStream_t stream
   MI_DROP_STALE_ERROR();
   if (a.n_blocks == 0) return hipSuccess;
   // compressed blocks below 64 KiB (64 KiB is the default block size of every writer) are walked from an LDS copy
-  if (a.max_block_comp + 32u <= (64u << 10))   // 64 KiB of LDS per workgroup without opting in to more
+  if (a.max_block_comp + 32u + 6144u <= (64u << 10))   // 64 KiB of LDS per workgroup without opting in to more (the kernel's own tables: 5 KiB)
     hipLaunchKernelGGL(lz4_parse<true>, dim3(a.n_blocks), dim3(kParseLanes), ((a.max_block_comp + 15u) & ~15u) + 16u, stream, a);
   else
     hipLaunchKernelGGL(lz4_parse<false>, dim3(a.n_blocks), dim3(kParseLanes), 0, stream, a);
