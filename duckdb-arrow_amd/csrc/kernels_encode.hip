@@ -322,6 +322,7 @@ constexpr uint32_t kEncBigLen = 1u << 23;
 constexpr int kEncStage5 = 6 * 1024;       // bytes per stage buffer
 constexpr int kEncStageBuf = kEncStage5 + 64;
 constexpr uint64_t kStateMask = (1ull << 62) - 1ull;
+constexpr int kLookBack = 4;   // predecessors inspected per look-back step
 
 __global__ __launch_bounds__(kBlockThreads, 6) void encode_string_1p(const mi_col_task* __restrict__ tasks,
                                                                      const uint32_t* __restrict__ tile_begin,
@@ -401,7 +402,8 @@ __global__ __launch_bounds__(kBlockThreads, 6) void encode_string_1p(const mi_co
     while (hi >= static_cast<int64_t>(first_tile)) {
       const int64_t j = hi - lane;
       unsigned long long st = 2ull << 62;  // lanes past the column's first tile: a finished, empty prefix
-      if (j >= static_cast<int64_t>(first_tile)) {
+      if (lane >= kLookBack) st = 1ull << 62;   // lanes outside the step: an empty sum that ends nothing
+      else if (j >= static_cast<int64_t>(first_tile)) {
         st = __hip_atomic_load(&tile_state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // the predecessor is dispatched before this tile and publishes after one load + one scan; the bound only keeps a
         // logic error from hanging the device (~1 s), it is never reached
@@ -423,7 +425,7 @@ __global__ __launch_bounds__(kBlockThreads, 6) void encode_string_1p(const mi_co
       for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
       prefix += __shfl(v, 0, 64);
       if (done_mask) break;
-      hi -= 64;
+      hi -= kLookBack;
     }
     if (lane == 0) {
       if (tile != first_tile)
