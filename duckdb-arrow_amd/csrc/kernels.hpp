@@ -78,10 +78,10 @@ struct Lz4Args {
   const Lz4BufferDev* buffers;
   uint32_t n_blocks, n_buffers;
   uint32_t max_block_comp, _pad;  // largest compressed block
-  void* seq;                      // 16 bytes per sequence: the lanes' slices ...
+  void* seq;                      // 16 bytes per sequence, in the slices of lz4_parse's 256 lanes per block
   uint32_t* seq_off;              // 4 bytes per sequence
-  void* cseq;                     // ... and the block's sequences in order (same capacity)
-  uint32_t* cseq_off;
+  uint32_t* lane_out;             // per block and lane: output position (inside the block) its slice begins at ...
+  uint32_t* lane_nseq;            // ... and its number of sequences
   uint32_t* link;                 // 4 bytes per decompressed byte (rounded up to 16 bytes), preset to 0xFF
   uint32_t* block_out_size;       // per block
   uint32_t* block_nseq;

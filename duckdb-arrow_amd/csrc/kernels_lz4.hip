@@ -52,19 +52,22 @@ struct Lz4Walk {
   uint32_t exit;    // where the next lane's first token is (== block end when the block ends here)
   uint32_t nseq;
   uint32_t olen;    // bytes these sequences produce
+  uint32_t first8;  // bit g: the walk has a token at mark0 + g (g < 8)
   bool ok;
 };
 using lptr = const uint8_t __attribute__((address_space(3)))*;
 
 template <bool STORE, typename BYTES>   // BYTES: the compressed bytes in global memory, or the workgroup's LDS copy of the block
 __device__ __forceinline__ Lz4Walk lz4_walk(BYTES in, uint32_t ip, uint32_t stop, uint32_t end, uint32_t block_max,
-                                             gptr<u32x4> seq, gptr<uint32_t> seq_off, uint32_t cap, uint32_t lit_bias) {
+                                             gptr<u32x4> seq, gptr<uint32_t> seq_off, uint32_t cap, uint32_t lit_bias, uint32_t mark0 = 0) {
   Lz4Walk w;
   w.nseq = 0;
   w.olen = 0;
+  w.first8 = 0;
   w.ok = true;
   bool zero_offset = false;
   while (ip < stop) {
+    if (ip - mark0 < 8u) w.first8 |= 1u << (ip - mark0);
     const uint32_t token = in[ip++];
     uint32_t ll = token >> 4;
     if (ll == 15) {
@@ -164,39 +167,55 @@ __global__ __launch_bounds__(kParseLanes) void lz4_parse(Lz4Args a) {
   const uint32_t seg_end = origin + (L + 1) * seg < end ? origin + (L + 1) * seg : end;
   uint32_t start = origin + L * seg < end ? origin + L * seg : end;
   const uint32_t seg_start = start;
-  // Round 0, without storing anything: where does a walk leave this segment if it starts at the boundary, 1 byte later,
-  // ... 7 bytes later?  The chain enters a segment at its first token at or after the boundary, i.e. within one sequence
-  // length of it: for the short sequences of numeric columns (3-6 compressed bytes, and so regular that a guessed walk
-  // stays out of step for the whole block) that is one of these eight positions, and the rounds below become look-ups.
+  // a walk that stores nothing: where it leaves the segment, and which of the first 8 positions it has tokens at
+  auto probe = [&](uint32_t from, uint32_t* first8) -> uint32_t {
+    Lz4Walk r;
+    if (IN_LDS) r = lz4_walk<false>((lptr)s_block, from, seg_end, end, block_max, seq, seq_off, cap, 0u, seg_start);
+    else r = lz4_walk<false>(in, from, seg_end, end, block_max, seq, seq_off, cap, 0u, seg_start);
+    if (first8) *first8 = r.first8;
+    return r.exit;
+  };
+  uint32_t exit_at = start < seg_end ? probe(start, nullptr) : start;   // round 0: every lane from its boundary guess
+  bool have_tables = false;   // uniform
   uint32_t known[8];
 #pragma unroll
-  for (uint32_t g = 0; g < 8; g++) {
-    const uint32_t from = seg_start + g;
-    known[g] = from;
-    if (from < seg_end) {
-      if (IN_LDS) known[g] = lz4_walk<false>((lptr)s_block, from, seg_end, end, block_max, seq, seq_off, cap, 0u).exit;
-      else known[g] = lz4_walk<false>(in, from, seg_end, end, block_max, seq, seq_off, cap, 0u).exit;
-    }
-  }
-#pragma unroll
-  for (uint32_t g = 0; g < 8; g++) {   // exits are < 64 KiB past the boundary (the block is), 0xFFFF = not representable
-    const uint32_t d = known[g] - seg_start;
-    s_known[L][g] = static_cast<uint16_t>(d < 0xFFFFu ? d : 0xFFFFu);
-  }
-  Lz4Walk w;
-  w.exit = known[0];
-  w.nseq = 0;
-  w.olen = 0;
-  w.ok = true;
-  uint32_t stored_from = 0xFFFFFFFFu;   // start of the walk whose descriptors are in this lane's slice
-  bool need = false;                    // the boundary guess is answered by known[0]
+  for (int g = 0; g < 8; g++) known[g] = 0;
+  bool need = false;
   uint32_t rounds = 0;
   for (uint32_t round = 0; round < kParseLanes + 2; round++) {   // lane k is final after <= k + 1 rounds
     rounds++;
     if (round % 6 == 5) {
-      // Still not settled: on regular numeric data the guessed walks never fall in step and the truth advances one lane per
-      // round, each round an exchange with two barriers.  But then (nearly) every answer is in the look-up tables: ONE lane
-      // follows the chain through them, a hop per segment and no barrier, as far as the tables reach.
+      // Still not settled.  Text falls in step within a few sequences, so this is regular numeric data: 3-6-byte sequences
+      // in a fixed rhythm, a guessed walk stays out of step for the whole block and the truth advances one lane per round
+      // (an exchange with two barriers each).  The chain enters a segment at its first token at or after the boundary, i.e.
+      // within one sequence length of it -- so every lane now tabulates where a walk leaves its segment when it starts at
+      // the boundary, 1 byte later, ... 7 bytes later.  Walks from different starts share their tail: a start that an
+      // earlier walk has a token at gets that walk's answer (a rhythm of p bytes costs p walks, not 8).
+      if (!have_tables) {
+        uint32_t done = 0;
+#pragma unroll
+        for (uint32_t g = 0; g < 8; g++) {
+          const uint32_t from = seg_start + g;
+          if (from >= seg_end) {
+            known[g] = from;
+          } else if (!((done >> g) & 1u)) {
+            uint32_t m = 0;
+            const uint32_t e = probe(from, &m);
+            m &= ~((1u << g) - 1u);   // tokens at or after this start
+            done |= m;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++)
+              if ((m >> j) & 1u) known[j] = e;
+          }
+        }
+#pragma unroll
+        for (uint32_t g = 0; g < 8; g++) {   // exits are < 64 KiB past the boundary (the block is), 0xFFFF = not representable
+          const uint32_t d = known[g] - seg_start;
+          s_known[L][g] = static_cast<uint16_t>(d < 0xFFFFu ? d : 0xFFFFu);
+        }
+        have_tables = true;
+      }
+      // ONE lane follows the chain through the tables, a hop per segment and no barrier, as far as they reach
       s_true[L] = end;
       __syncthreads();
       if (L == 0) {
@@ -213,31 +232,26 @@ __global__ __launch_bounds__(kParseLanes) void lz4_parse(Lz4Args a) {
       }
       __syncthreads();
       const uint32_t t = s_true[L];
-      if (t != end || start >= seg_end) {
-        // a segment the chain was followed into (or one it provably skips: nothing to do there)
-        if (t != start && t != end) {
-          start = t;
-          need = true;
-        }
+      if (t != end && t != start) {
+        start = t;
+        need = true;
       }
     }
     if (need) {
       const uint32_t delta = start - seg_start;
       if (start >= seg_end) {
-        w.exit = start;   // the chain jumps over this segment
-      } else if (start >= seg_start && delta < 8) {
-        w.exit = delta == 0 ? known[0] : delta == 1 ? known[1] : delta == 2 ? known[2] : delta == 3 ? known[3] : delta == 4 ? known[4]
-                 : delta == 5 ? known[5] : delta == 6 ? known[6] : known[7];
+        exit_at = start;   // the chain jumps over this segment
+      } else if (have_tables && start >= seg_start && delta < 8) {
+        exit_at = delta == 0 ? known[0] : delta == 1 ? known[1] : delta == 2 ? known[2] : delta == 3 ? known[3] : delta == 4 ? known[4]
+                  : delta == 5 ? known[5] : delta == 6 ? known[6] : known[7];
       } else {
-        if (IN_LDS) w = lz4_walk<true>((lptr)s_block, start, seg_end, end, block_max, seq, seq_off, cap, b.comp_off);
-        else w = lz4_walk<true>(in, start, seg_end, end, block_max, seq, seq_off, cap, 0u);
-        stored_from = start;
+        exit_at = probe(start, nullptr);
       }
     }
     // the chain enters this lane's segment where the lanes before it left theirs: the furthest exit so far (a sequence
     // that spans many segments leaves the lanes in between with nothing; taking the running maximum tells all of them in
     // one round instead of one lane per round).  Inclusive maximum inside the wave, the waves before it through LDS.
-    uint32_t reach = w.exit;
+    uint32_t reach = exit_at;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       const uint32_t o = __shfl_up(reach, d, 64);
@@ -253,12 +267,12 @@ __global__ __launch_bounds__(kParseLanes) void lz4_parse(Lz4Args a) {
     start = from;
     if (!__syncthreads_or(need ? 1 : 0)) break;   // also: s_wave may be written again
   }
-  // the descriptors of the final walk (answers that came from the look-up table stored none)
-  if (start >= seg_end) {
-    w.nseq = 0;
-    w.olen = 0;
-    w.ok = true;
-  } else if (stored_from != start) {
+  // every start is final: the one walk that stores its descriptors (positions relative to the lane's first output byte)
+  Lz4Walk w;
+  w.nseq = 0;
+  w.olen = 0;
+  w.ok = true;
+  if (start < seg_end) {
     if (IN_LDS) w = lz4_walk<true>((lptr)s_block, start, seg_end, end, block_max, seq, seq_off, cap, b.comp_off);
     else w = lz4_walk<true>(in, start, seg_end, end, block_max, seq, seq_off, cap, 0u);
   }
@@ -268,7 +282,7 @@ __global__ __launch_bounds__(kParseLanes) void lz4_parse(Lz4Args a) {
     atomicAdd(&a.round_left[39], rounds);
     atomicAdd(&a.round_left[37], 1u);
   }
-  // the lanes' slices become one array (order = lane order), output positions relative to the block
+  // where each lane's sequences and output bytes begin inside the block: lz4_expand reads the lanes' slices as they are
   uint32_t seq_before = w.nseq, out_before = w.olen;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -293,28 +307,10 @@ __global__ __launch_bounds__(kParseLanes) void lz4_parse(Lz4Args a) {
     total_out += s_wave2[v];
   }
   const bool all_ok = !any_bad && total_out <= block_max;
-  seq_before -= w.nseq;
   out_before -= w.olen;
-  gptr<u32x4> cseq = GM<u32x4>(a.cseq) + b.seq_base;
-  gptr<uint32_t> cseq_off = GM<uint32_t>(a.cseq_off) + b.seq_base;
-  if (all_ok) {
-    uint32_t i = 0;
-    for (; i + 4 <= w.nseq; i += 4) {   // four independent loads in flight: the slice was written moments ago, it is an L2 round trip each
-      u32x4 d0 = seq[i], d1 = seq[i + 1], d2 = seq[i + 2], d3 = seq[i + 3];
-      const uint32_t o0 = seq_off[i], o1 = seq_off[i + 1], o2 = seq_off[i + 2], o3 = seq_off[i + 3];
-      d0.x += out_before; d1.x += out_before; d2.x += out_before; d3.x += out_before;
-      cseq[seq_before + i] = d0; cseq[seq_before + i + 1] = d1; cseq[seq_before + i + 2] = d2; cseq[seq_before + i + 3] = d3;
-      cseq_off[seq_before + i] = o0; cseq_off[seq_before + i + 1] = o1; cseq_off[seq_before + i + 2] = o2; cseq_off[seq_before + i + 3] = o3;
-    }
-    for (; i < w.nseq; i++) {
-      u32x4 d = seq[i];
-      d.x += out_before;
-      cseq[seq_before + i] = d;
-      cseq_off[seq_before + i] = seq_off[i];
-    }
-  } else if (total_out > block_max && L == 0) {
-    lz4_fail(a.status);
-  }
+  a.lane_out[static_cast<size_t>(bi) * kParseLanes + L] = all_ok ? out_before : 0u;
+  a.lane_nseq[static_cast<size_t>(bi) * kParseLanes + L] = all_ok ? w.nseq : 0u;
+  if (!all_ok && total_out > block_max && L == 0) lz4_fail(a.status);
   if (L == 0) {
     a.block_out_size[bi] = all_ok ? total_out : 0u;
     a.block_nseq[bi] = all_ok ? total_seq : 0u;
@@ -338,10 +334,14 @@ __global__ __launch_bounds__(64) void lz4_layout(Lz4Args a) {
 typedef uint64_t u64_any __attribute__((aligned(1)));
 
 // Output-centric: a thread produces 4 consecutive link words (one 16-byte store, consecutive lanes = consecutive
-// addresses) and finds the sequence that covers its first byte by binary search over the block's descriptors (in order
-// of output position; the upper levels of the search are the same lines for every thread).  A thread per SEQUENCE was 3x
-// slower: its stores were scattered 4-byte words and every wave ran as long as its longest match.
+// addresses).  The block's sequences lie in the 256 slices lz4_parse's lanes wrote, with the output position each slice
+// begins at: the thread finds its slice in that table (LDS), its sequence inside the slice by binary search (<= 7 probes)
+// and walks on from there, slice to slice.  A thread per SEQUENCE was 3x slower: its stores were scattered 4-byte words and
+// every wave ran as long as its longest match.
 __global__ __launch_bounds__(kBlockThreads) void lz4_expand(Lz4Args a) {
+  static_assert(kBlockThreads == static_cast<int>(kParseLanes), "one table entry per thread");
+  __shared__ uint32_t s_lane_out[kParseLanes + 1];
+  __shared__ uint32_t s_lane_n[kParseLanes];
   const uint32_t bi = blockIdx.x;
   const Lz4BlockDev b = a.blocks[bi];
   if (!a.buffer_ok[b.buffer]) return;  // uniform
@@ -354,65 +354,72 @@ __global__ __launch_bounds__(kBlockThreads) void lz4_expand(Lz4Args a) {
     for (uint32_t i = threadIdx.x; i < b.comp_size; i += kBlockThreads) link[base + i] = kLinkKnown | in[b.comp_off + i];
     return;
   }
-  const uint32_t nseq = a.block_nseq[bi];
-  if (nseq == 0) return;
-  gptr<const u32x4> seq = GC<u32x4>(a.cseq) + b.seq_base;
-  gptr<const uint32_t> seq_off = GC<uint32_t>(a.cseq_off) + b.seq_base;
+  if (a.block_nseq[bi] == 0) return;
+  s_lane_out[threadIdx.x] = a.lane_out[static_cast<size_t>(bi) * kParseLanes + threadIdx.x];
+  s_lane_n[threadIdx.x] = a.lane_nseq[static_cast<size_t>(bi) * kParseLanes + threadIdx.x];
+  if (threadIdx.x == 0) s_lane_out[kParseLanes] = n_out;
+  __syncthreads();
+  const uint32_t cap = ((b.comp_size + kParseLanes - 1) / kParseLanes) / 3 + 2;   // slice stride, as in lz4_parse
+  gptr<const u32x4> seq0 = GC<u32x4>(a.seq) + b.seq_base;
+  gptr<const uint32_t> off0 = GC<uint32_t>(a.seq_off) + b.seq_base;
   const bool aligned = (base & 3u) == 0;
   bool bad = false;
-  // every 16th sequence's output position in LDS: the search runs there (LDS latency) and finishes with <= 4 probes of the
-  // descriptors themselves (L2 latency) instead of 13 of those
-  constexpr uint32_t kCoarse = 16;
-  __shared__ uint32_t s_pos[(64u << 10) / 3 / kCoarse + 8];   // a 64 KiB block holds < 21846 sequences
-  const uint32_t ncoarse = (nseq + kCoarse - 1) / kCoarse;
-  const bool use_lds = ncoarse <= sizeof(s_pos) / sizeof(s_pos[0]);   // uniform; larger blocks (4 MiB frames) search the descriptors
-  if (use_lds) {
-    for (uint32_t i = threadIdx.x; i < ncoarse; i += kBlockThreads) s_pos[i] = seq[i * kCoarse].x;
-    __syncthreads();
-  }
   for (uint32_t p0 = threadIdx.x * 4; p0 < n_out; p0 += kBlockThreads * 4) {
-    // last sequence that starts at or before p0 (the first one starts at 0)
-    uint32_t lo = 0, hi = nseq;
-    if (use_lds) {
-      uint32_t clo = 0, chi = ncoarse;
-      while (chi - clo > 1) {
-        const uint32_t mid = (clo + chi) >> 1;
-        if (s_pos[mid] <= p0) clo = mid; else chi = mid;
-      }
-      lo = clo * kCoarse;
-      hi = lo + kCoarse < nseq ? lo + kCoarse : nseq;
-    }
+    // the last slice that begins at or before p0: empty slices begin where the next one does, so this one is not empty
+    uint32_t lo = 0, hi = kParseLanes;
     while (hi - lo > 1) {
       const uint32_t mid = (lo + hi) >> 1;
-      if (seq[mid].x <= p0) lo = mid; else hi = mid;
+      if (s_lane_out[mid] <= p0) lo = mid; else hi = mid;
     }
-    uint32_t si = lo;
+    uint32_t k = lo, lane_base = s_lane_out[k], nk = s_lane_n[k];
+    gptr<const u32x4> seq = seq0 + k * cap;
+    gptr<const uint32_t> seq_off = off0 + k * cap;
+    // ... and the last sequence of it that begins at or before p0
+    uint32_t si = 0;
+    {
+      uint32_t slo = 0, shi = nk;
+      const uint32_t rel = p0 - lane_base;
+      while (shi - slo > 1) {
+        const uint32_t mid = (slo + shi) >> 1;
+        if (seq[mid].x <= rel) slo = mid; else shi = mid;
+      }
+      si = slo;
+    }
     u32x4 d = seq[si];
     uint32_t offset = seq_off[si];
     uint32_t w[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const uint32_t p = p0 + k;
-      w[k] = kLinkUntouched;
+    for (int q = 0; q < 4; q++) {
+      const uint32_t p = p0 + q;
+      w[q] = kLinkUntouched;
       if (p >= n_out) continue;
-      while (p >= d.x + d.z + d.w && si + 1 < nseq) {   // sequences produce >= 1 byte, except a block's empty last one
+      while (p - lane_base >= d.x + d.z + d.w) {   // on to the next sequence (p < n_out: there is one)
         si++;
+        if (si >= nk) {                            // ... of the next slice that has any
+          do { k++; } while (k + 1 < kParseLanes && s_lane_n[k] == 0);
+          lane_base = s_lane_out[k];
+          nk = s_lane_n[k];
+          seq = seq0 + k * cap;
+          seq_off = off0 + k * cap;
+          si = 0;
+          if (nk == 0) break;                      // cannot happen for p < n_out; never spin
+        }
         d = seq[si];
         offset = seq_off[si];
       }
-      const uint32_t r = p - d.x;
+      const uint32_t r = p - lane_base - d.x;
       if (r < d.z) {
-        w[k] = kLinkKnown | in[d.y + r];
+        w[q] = kLinkKnown | in[d.y + r];
       } else {
-        const uint64_t m_at = base + d.x + d.z;
+        const uint64_t m_at = base + lane_base + d.x + d.z;
         const uint32_t i = r - d.z;
-        if (offset > m_at - buffer_lo) {   // reaches in front of the buffer: not a frame an encoder writes
+        if (i >= d.w || offset > m_at - buffer_lo) {   // reaches in front of the buffer: not a frame an encoder writes
           bad = true;
-          w[k] = kLinkKnown;
+          w[q] = kLinkKnown;
         } else {
           // an overlapping match (offset < length: a run) repeats its first `offset` bytes: every byte links straight into
           // that period instead of to the byte `offset` before it, or a run of n bytes would be a chain n / offset deep
-          w[k] = static_cast<uint32_t>(m_at - offset) + (i < offset ? i : i % offset);
+          w[q] = static_cast<uint32_t>(m_at - offset) + (i < offset ? i : i % offset);
         }
       }
     }
@@ -422,8 +429,8 @@ __global__ __launch_bounds__(kBlockThreads) void lz4_expand(Lz4Args a) {
       *(gptr<u32x4>)(link + base + p0) = v;
     } else {
 #pragma unroll
-      for (int k = 0; k < 4; k++)
-        if (p0 + k < n_out) link[base + p0 + k] = w[k];
+      for (int q = 0; q < 4; q++)
+        if (p0 + q < n_out) link[base + p0 + q] = w[q];
     }
   }
   if (bad) lz4_fail(a.status);

@@ -834,7 +834,7 @@ void ArrowScan::EnqueueLz4(Slot& s) {
                o_status = take(4), o_mark = take(out_size + 16);
   const size_t counters_end = at;
   const size_t o_seq = take(static_cast<size_t>(total_seq) * 16), o_seqoff = take(static_cast<size_t>(total_seq) * 4);
-  const size_t o_cseq = take(static_cast<size_t>(total_seq) * 16), o_cseqoff = take(static_cast<size_t>(total_seq) * 4);
+  const size_t o_lane_out = take(nb * 256 * 4), o_lane_n = take(nb * 256 * 4);
   const size_t o_link = take(out_size * 4 + 16), o_skel = take(out_size * 4 + 16);
   if (at > s.d_lz4_cap) {
     if (s.d_lz4) MI_HIP_CHECK(hipFree(s.d_lz4));
@@ -923,8 +923,8 @@ void ArrowScan::EnqueueLz4(Slot& s) {
     if (!blk.stored) a.max_block_comp = std::max(a.max_block_comp, blk.comp_size);
   a.seq = s.d_lz4 + o_seq;
   a.seq_off = reinterpret_cast<uint32_t*>(s.d_lz4 + o_seqoff);
-  a.cseq = s.d_lz4 + o_cseq;
-  a.cseq_off = reinterpret_cast<uint32_t*>(s.d_lz4 + o_cseqoff);
+  a.lane_out = reinterpret_cast<uint32_t*>(s.d_lz4 + o_lane_out);
+  a.lane_nseq = reinterpret_cast<uint32_t*>(s.d_lz4 + o_lane_n);
   a.link = reinterpret_cast<uint32_t*>(s.d_lz4 + o_link);
   a.block_out_size = reinterpret_cast<uint32_t*>(s.d_lz4 + o_bsize);
   a.block_nseq = reinterpret_cast<uint32_t*>(s.d_lz4 + o_bnseq);
