@@ -219,3 +219,29 @@ def test_lz4_file_list_sharded_filtered_and_compacted(con, golden_dir, tmp_path)
     halves = [scan(packed, rank=r, world=2) for r in (0, 1)]
     assert sorted(halves[0][0][0] + halves[1][0][0]) == sorted(want[0])
     assert halves[0][1]["record_batches"] + halves[1][1]["record_batches"] == st["record_batches"]
+
+
+def test_lz4_in_a_multi_device_scan(con, golden_dir, tmp_path):
+    """mi_scan_open_files_multi over LZ4 files: every sub-scan ships and decompresses its own record batches (stats are summed
+    over the devices); counts, the filter and the fused aggregate equal the single-context scan of the uncompressed file."""
+    t = ipc.open_stream(os.path.join(golden_dir, "lineitem_sf0_01_q6.arrows")).read_all()
+    paths = []
+    half = t.num_rows // 2
+    for i, part in enumerate((t.slice(0, half), t.slice(half))):
+        p = str(tmp_path / ("q6_%d_lz4.arrows" % i))
+        _write(p, part, 4096)
+        paths.append(p)
+    plain = os.path.join(golden_dir, "lineitem_sf0_01_q6.arrows")
+    ref = con.read_arrow(plain)
+    ref.filter_range("l_shipdate", 8766, 9130)
+    want = ref.count(detail=True)
+    rel = con.read_arrow(paths, contexts=[da.Context(0), da.Context(0), da.Context(0)], device_resident=True)
+    rel.filter_range("l_shipdate", 8766, 9130)
+    got = rel.count(detail=True)
+    st = rel.stats()
+    assert (got["rows"], got["selected"]) == (want["rows"], want["selected"])
+    assert st["lz4_batches_on_device"] == st["record_batches"] == sum(len(list(ipc.open_stream(p))) for p in paths)
+    s1 = con.read_arrow(paths, contexts=[da.Context(0), da.Context(0)], device_resident=True).sum_product(
+        "l_extendedprice", "l_discount", [("l_shipdate", 8766, 9130)])
+    s2 = con.read_arrow(plain).sum_product("l_extendedprice", "l_discount", [("l_shipdate", 8766, 9130)])
+    assert s1 == s2
