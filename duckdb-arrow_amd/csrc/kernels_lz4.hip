@@ -119,6 +119,43 @@ __device__ __forceinline__ Lz4Walk lz4_walk(BYTES in, uint32_t ip, uint32_t stop
   return w;
 }
 
+// The walk that stores nothing and only wants to know where it leaves [ip, stop): ONE dependent read per sequence (the token;
+// the literal length and the two offset bytes are skipped, not read), more only for the 255-runs of long lengths.  The bytes
+// are not validated here -- a walk that runs into nonsense reports `stop` (no information), the storing walk validates.
+template <typename BYTES>
+__device__ __forceinline__ uint32_t lz4_probe(BYTES in, uint32_t ip, uint32_t stop, uint32_t end, uint32_t mark0, uint32_t* first8) {
+  uint32_t seen = 0;
+  while (ip < stop) {
+    if (ip - mark0 < 8u) seen |= 1u << (ip - mark0);
+    const uint32_t token = in[ip++];
+    uint32_t ll = token >> 4;
+    if (ll == 15) {
+      uint32_t x;
+      do {
+        if (ip >= end) { *first8 = seen; return stop; }
+        x = in[ip++];
+        ll += x;
+      } while (x == 255 && ll < (1u << 24));
+    }
+    if (ll > end - ip) { *first8 = seen; return stop; }
+    ip += ll;
+    if (ip < end) {  // the last sequence of a block is literals only
+      if (end - ip < 2) { *first8 = seen; return stop; }
+      ip += 2;
+      if ((token & 15u) == 15u) {
+        uint32_t x, ml = 0;
+        do {
+          if (ip >= end) { *first8 = seen; return stop; }
+          x = in[ip++];
+          ml += x;
+        } while (x == 255 && ml < (1u << 24));
+      }
+    }
+  }
+  *first8 = seen;
+  return ip;
+}
+
 // One workgroup per block.  The token chain of a block is serial, but LZ4 streams re-synchronise: a walk that starts at a wrong
 // position lands on a true token position after a few sequences and stays on the chain from there.  So the block is cut into
 // 256 segments; every lane walks its segment from a GUESSED start (the segment boundary), then from the position the lane
@@ -169,11 +206,10 @@ __global__ __launch_bounds__(kParseLanes) void lz4_parse(Lz4Args a) {
   const uint32_t seg_start = start;
   // a walk that stores nothing: where it leaves the segment, and which of the first 8 positions it has tokens at
   auto probe = [&](uint32_t from, uint32_t* first8) -> uint32_t {
-    Lz4Walk r;
-    if (IN_LDS) r = lz4_walk<false>((lptr)s_block, from, seg_end, end, block_max, seq, seq_off, cap, 0u, seg_start);
-    else r = lz4_walk<false>(in, from, seg_end, end, block_max, seq, seq_off, cap, 0u, seg_start);
-    if (first8) *first8 = r.first8;
-    return r.exit;
+    uint32_t seen = 0;
+    const uint32_t e = IN_LDS ? lz4_probe((lptr)s_block, from, seg_end, end, seg_start, &seen) : lz4_probe(in, from, seg_end, end, seg_start, &seen);
+    if (first8) *first8 = seen;
+    return e;
   };
   uint32_t exit_at = start < seg_end ? probe(start, nullptr) : start;   // round 0: every lane from its boundary guess
   bool have_tables = false;   // uniform
@@ -364,21 +400,24 @@ __global__ __launch_bounds__(kBlockThreads) void lz4_expand(Lz4Args a) {
   gptr<const uint32_t> off0 = GC<uint32_t>(a.seq_off) + b.seq_base;
   const bool aligned = (base & 3u) == 0;
   bool bad = false;
-  for (uint32_t p0 = threadIdx.x * 4; p0 < n_out; p0 += kBlockThreads * 4) {
-    // the last slice that begins at or before p0: empty slices begin where the next one does, so this one is not empty
+  // a thread owns kChunk consecutive output bytes: ONE search, then it walks the sequences forward (each descriptor is loaded
+  // once); its 16-byte stores fill whole cache lines over the chunk
+  constexpr uint32_t kChunk = 256;
+  for (uint32_t c0 = threadIdx.x * kChunk; c0 < n_out; c0 += kBlockThreads * kChunk) {
+    // the last slice that begins at or before c0: empty slices begin where the next one does, so this one is not empty
     uint32_t lo = 0, hi = kParseLanes;
     while (hi - lo > 1) {
       const uint32_t mid = (lo + hi) >> 1;
-      if (s_lane_out[mid] <= p0) lo = mid; else hi = mid;
+      if (s_lane_out[mid] <= c0) lo = mid; else hi = mid;
     }
     uint32_t k = lo, lane_base = s_lane_out[k], nk = s_lane_n[k];
     gptr<const u32x4> seq = seq0 + k * cap;
     gptr<const uint32_t> seq_off = off0 + k * cap;
-    // ... and the last sequence of it that begins at or before p0
+    // ... and the last sequence of it that begins at or before c0
     uint32_t si = 0;
     {
       uint32_t slo = 0, shi = nk;
-      const uint32_t rel = p0 - lane_base;
+      const uint32_t rel = c0 - lane_base;
       while (shi - slo > 1) {
         const uint32_t mid = (slo + shi) >> 1;
         if (seq[mid].x <= rel) slo = mid; else shi = mid;
@@ -387,6 +426,9 @@ __global__ __launch_bounds__(kBlockThreads) void lz4_expand(Lz4Args a) {
     }
     u32x4 d = seq[si];
     uint32_t offset = seq_off[si];
+    const uint32_t c1 = c0 + kChunk < n_out ? c0 + kChunk : n_out;
+#pragma clang loop unroll(disable)
+    for (uint32_t p0 = c0; p0 < c1; p0 += 4) {
     uint32_t w[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -432,6 +474,7 @@ __global__ __launch_bounds__(kBlockThreads) void lz4_expand(Lz4Args a) {
       for (int q = 0; q < 4; q++)
         if (p0 + q < n_out) link[base + p0 + q] = w[q];
     }
+    }  // quads of the chunk
   }
   if (bad) lz4_fail(a.status);
 }
