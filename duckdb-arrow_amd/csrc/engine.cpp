@@ -201,6 +201,13 @@ static int64_t TaskBytesWritten(const mi_col_task& t) {
   return b;
 }
 
+// hipMemset() is enqueued on the null stream and may return before it has run; the plans run on non-blocking streams, which
+// the null stream does not order with.  Everything that must be zero before such a stream touches it is waited for.
+static void SyncMemset(void* p, int value, size_t bytes) {
+  MI_HIP_CHECK(hipMemset(p, value, bytes));
+  MI_HIP_CHECK(hipStreamSynchronize(nullptr));
+}
+
 Plan::Plan(Context* ctx_p, const mi_col_task* in_tasks, int32_t n_tasks) : ctx(ctx_p) {
   Set(in_tasks, n_tasks, nullptr);
 }
@@ -208,7 +215,7 @@ Plan::Plan(Context* ctx_p, const mi_col_task* in_tasks, int32_t n_tasks) : ctx(c
 Plan::Plan(Context* ctx_p) : ctx(ctx_p), reusable(true) {
   ctx->Bind();
   MI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_status), 64));
-  MI_HIP_CHECK(hipMemset(d_status, 0, 64));
+  SyncMemset(d_status, 0, 64);
 }
 
 template <typename T>
@@ -303,14 +310,14 @@ void Plan::Set(const mi_col_task* in_tasks, int32_t n_tasks, hipStream_t upload_
   EnsureDevice(&d_tile_task, &cap_tile_task, tile_task.size());
   if (!d_status) {
     MI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_status), 64));
-    MI_HIP_CHECK(hipMemset(d_status, 0, 64));
+    SyncMemset(d_status, 0, 64);
   }
   if (class_tiles[device::kClassEncString]) EnsureDevice(&d_tile_sums, &cap_tile_sums, 2 * static_cast<size_t>(class_tiles[device::kClassEncString]) + 1);
   if (class_tiles[device::kClassGather]) EnsureDevice(&d_gather_bases, &cap_gather_bases, tile_task.size());
   if (n_null_counts) {
     const size_t before = cap_null_counts;
     EnsureDevice(&d_null_counts, &cap_null_counts, static_cast<size_t>(n_null_counts));
-    if (cap_null_counts != before) MI_HIP_CHECK(hipMemset(d_null_counts, 0, cap_null_counts * sizeof(int64_t)));
+    if (cap_null_counts != before) SyncMemset(d_null_counts, 0, cap_null_counts * sizeof(int64_t));
   }
   if (reusable && upload_stream) {
     if (cap_tasks != old_cap_tasks || !h_tasks) {
@@ -412,7 +419,10 @@ uint32_t Plan::Status() {
   MI_HIP_CHECK(hipStreamSynchronize(s));
   uint32_t bits = 0;
   MI_HIP_CHECK(hipMemcpy(&bits, d_status, sizeof(bits), hipMemcpyDeviceToHost));
-  if (bits) MI_HIP_CHECK(hipMemset(d_status, 0, sizeof(bits)));
+  if (bits) {   // on the plan's own stream: a memset on the null stream is not ordered with the non-blocking streams the plans run on
+    MI_HIP_CHECK(hipMemsetAsync(d_status, 0, sizeof(bits), s));
+    MI_HIP_CHECK(hipStreamSynchronize(s));
+  }
   return bits;
 }
 
@@ -423,7 +433,13 @@ std::vector<int64_t> Plan::NullCounts(bool reset) {
     hipStream_t s = last_stream ? last_stream : ctx->stream;
     MI_HIP_CHECK(hipStreamSynchronize(s));
     MI_HIP_CHECK(hipMemcpy(per_slot.data(), d_null_counts, per_slot.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
-    if (reset) MI_HIP_CHECK(hipMemset(d_null_counts, 0, per_slot.size() * sizeof(int64_t)));
+    if (reset) {
+      // on the plan's own stream and finished before this returns: hipMemset() goes to the null stream, which is not ordered
+      // with the non-blocking streams the plans run on -- the next row group's kernels could add their NULLs to the counters
+      // BEFORE the memset of this row group cleared them (seen as null_count 0 in a file written by several sink threads)
+      MI_HIP_CHECK(hipMemsetAsync(d_null_counts, 0, per_slot.size() * sizeof(int64_t), s));
+      MI_HIP_CHECK(hipStreamSynchronize(s));
+    }
   }
   return MapNullCounts(per_slot.data());
 }

@@ -199,6 +199,7 @@ class HbmStream {
     own_out = true;
     // NULL slots of dictionaries and padding between arrays read as zero
     MI_HIP_CHECK(hipMemset(d_out, 0, arena_bytes));
+    MI_HIP_CHECK(hipStreamSynchronize(nullptr));   // the null stream is not ordered with the (non-blocking) streams the plans run on
   }
   void Finish() {
     planner.Rebase(0, d_out, d_aux);

@@ -428,6 +428,7 @@ void ArrowScan::DecodeDictionary(Source& src, const DecodedBatch& b) {
   MI_HIP_CHECK(hipMalloc(&d->d_data, data_bytes));
   MI_HIP_CHECK(hipMalloc(&d->d_validity, valid_bytes));
   MI_HIP_CHECK(hipMemset(d->d_data, 0, data_bytes));
+  MI_HIP_CHECK(hipStreamSynchronize(nullptr));   // the null stream is not ordered with the (non-blocking) streams the plans run on
   uint8_t* heap = nullptr;
   if (b.body_size > 0) {
     void* p = nullptr;
