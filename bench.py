@@ -311,6 +311,43 @@ def main():
                     legs[leg] = {"seconds": best, "rows_per_s": info["n_rows"] / best, "GBps_out": float(buf.size) / best / 1e9}
                 if os.path.exists(opath):
                     os.remove(opath)
+                # the same table as ONE LZ4_FRAME-compressed stream (what pyarrow / Feather V2 write), device-resident
+                # count: bodies decompressed by the reader's host threads vs in HBM by the K8 kernels (compressed bytes over PCIe)
+                try:
+                    import pyarrow as pa
+                    import pyarrow.ipc as ipc
+                    lpath = os.path.join(d, "lineitem_lz4.arrows")
+                    reader = ipc.open_stream(pa.py_buffer(buf))
+                    with ipc.new_stream(lpath, reader.schema, options=ipc.IpcWriteOptions(compression="lz4")) as w:
+                        for b in reader:
+                            w.write_batch(b)
+                    lz4 = {"file_bytes": os.path.getsize(lpath)}
+                    for tag, kw in (("host_threads", {"host_decompress": True}), ("in_hbm", {})):
+                        best = None
+                        for _ in range(2):
+                            rel = con.read_arrow(lpath, device_resident=True, pipeline_depth=8, **kw)
+                            t1 = time.perf_counter()
+                            got = rel.count(detail=True)
+                            dt = time.perf_counter() - t1
+                            st = rel.stats()
+                            rel.close()
+                            assert got["rows"] == info["n_rows"]
+                            best = dt if best is None else min(best, dt)
+                        lz4[tag] = {"seconds": best, "rows_per_s": info["n_rows"] / best, "h2d_bytes": st["h2d_bytes"],
+                                    "lz4_batches_on_device": st["lz4_batches_on_device"]}
+                    best = None
+                    for _ in range(2):
+                        rel = con.read_arrow(paths, device_resident=True, pipeline_depth=8)
+                        t1 = time.perf_counter()
+                        rel.count(detail=True)
+                        dt = time.perf_counter() - t1
+                        rel.close()
+                        best = dt if best is None else min(best, dt)
+                    lz4["uncompressed_files"] = {"seconds": best, "rows_per_s": info["n_rows"] / best}
+                    legs["lz4_device_resident_scan"] = lz4
+                    os.remove(lpath)
+                except ImportError:
+                    pass   # no pyarrow on this box: the leg needs it to write the compressed stream
             con.close()
             operator_path = dict(legs, scaling="strong", files=n_files, table="TPC-H SF%g lineitem (%d rows) in %s" % (args.sf, info["n_rows"], args.shm_dir),
                                  rows_per_s=legs["full_scan_host_consumer"]["rows_per_s"],
