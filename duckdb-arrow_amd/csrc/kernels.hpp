@@ -110,6 +110,8 @@ constexpr int kLeafIn = 4;          // v is one of in_values[0 .. n_in)
 constexpr int kLeafStrIn = 5;       // string_t column: the row equals one of n_in byte strings.  in_values holds 3 words per
                                     // constant: {len | dword1 << 32, dword2 | dword3 << 32, device address of the bytes} where
                                     // dword1..3 are the string_t image (inline bytes, or prefix + 0 + 0 for > 12 bytes)
+constexpr int kLeafDictMap = 6;     // dictionary-encoded string column: data = the uint32 selection vector, in_values = one byte per
+                                    // dictionary entry (n_in of them; 0 no, 1 yes, 2 NULL entry), lo = 0 match, 1 no match, 2 IS NULL, 3 IS NOT NULL
 constexpr int kLeafUnsigned = 1;    // flags: the column holds unsigned integers
 constexpr int kLeafNegate = 2;      //        NOT (range / in-list); NULL still fails
 constexpr int kLeafEndsClause = 4;

@@ -119,6 +119,43 @@ __device__ __forceinline__ void leaf_strin(const FilterLeafDev& L, int64_t first
   }
 }
 
+// kLeafDictMap: a string predicate on a dictionary-encoded column was evaluated once per dictionary (on the host: one byte per
+// entry: 0 no, 1 yes, 2 the entry is NULL); a row passes by looking its index up -- 4 bytes per row instead of a string_t and
+// its heap bytes.  Rows without a value point at the extra NULL entry (index dict_len), so the row validity is not needed, and
+// IS [NOT] NULL on a dictionary column -- a row is NULL when its index OR its dictionary entry is -- is the same look-up.
+__device__ __forceinline__ void leaf_dictmap(const FilterLeafDev& L, int64_t first_window, int64_t nrows, int r, uint32_t (&m)[kFilterWindows]) {
+  typedef uint32_t vec8 __attribute__((ext_vector_type(8)));
+  typedef vec8 vec8_a4 __attribute__((aligned(4)));
+  gptr<const uint32_t> idx = GC<uint32_t>(L.data);
+  gptr<const uint8_t> map = GC<uint8_t>(L.in_values);
+  const uint32_t n_map = static_cast<uint32_t>(L.n_in);
+  const int mode = static_cast<int>(L.lo);   // 0: matches, 1: does not match (NULL fails both), 2: IS NULL, 3: IS NOT NULL
+  auto pass = [&](uint32_t code) -> bool {
+    return mode == 0 ? code == 1u : mode == 1 ? code == 0u : mode == 2 ? code == 2u : code != 2u;
+  };
+#pragma unroll
+  for (int w = 0; w < kFilterWindows; w++) {
+    const int64_t row0 = (first_window + w) * kTileRows;
+    const int64_t left = nrows - row0;
+    const int n = left < kTileRows ? static_cast<int>(left < 0 ? 0 : left) : kTileRows;
+    uint32_t mm = 0;
+    if (r + 8 <= n) {
+      const vec8 v = __builtin_nontemporal_load((gptr<const vec8_a4>)(idx + row0 + r));
+#pragma unroll
+      for (int k = 0; k < 8; k++) mm |= pass(v[k] < n_map ? map[v[k]] : 2u) ? (1u << k) : 0u;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        if (r + k < n) {
+          const uint32_t i = idx[row0 + r + k];
+          mm |= pass(i < n_map ? map[i] : 2u) ? (1u << k) : 0u;
+        }
+      }
+    }
+    m[w] = mm;
+  }
+}
+
 __global__ __launch_bounds__(kBlockThreads) void filter_program(const FilterProgram prog, int64_t nrows,
                                                                 mi_sel_t* __restrict__ sel_out_p,
                                                                 uint32_t* __restrict__ count_out_p) {
@@ -150,6 +187,7 @@ __global__ __launch_bounds__(kBlockThreads) void filter_program(const FilterProg
       for (int w = 0; w < kFilterWindows; w++) m[w] = L.op == kLeafIsNull ? (~vb[w] & 0xFFu) : vb[w];
     } else {
       if (L.op == kLeafStrIn) leaf_strin(L, first_window, nrows, r, m);
+      else if (L.op == kLeafDictMap) leaf_dictmap(L, first_window, nrows, r, m);
       else switch (L.width) {
         case 1: leaf_compare<int8_t>(L, first_window, nrows, r, m); break;
         case 2: leaf_compare<int16_t>(L, first_window, nrows, r, m); break;
@@ -159,7 +197,7 @@ __global__ __launch_bounds__(kBlockThreads) void filter_program(const FilterProg
 #pragma unroll
       for (int w = 0; w < kFilterWindows; w++) {
         if (L.flags & kLeafNegate) m[w] = ~m[w] & 0xFFu;
-        m[w] &= vb[w];  // a comparison with NULL is not true
+        if (L.op != kLeafDictMap) m[w] &= vb[w];  // a comparison with NULL is not true (the dictionary map knows its NULLs)
       }
     }
 #pragma unroll

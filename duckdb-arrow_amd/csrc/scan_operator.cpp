@@ -257,11 +257,14 @@ void ArrowScan::Init(const std::vector<std::string>& projected) {
         }
         int32_t kind, w, nb;
         int64_t param;
+        // IN () -- an empty range -- keeps nothing (its negation every valid row) whatever the column holds
+        if (!leaf.is_string && leaf.op == device::kLeafRange && !leaf.lo_open && !leaf.hi_open && leaf.lo > leaf.hi) continue;
         if (leaf.is_string) {
           // byte-string constants: the column must decode to string_t rows that point into ONE data buffer
-          if (!(sc.field.Plan(&kind, &param, &w, &nb) && !sc.field.has_dictionary && (kind == MI_K_STR32 || kind == MI_K_STR64 || kind == MI_K_FIXED_BINARY)))
+          const bool value_ok = sc.field.Plan(&kind, &param, &w, &nb, /*value_only*/ true) && (kind == MI_K_STR32 || kind == MI_K_STR64 || kind == MI_K_FIXED_BINARY);
+          if (!value_ok)
             throw NotImplementedException("string filter pushdown on column '" + sc.name + "' (" + sc.field.DuckType() +
-                                          ") needs a utf8 / large_utf8 / binary / fixed_size_binary column");
+                                          ") needs a utf8 / large_utf8 / binary / fixed_size_binary column (dictionary-encoded or not)");
           continue;
         }
         const bool ok = sc.field.Plan(&kind, &param, &w, &nb) && !sc.field.has_dictionary &&
@@ -479,6 +482,37 @@ void ArrowScan::DecodeDictionary(Source& src, const DecodedBatch& b) {
     std::vector<uint64_t> nw(static_cast<size_t>((n_new + 63) / 64));
     MI_HIP_CHECK(hipMemcpy(nw.data(), scratch_valid, nw.size() * 8, hipMemcpyDeviceToHost));
     for (int64_t i = 0; i < n_new; i++) set_bit(n_old + i, (nw[static_cast<size_t>(i >> 6)] >> (i & 63)) & 1);
+  }
+  // string-valued dictionaries keep their values on the host too (validated by the decode above): pushed-down string
+  // predicates are matched against the dictionary once and against the rows by index
+  d->host_valid.resize(static_cast<size_t>(n));
+  for (int64_t i = 0; i < n; i++) d->host_valid[static_cast<size_t>(i)] = (words[static_cast<size_t>(i >> 6)] >> (i & 63)) & 1;
+  if (kind == MI_K_STR32 || kind == MI_K_STR64 || kind == MI_K_FIXED_BINARY) {
+    if (delta) d->host_strings = old->host_strings;
+    const mi_buffer_span* sp = &b.buffers[0];
+    for (int64_t i = 0; i < n_new; i++) {
+      const bool ok = sp[0].length == 0 || ((b.body[sp[0].offset + (i >> 3)] >> (i & 7)) & 1);
+      std::string v;
+      if (ok) {
+        if (kind == MI_K_FIXED_BINARY) {
+          v.assign(reinterpret_cast<const char*>(b.body + sp[1].offset + i * param), static_cast<size_t>(param));
+        } else {
+          int64_t o0, o1;
+          if (kind == MI_K_STR32) {
+            int32_t a, c;
+            std::memcpy(&a, b.body + sp[1].offset + 4 * i, 4);
+            std::memcpy(&c, b.body + sp[1].offset + 4 * (i + 1), 4);
+            o0 = a; o1 = c;
+          } else {
+            std::memcpy(&o0, b.body + sp[1].offset + 8 * i, 8);
+            std::memcpy(&o1, b.body + sp[1].offset + 8 * (i + 1), 8);
+          }
+          if (o0 < 0 || o1 < o0 || o1 > sp[2].length) throw InternalException("Arrow IPC validation failed: dictionary offsets");
+          v.assign(reinterpret_cast<const char*>(b.body + sp[2].offset + o0), static_cast<size_t>(o1 - o0));
+        }
+      }
+      d->host_strings.push_back(std::move(v));
+    }
   }
   set_bit(n, false);  // the extra NULL entry at index dict_len (ColumnArrowToDuckDBDictionary)
   MI_HIP_CHECK(hipMemcpy(d->d_validity, words.data(), valid_bytes, hipMemcpyHostToDevice));
@@ -728,6 +762,34 @@ void ArrowScan::EnqueueBatch(Slot& s) {
         L.data = pn.alias_body_off >= 0 ? static_cast<const void*>(s.d_in + pn.alias_body_off) : static_cast<const void*>(s.d_out + pn.data_off);
         L.validity = pn.valid_off >= 0 ? reinterpret_cast<const uint64_t*>(s.d_out + pn.valid_off) : nullptr;
         L.width = std::max(pn.width, 1);
+        const bool null_test = leaf.op == device::kLeafIsNull || leaf.op == device::kLeafIsNotNull;
+        if (pn.kind == MI_K_DICT && (leaf.is_string || null_test)) {
+          // dictionary-encoded: match the dictionary version this batch uses once (host), the rows by index.  IS [NOT] NULL
+          // goes the same way: a row is NULL when its index or its dictionary entry is
+          const std::shared_ptr<DictState>& dict = s.node_dict[static_cast<size_t>(root)];
+          if (!dict || (leaf.is_string && static_cast<int64_t>(dict->host_strings.size()) != dict->dict_len))
+            throw NotImplementedException("string filter on the dictionary-encoded column '" + leaf.column + "': its dictionary values are not strings");
+          auto it = dict->match_maps.find(li);
+          if (it == dict->match_maps.end()) {
+            std::vector<uint8_t> codes(static_cast<size_t>(dict->dict_len) + 1, 0);
+            for (int64_t e = 0; e < dict->dict_len; e++)
+              codes[static_cast<size_t>(e)] = !dict->host_valid[static_cast<size_t>(e)] ? 2
+                                              : (leaf.is_string && std::binary_search(leaf.str_values.begin(), leaf.str_values.end(), dict->host_strings[static_cast<size_t>(e)])) ? 1 : 0;
+            codes[static_cast<size_t>(dict->dict_len)] = 2;   // the NULL entry rows without a value point at
+            void* p = nullptr;
+            MI_HIP_CHECK(hipMalloc(&p, RoundUp(codes.size() + 16)));
+            std::shared_ptr<void> keep(p, [](void* q) { (void)hipFree(q); });
+            MI_HIP_CHECK(hipMemcpy(p, codes.data(), codes.size(), hipMemcpyHostToDevice));
+            it = dict->match_maps.emplace(li, std::move(keep)).first;
+          }
+          L.op = device::kLeafDictMap;
+          L.in_values = static_cast<const int64_t*>(it->second.get());
+          L.n_in = static_cast<int32_t>(std::min<int64_t>(dict->dict_len + 1, 0x7FFFFFFF));
+          L.lo = leaf.op == device::kLeafIsNull ? 2 : leaf.op == device::kLeafIsNotNull ? 3 : leaf.negate ? 1 : 0;
+          L.flags &= ~device::kLeafNegate;   // applied inside the kernel: a NULL entry fails = and <> alike
+          L.width = 4;
+          continue;
+        }
         if (leaf.is_string) {
           // the rows' long-string pointers are consumer addresses (pn.ptr_base = byte 0 of the Arrow data buffer as the
           // consumer sees it); the kernel reads the bytes from the HBM copy of that buffer

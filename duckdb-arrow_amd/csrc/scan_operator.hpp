@@ -167,6 +167,11 @@ class ArrowScan : public ScanBase {
     std::vector<std::shared_ptr<void>> host_bodies;  // host bodies: long dictionary strings point into them
     int64_t dict_len = 0;
     int32_t kind = 0, out_width = 0;
+    //! string-valued dictionaries: the values themselves (empty + not valid for NULL entries), for pushed-down string
+    //! predicates -- the dictionary is matched once, on the host, the rows by index (K6, kLeafDictMap)
+    std::vector<std::string> host_strings;
+    std::vector<char> host_valid;
+    std::map<size_t, std::shared_ptr<void>> match_maps;   // filter leaf -> device byte per entry: 0 no, 1 yes, 2 NULL
     ~DictState();
   };
   struct Slot {

@@ -547,7 +547,7 @@ typedef struct mi_filter_node {
   const char* column;     /* leaves */
   int64_t value;          /* comparison constant */
   const int64_t* values;  /* MI_F_IN */
-  /* VARCHAR / BLOB columns (utf8, large_utf8, binary, fixed_size_binary): MI_F_EQ / MI_F_NE take str_value (str_len bytes, no
+  /* VARCHAR / BLOB columns (utf8, large_utf8, binary, fixed_size_binary, dictionary-encoded or not): MI_F_EQ / MI_F_NE take str_value (str_len bytes, no
    * terminator needed), MI_F_IN takes str_values / str_lens; byte-wise equality like DuckDB's.  Leave NULL for the
    * integer forms above.  Ordering comparisons on strings are not pushed down (MI_ENOTSUP). */
   const char* str_value;

@@ -122,3 +122,45 @@ def test_string_filter_errors_and_other_consumers(con, table, tmp_path):
     for kw in ({}, {"device_resident": True}):
         rel = con.read_arrow(packed, **kw).filter(expr)
         assert rel.count(detail=True)["selected"] == want
+
+
+DICT_EXPRS = [
+    ("author", "=", "alice"), ("author", "<>", "alice"), ("author", "in", ["bob", "carol the third of her name", "nobody"]),
+    ("author", "in", []), ("comp", "=", "C++"), ("comp", "<>", "Python"), ("author", "is null"), ("author", "is not null"),
+    ("and", ("author", "in", ["alice", "bob"]), ("comp", "<>", "C++"), ("q", "<", 30)),
+    ("or", ("author", "=", "dave"), ("and", ("comp", "=", "Rust"), ("mode", "=", "MAIL"))),
+]
+
+
+@pytest.mark.parametrize("expr", DICT_EXPRS, ids=[str(e)[:70] for e in DICT_EXPRS])
+def test_string_predicates_on_dictionary_encoded_columns(con, tmp_path_factory, expr):
+    """The arrow-commits shape (BASELINE config 5): low-cardinality VARCHAR columns arrive dictionary-encoded.  A string predicate
+    on such a column is matched against the dictionary once and against the rows by index; dictionaries change from record
+    batch to record batch (replacement), entries and rows can be NULL."""
+    rng = np.random.default_rng(8)
+    n = 6000
+    authors = ["alice", "bob", "carol the third of her name", "dave", None]
+    comps = ["C++", "Python", "Rust", "Go"]
+    batches = []
+    for bi in range(4):
+        # every batch brings its own dictionary (different order / subset): the stream carries replacement dictionaries
+        order = list(rng.permutation(len(authors)))
+        a_vals = [authors[i] for i in order][: 3 + bi % 3]
+        a_idx = pa.array(rng.integers(0, len(a_vals), n).astype(np.int32), mask=rng.random(n) < 0.1)
+        a = pa.DictionaryArray.from_arrays(a_idx, pa.array(a_vals, pa.string()))
+        c_vals = comps[bi % 2:] + comps[: bi % 2]
+        c = pa.DictionaryArray.from_arrays(pa.array(rng.integers(0, len(c_vals), n).astype(np.int8)), pa.array(c_vals, pa.large_string()))
+        batches.append(pa.record_batch([pa.array(np.arange(bi * n, (bi + 1) * n, dtype=np.int64)), a, c,
+                                        pa.array([MODES[int(x)] for x in rng.integers(0, len(MODES), n)]),
+                                        pa.array(rng.integers(0, 50, n).astype(np.int32))], names=["k", "author", "comp", "mode", "q"]))
+    path = str(tmp_path_factory.mktemp("dflt") / "d.arrows")
+    with ipc.new_stream(path, batches[0].schema) as w:
+        for b in batches:
+            w.write_batch(b)
+    t = pa.Table.from_batches(batches)
+    cols = {name: t.column(name).to_pylist() for name in t.column_names}
+    want = [i for i in range(t.num_rows) if _eval(expr, cols, i)]
+    rel = con.read_arrow(path, accept_dictionaries=True).project(["k", "author"]).filter(expr)
+    got_k, got_author = rel.fetch_columns()
+    assert got_k == want and got_author == [cols["author"][i] for i in want]
+    assert con.read_arrow(path, accept_dictionaries=True).filter(expr).count(detail=True)["selected"] == len(want)
