@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "device_common.hpp"
 #include "kernels.hpp"
@@ -616,7 +617,8 @@ hipError_t LaunchLz4Decompress(const Lz4Args& a, int num_cus, hipStream_t stream
   MI_DROP_STALE_ERROR();
   if (a.n_blocks == 0) return hipSuccess;
   // compressed blocks below 64 KiB (64 KiB is the default block size of every writer) are walked from an LDS copy
-  if (a.max_block_comp + 32u + 6144u <= (64u << 10))   // 64 KiB of LDS per workgroup without opting in to more (the kernel's own tables: 5 KiB)
+  static const bool force_global = std::getenv("MI_LZ4_PARSE_GLOBAL") != nullptr;   // tests: the variant for blocks too large for LDS
+  if (!force_global && a.max_block_comp + 32u + 6144u <= (64u << 10))   // 64 KiB of LDS per workgroup without opting in to more (the kernel's own tables: 5 KiB)
     hipLaunchKernelGGL(lz4_parse<true>, dim3(a.n_blocks), dim3(kParseLanes), ((a.max_block_comp + 15u) & ~15u) + 16u, stream, a);
   else
     hipLaunchKernelGGL(lz4_parse<false>, dim3(a.n_blocks), dim3(kParseLanes), 0, stream, a);

@@ -17,6 +17,7 @@ from helpers import canon_python
 from test_gpu_scan_operator import _mirror_device_vector
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -245,3 +246,31 @@ def test_lz4_in_a_multi_device_scan(con, golden_dir, tmp_path):
         "l_extendedprice", "l_discount", [("l_shipdate", 8766, 9130)])
     s2 = con.read_arrow(plain).sum_product("l_extendedprice", "l_discount", [("l_shipdate", 8766, 9130)])
     assert s1 == s2
+
+
+def test_lz4_blocks_walked_from_global_memory(tmp_path):
+    """Compressed blocks too large for the workgroup's LDS (near-incompressible 64 KiB blocks, 4 MiB block frames) are walked
+    from global memory: the same kernel, the other instantiation -- forced here (MI_LZ4_PARSE_GLOBAL) in a fresh process."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r)
+        sys.path.insert(0, os.path.join(%r, "tests"))
+        import numpy as np, pyarrow as pa, pyarrow.ipc as ipc
+        import duckdb_arrow_amd as da
+        rng = np.random.default_rng(5)
+        n = 150000
+        t = pa.table({"k": pa.array(np.arange(n, dtype=np.int64) * 5), "s": pa.array(["text %%d %%s" %% (i %% 701, "z" * (i %% 23)) for i in range(n)]),
+                      "q": pa.array(rng.integers(0, 50, n).astype(np.int32))})
+        p = %r
+        with ipc.new_stream(p, t.schema, options=ipc.IpcWriteOptions(compression="lz4")) as w:
+            w.write_table(t, max_chunksize=60000)
+        con = da.Connection(0)
+        want = con.read_arrow(p, host_decompress=True).fetch_columns()
+        rel = con.read_arrow(p, host_decompress="gpu")
+        got = rel.fetch_columns()
+        assert got == want and rel.stats()["lz4_batches_on_device"] == 3
+        print("ok")
+    """) % (ROOT, ROOT, str(tmp_path / "g.arrows"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, MI_LZ4_PARSE_GLOBAL="1"), timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
