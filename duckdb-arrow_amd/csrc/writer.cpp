@@ -1044,9 +1044,31 @@ void PumpScanFused(mi_writer* w, ArrowScan* scan, const BatchRef& first, int64_t
   Context* ctx = w->ctx;
   ArrowStreamWriter& out = *w->writer;
   ctx->Bind();
+  auto local = MakeLocal(w);             // host path of row groups that straddle record batches
   constexpr int kEncoders = 4;
   std::vector<FusedEncoder> enc(kEncoders);
   hipStream_t enc_stream = nullptr, back_stream = nullptr;
+  // whatever ends this function, the device objects created below go away (the encoders' plans free themselves)
+  struct Cleanup {
+    std::vector<FusedEncoder>& enc;
+    hipStream_t& enc_stream;
+    hipStream_t& back_stream;
+    ~Cleanup() {
+      if (enc_stream) (void)hipStreamSynchronize(enc_stream);
+      if (back_stream) (void)hipStreamSynchronize(back_stream);
+      for (auto& e : enc) {
+        e.plan.reset();
+        if (e.d_body) (void)hipFree(e.d_body);
+        if (e.h_body) (void)hipHostFree(e.h_body);
+        if (e.h_nulls) (void)hipHostFree(e.h_nulls);
+        if (e.h_status) (void)hipHostFree(e.h_status);
+        if (e.encoded) (void)hipEventDestroy(e.encoded);
+        if (e.done) (void)hipEventDestroy(e.done);
+      }
+      if (enc_stream) (void)hipStreamDestroy(enc_stream);
+      if (back_stream) (void)hipStreamDestroy(back_stream);
+    }
+  } cleanup{enc, enc_stream, back_stream};
   MI_HIP_CHECK(hipStreamCreateWithFlags(&enc_stream, hipStreamNonBlocking));
   MI_HIP_CHECK(hipStreamCreateWithFlags(&back_stream, hipStreamNonBlocking));
   for (auto& e : enc) {
@@ -1055,7 +1077,6 @@ void PumpScanFused(mi_writer* w, ArrowScan* scan, const BatchRef& first, int64_t
     MI_HIP_CHECK(hipEventCreateWithFlags(&e.done, hipEventDisableTiming));
     MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e.h_status), 64, hipHostMallocDefault));
   }
-  auto local = MakeLocal(w);             // host path of row groups that straddle record batches
   ChunkStorage storage;
   mi_data_chunk chunk;
 
@@ -1354,21 +1375,10 @@ void PumpScanFused(mi_writer* w, ArrowScan* scan, const BatchRef& first, int64_t
   }
   cv.notify_all();
   io.join();
-  (void)hipStreamSynchronize(enc_stream);
+  (void)hipStreamSynchronize(enc_stream);   // the GPU is done with every scan slot before the batches go back
   (void)hipStreamSynchronize(back_stream);
   for (size_t tok = 0; tok < held.size(); tok++)
     if (!held[tok].released || std::find(to_release.begin(), to_release.end(), static_cast<int>(tok)) != to_release.end()) scan->ReleaseBatch(held[tok].ref);
-  for (auto& e : enc) {
-    e.plan.reset();
-    if (e.d_body) (void)hipFree(e.d_body);
-    if (e.h_body) (void)hipHostFree(e.h_body);
-    if (e.h_nulls) (void)hipHostFree(e.h_nulls);
-    if (e.h_status) (void)hipHostFree(e.h_status);
-    if (e.encoded) (void)hipEventDestroy(e.encoded);
-    if (e.done) (void)hipEventDestroy(e.done);
-  }
-  (void)hipStreamDestroy(enc_stream);
-  (void)hipStreamDestroy(back_stream);
   if (error) std::rethrow_exception(error);
   if (rows_out) *rows_out = rows;
 }
