@@ -43,6 +43,7 @@ namespace {
 constexpr uint32_t kLinkKnown = 0x80000000u;
 constexpr uint32_t kLinkUntouched = 0xFFFFFFFFu;
 constexpr uint32_t kSkelCount = 36;            // round_left[36]: entries of the skeleton list
+constexpr int kSkelHops = 4;                   // links followed per skeleton round
 constexpr uint32_t kLocalTileQuads = 2048;     // lz4_resolve_local: 8 KiB of output = 32 KiB of LDS per workgroup
 
 __device__ __forceinline__ void lz4_fail(uint32_t* status) { atomicOr(status, MI_ST_DECOMPRESS); }
@@ -575,7 +576,14 @@ __global__ __launch_bounds__(kBlockThreads) void lz4_resolve_skeleton(Lz4Args a,
     const uint32_t j = skel[i];
     const uint32_t s = link[j];
     if (s >> 31) continue;
-    const uint32_t u = __builtin_nontemporal_load(link + s);   // before this launch or during it: both are on the chain
+    // a skeleton round is short and latency-bound (a launch, one dependent gather, a store): following kSkelHops links in it
+    // costs little more and divides the chain depth by kSkelHops + 1 instead of 2 -- fewer rounds.  (Over ALL words, where
+    // the gathers are what a round costs, more hops per round were slower.)  A value read before this launch or during it
+    // is on the chain either way.
+    uint32_t u = __builtin_nontemporal_load(link + s);
+#pragma unroll
+    for (int h = 1; h < kSkelHops; h++)
+      if (!(u >> 31)) u = __builtin_nontemporal_load(link + u);
     link[j] = u;
     if (!(u >> 31)) left = true;
   }
@@ -625,10 +633,10 @@ hipError_t LaunchLz4Decompress(const Lz4Args& a, int num_cus, hipStream_t stream
   hipLaunchKernelGGL(lz4_layout, dim3((a.n_buffers + 63) / 64), dim3(64), 0, stream, a);
   hipLaunchKernelGGL(lz4_expand, dim3(a.n_blocks), dim3(kBlockThreads), 0, stream, a);
   // chains only run backwards inside one buffer, and after lz4_resolve_local every hop that is left crosses a boundary of
-  // its 8 KiB tiles: depth <= tiles the longest buffer touches, rounds <= log2(depth) + 1 (10 for a 3 MB buffer)
+  // its 8 KiB tiles: depth <= tiles the longest buffer touches, rounds <= log5(depth) + 1 (5 for a 3 MB buffer)
   const uint64_t depth = a.max_buffer_len / (4 * kLocalTileQuads) + 2;
-  int rounds = 2;
-  while (rounds < 33 && (1ull << (rounds - 1)) < depth) rounds++;
+  int rounds = 2;   // a round divides the depth by kSkelHops + 1
+  for (uint64_t reach = kSkelHops + 1; rounds < 33 && reach < depth; reach *= kSkelHops + 1) rounds++;
   const uint64_t want = ((a.out_size + 3) / 4 + kBlockThreads - 1) / kBlockThreads;
   const uint32_t grid = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(want, static_cast<uint64_t>(num_cus) * 16)));
   const uint64_t nlocal = ((a.out_size + 3) / 4 + kLocalTileQuads - 1) / kLocalTileQuads;
