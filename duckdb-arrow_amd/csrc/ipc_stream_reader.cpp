@@ -1169,17 +1169,21 @@ void IPCFileStreamReader::DecodeBody() {
       return;
     }
     uint8_t* p = nullptr;
-    bool compressed = false;
+    bool compressed = false, stays_compressed = false;
     std::vector<std::pair<int64_t, int64_t>> ranges;
     if (message.type == MessageType::RECORD_BATCH || message.type == MessageType::DICTIONARY_BATCH) {
       const RecordBatchMeta meta = DecodeRecordBatch(message_meta, message_meta_len);
       compressed = meta.compression != -1;
+      stays_compressed = defer_lz4 && meta.compression == 0 && message.type == MessageType::RECORD_BATCH && base_schema.endianness == 0;
       // projection pushdown reaches the file: only the buffers of the projected columns are read (the reference reads
       // the whole body, ipc_file_stream_reader.cpp:71-89); what is skipped is never looked at
       if (message.type == MessageType::RECORD_BATCH) ranges = ProjectedBodyRanges(meta, message.body_length, 256 << 10);
     }
-    cur_owner = (body_allocator && !compressed) ? body_allocator(static_cast<size_t>(message.body_length), message.type, &p)
-                                                : DefaultBodyAlloc(static_cast<size_t>(message.body_length), message.type, &p);
+    // uncompressed bodies, and LZ4 bodies a GPU consumer decompresses itself, are copied to the device as they are: they
+    // go where the consumer wants them (pinned staging); bodies the host decompresses only need to be readable here
+    const bool to_device = !compressed || stays_compressed;
+    cur_owner = (body_allocator && to_device) ? body_allocator(static_cast<size_t>(message.body_length), message.type, &p)
+                                              : DefaultBodyAlloc(static_cast<size_t>(message.body_length), message.type, &p);
     if (ranges.empty()) {
       ReadData(p, static_cast<idx_t>(message.body_length));
     } else {

@@ -55,7 +55,7 @@ ArrowScan::ArrowScan(Context* ctx_p, std::vector<std::string> paths, const mi_sc
     sources.push_back(std::move(s));
   }
   slots.resize(static_cast<size_t>(PipelineDepth(opts)));
-  staging.resize(slots.size() + kReadAhead + 1);
+  staging.resize(slots.size() + kReadAhead + 2);   // slots + queue + the body being read + its decompressed copy
 }
 
 ArrowScan::ArrowScan(Context* ctx_p, std::vector<ArrowIPCBuffer> buffers_p, const mi_scan_options& o)
@@ -63,7 +63,7 @@ ArrowScan::ArrowScan(Context* ctx_p, std::vector<ArrowIPCBuffer> buffers_p, cons
   Source s;
   sources.push_back(std::move(s));
   slots.resize(static_cast<size_t>(PipelineDepth(opts)));
-  staging.resize(slots.size() + kReadAhead + 1);
+  staging.resize(slots.size() + kReadAhead + 2);   // slots + queue + the body being read + its decompressed copy
 }
 
 ArrowScan::~ArrowScan() {
@@ -352,7 +352,7 @@ void ArrowScan::EnsurePipelineDepth(int depth) {
   std::vector<Slot> bigger(static_cast<size_t>(depth));
   for (size_t i = 0; i < slots.size(); i++) bigger[i] = std::move(slots[i]);
   slots = std::move(bigger);
-  staging.resize(slots.size() + kReadAhead + 1);
+  staging.resize(slots.size() + kReadAhead + 2);   // slots + queue + the body being read + its decompressed copy
   if (initialized)
     for (auto& s : slots) InitSlot(s);
 }
