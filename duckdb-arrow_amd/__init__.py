@@ -538,7 +538,7 @@ class Relation:
         st = _ffi.ScanStats()
         _ffi.check(_ffi.lib().mi_scan_get_stats(self._h, C.byref(st)))
         return {k: getattr(st, k) for k in ("record_batches", "lz4_batches_on_device", "h2d_bytes", "decompressed_bytes", "lz4_blocks",
-                                            "lz4_parse_rounds", "lz4_parse_rounds_max")}
+                                            "lz4_parse_rounds", "lz4_parse_rounds_max", "zstd_batches_on_device")}
 
     def close(self):
         if self._h:

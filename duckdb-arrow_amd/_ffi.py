@@ -162,7 +162,7 @@ class WriteOptions(C.Structure):
 class ScanStats(C.Structure):
     _fields_ = [("record_batches", C.c_int64), ("lz4_batches_on_device", C.c_int64), ("h2d_bytes", C.c_int64),
                 ("decompressed_bytes", C.c_int64), ("lz4_blocks", C.c_int64), ("lz4_parse_rounds", C.c_int64),
-                ("lz4_parse_rounds_max", C.c_int64), ("_reserved", C.c_int64 * 1)]
+                ("lz4_parse_rounds_max", C.c_int64), ("zstd_batches_on_device", C.c_int64)]
 
 
 class SynthOptions(C.Structure):

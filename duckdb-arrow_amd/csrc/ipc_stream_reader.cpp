@@ -447,6 +447,144 @@ static bool WalkLz4Frame(const uint8_t* body, int64_t frame_off, int64_t frame_l
   return true;
 }
 
+bool WalkZstdFrame(const uint8_t* body, int64_t frame_off, int64_t frame_len, uint32_t buffer_index, int64_t declared_len,
+                   DeferredLz4Body::Buffer* buf, std::vector<DeferredLz4Body::Block>* blocks, std::vector<zstd::BlockInfo>* infos,
+                   uint32_t* literal_scratch) {
+  const uint8_t* p = body + frame_off;
+  if (frame_len < 9 || p[0] != 0x28 || p[1] != 0xB5 || p[2] != 0x2F || p[3] != 0xFD) return false;
+  const uint8_t fhd = p[4];
+  const int fcs_flag = fhd >> 6;
+  const bool single_segment = (fhd & 0x20) != 0;
+  if ((fhd & 0x08) || (fhd & 0x04) || (fhd & 0x03)) return false;   // reserved bit; content checksum; dictionary id
+  int64_t at = 5;
+  uint64_t window = 0;
+  if (!single_segment) {
+    const uint8_t wd = p[at++];
+    const uint64_t base = uint64_t(1) << (10 + (wd >> 3));
+    window = base + (base >> 3) * (wd & 7u);
+  }
+  const int fcs_bytes = fcs_flag == 0 ? (single_segment ? 1 : 0) : fcs_flag == 1 ? 2 : fcs_flag == 2 ? 4 : 8;
+  if (at + fcs_bytes > frame_len) return false;
+  if (fcs_bytes) {
+    uint64_t fcs = 0;
+    std::memcpy(&fcs, p + at, static_cast<size_t>(fcs_bytes));   // little-endian host (the extension's platforms)
+    if (fcs_bytes == 2) fcs += 256;
+    if (fcs != static_cast<uint64_t>(declared_len)) return false;   // the host path words the error
+    if (single_segment) window = fcs;
+    at += fcs_bytes;
+  }
+  const uint64_t block_max = std::min<uint64_t>(std::max<uint64_t>(window, 1), zstd::kBlockMax);
+  buf->block_max = zstd::kBlockMax;
+  buf->first_block = static_cast<uint32_t>(blocks->size());
+  const uint32_t none = ~0u;
+  uint32_t last_huf = none, last_tbl[3] = {none, none, none};
+  for (bool last = false; !last;) {
+    if (at + 3 > frame_len) return false;
+    const uint32_t h = static_cast<uint32_t>(p[at]) | (static_cast<uint32_t>(p[at + 1]) << 8) | (static_cast<uint32_t>(p[at + 2]) << 16);
+    at += 3;
+    last = (h & 1u) != 0;
+    const uint32_t type = (h >> 1) & 3u, size = h >> 3;
+    if (type == 3) return false;
+    const uint32_t stored = type == 1 ? 1u : size;
+    if ((type != 1 && size > block_max) || (type == 1 && size > block_max) || at + stored > frame_len) return false;
+    const uint32_t self = static_cast<uint32_t>(blocks->size());
+    DeferredLz4Body::Block b;
+    b.comp_off = static_cast<uint32_t>(frame_off + at);
+    b.comp_size = stored;
+    b.buffer = buffer_index;
+    b.stored = type == 0;
+    zstd::BlockInfo z;
+    std::memset(&z, 0, sizeof(z));
+    z.comp_off = b.comp_off;
+    z.comp_size = stored;
+    z.type = type;
+    z.huf_src = z.ll_src = z.of_src = z.ml_src = self;
+    const uint8_t* c = p + at;
+    if (type == 1) {
+      z.regen = size;
+      z.lit_pos = *literal_scratch;   // its one byte, written to the scratch like a literal
+      *literal_scratch += 1;
+      b.seq_cap = 256;
+    } else if (type == 2) {
+      if (size < 2) return false;
+      // literals section header
+      z.lit_type = c[0] & 3u;
+      const uint32_t fmt = (c[0] >> 2) & 3u;
+      if (z.lit_type < 2) {
+        if (!(fmt & 1u)) { z.lit_hdr = 1; z.lit_regen = c[0] >> 3; }
+        else if (fmt == 1) { z.lit_hdr = 2; z.lit_regen = (c[0] >> 4) | (static_cast<uint32_t>(c[1]) << 4); }
+        else {
+          if (size < 3) return false;
+          z.lit_hdr = 3;
+          z.lit_regen = (c[0] >> 4) | (static_cast<uint32_t>(c[1]) << 4) | (static_cast<uint32_t>(c[2]) << 12);
+        }
+        z.lit_comp = z.lit_type == 0 ? z.lit_regen : 1;
+        z.lit_streams = 1;
+      } else {
+        if (size < 5) return false;
+        const uint64_t v = static_cast<uint64_t>(c[0]) | (static_cast<uint64_t>(c[1]) << 8) | (static_cast<uint64_t>(c[2]) << 16) |
+                           (static_cast<uint64_t>(c[3]) << 24) | (static_cast<uint64_t>(c[4]) << 32);
+        if (fmt <= 1) { z.lit_hdr = 3; z.lit_regen = (v >> 4) & 0x3FFu; z.lit_comp = (v >> 14) & 0x3FFu; }
+        else if (fmt == 2) { z.lit_hdr = 4; z.lit_regen = (v >> 4) & 0x3FFFu; z.lit_comp = (v >> 18) & 0x3FFFu; }
+        else { z.lit_hdr = 5; z.lit_regen = (v >> 4) & 0x3FFFFu; z.lit_comp = (v >> 22) & 0x3FFFFu; }
+        z.lit_streams = fmt == 0 ? 1 : 4;
+        if (z.lit_type == 3) {
+          if (last_huf == none) return false;
+          z.huf_src = last_huf;
+        } else {
+          last_huf = self;
+        }
+        if (z.lit_comp == 0 || z.lit_regen == 0) return false;
+      }
+      if (z.lit_regen > zstd::kBlockMax || static_cast<uint64_t>(z.lit_hdr) + z.lit_comp + 1 > size) return false;
+      if (z.lit_type == 0) {
+        z.lit_pos = b.comp_off + z.lit_hdr;
+      } else {
+        z.lit_pos = *literal_scratch;
+        *literal_scratch += (z.lit_regen + 3u) & ~3u;
+      }
+      // sequences section: the count, then (count > 0) the modes of the three tables
+      z.seq_pos = z.lit_hdr + z.lit_comp;
+      const uint8_t* q = c + z.seq_pos;
+      const uint32_t left = size - z.seq_pos;
+      if (q[0] == 0) { z.seq_hdr = 1; z.nseq = 0; }
+      else if (q[0] < 128) { z.seq_hdr = 1; z.nseq = q[0]; }
+      else if (q[0] < 255) {
+        if (left < 2) return false;
+        z.seq_hdr = 2;
+        z.nseq = ((static_cast<uint32_t>(q[0]) - 128u) << 8) + q[1];
+      } else {
+        if (left < 3) return false;
+        z.seq_hdr = 3;
+        z.nseq = static_cast<uint32_t>(q[1]) + (static_cast<uint32_t>(q[2]) << 8) + 0x7F00u;
+      }
+      if (z.nseq == 0) {
+        if (left != z.seq_hdr) return false;
+      } else {
+        if (left < z.seq_hdr + 2) return false;
+        const uint32_t modes = q[z.seq_hdr];
+        if (modes & 3u) return false;
+        uint32_t* src[3] = {&z.ll_src, &z.of_src, &z.ml_src};
+        for (int t = 0; t < 3; t++) {
+          if (((modes >> (6 - 2 * t)) & 3u) == 3u) {
+            if (last_tbl[t] == none) return false;
+            *src[t] = last_tbl[t];
+          } else {
+            last_tbl[t] = self;
+          }
+        }
+      }
+      b.seq_cap = 256u * ((z.nseq + 1u + 255u) / 256u);
+    }
+    blocks->push_back(b);
+    infos->push_back(z);
+    at += stored;
+  }
+  if (at != frame_len) return false;   // a second frame, a skippable frame, trailing bytes: the host library's business
+  buf->n_blocks = static_cast<uint32_t>(blocks->size()) - buf->first_block;
+  return true;
+}
+
 void IPCStreamReader::DecompressBody(RecordBatchMeta* meta) {
   if (meta->compression != 0 && meta->compression != 1) throw IOException("Unknown BodyCompression codec " + std::to_string(meta->compression));
   const bool lz4 = meta->compression == 0;
@@ -506,7 +644,7 @@ void IPCStreamReader::DecompressBody(RecordBatchMeta* meta) {
     total += (n + 63) & ~static_cast<int64_t>(63);
   }
   // GPU consumers (SetDeferLz4): keep the body compressed and hand out the frame / block tables instead
-  bool deferrable = lz4 && defer_lz4 && !meta->is_dictionary && base_schema.endianness == 0 && total < (int64_t(1) << 31) - 64 &&
+  bool deferrable = (lz4 ? defer_lz4 : defer_zstd) && !meta->is_dictionary && base_schema.endianness == 0 && total < (int64_t(1) << 31) - 64 &&
                     cur_size < (int64_t(1) << 31) - 64;
   if (deferrable)
     for (auto& f : (HasProjection() ? projected_schema.fields : base_schema.fields))
@@ -515,6 +653,7 @@ void IPCStreamReader::DecompressBody(RecordBatchMeta* meta) {
     auto d = std::make_shared<DeferredLz4Body>();
     d->comp = cur_ptr;
     d->comp_size = cur_size;
+    d->codec = lz4 ? 0 : 1;
     bool ok = true;
     for (size_t i = 0; i < nbuf && ok; i++) {
       const mi_buffer_span& b = meta->buffers[i];
@@ -527,7 +666,10 @@ void IPCStreamReader::DecompressBody(RecordBatchMeta* meta) {
       f.comp_len = b.length - 8;
       f.out_off = opos[i];
       f.out_len = ulen[i];
-      if (!f.raw) ok = WalkLz4Frame(cur_ptr, f.comp_off, f.comp_len, static_cast<uint32_t>(d->buffers.size()), &f, &d->blocks);
+      if (!f.raw)
+        ok = lz4 ? WalkLz4Frame(cur_ptr, f.comp_off, f.comp_len, static_cast<uint32_t>(d->buffers.size()), &f, &d->blocks)
+                 : WalkZstdFrame(cur_ptr, f.comp_off, f.comp_len, static_cast<uint32_t>(d->buffers.size()), ulen[i], &f, &d->blocks,
+                                 &d->zblocks, &d->literal_scratch);
       d->buffers.push_back(f);
     }
     if (ok) {
@@ -1174,7 +1316,7 @@ void IPCFileStreamReader::DecodeBody() {
     if (message.type == MessageType::RECORD_BATCH || message.type == MessageType::DICTIONARY_BATCH) {
       const RecordBatchMeta meta = DecodeRecordBatch(message_meta, message_meta_len);
       compressed = meta.compression != -1;
-      stays_compressed = defer_lz4 && meta.compression == 0 && message.type == MessageType::RECORD_BATCH && base_schema.endianness == 0;
+      stays_compressed = ((defer_lz4 && meta.compression == 0) || (defer_zstd && meta.compression == 1)) && message.type == MessageType::RECORD_BATCH && base_schema.endianness == 0;
       // projection pushdown reaches the file: only the buffers of the projected columns are read (the reference reads
       // the whole body, ipc_file_stream_reader.cpp:71-89); what is skipped is never looked at
       if (message.type == MessageType::RECORD_BATCH) ranges = ProjectedBodyRanges(meta, message.body_length, 256 << 10);

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "ipc_format.hpp"
+#include "zstd_format.hpp"
 
 namespace miarrow {
 
@@ -53,8 +54,8 @@ struct DecodedNode {
   std::vector<int32_t> children;         // indices into DecodedBatch::nodes
 };
 
-//! A record-batch body whose LZ4_FRAME buffers are still compressed (IPCStreamReader::SetDeferLz4): the frames were walked
-//! on the host (frame header, block headers), the bytes are decompressed in HBM by the K8 kernels (kernels_lz4.hip).
+//! A record-batch body whose LZ4_FRAME / ZSTD buffers are still compressed (IPCStreamReader::SetDeferLz4): the frames were
+//! walked on the host (frame header, block headers), the bytes are decompressed in HBM by the K8 kernels (kernels_lz4.hip).
 struct DeferredLz4Body {
   struct Buffer {
     int64_t comp_off = 0, comp_len = 0;   // raw: the bytes themselves; else the frame, inside the compressed body
@@ -64,12 +65,21 @@ struct DeferredLz4Body {
   };
   struct Block {
     uint32_t comp_off = 0, comp_size = 0, buffer = 0, stored = 0;
+    uint32_t seq_cap = 0;                 // ZSTD: sequence descriptors the block needs (LZ4: derived from comp_size)
   };
   const uint8_t* comp = nullptr;          // the compressed body as it was read (kept alive by DecodedBatch::owner)
   int64_t comp_size = 0;
   std::vector<Buffer> buffers;            // the needed, non-empty buffers of the message
-  std::vector<Block> blocks;              // every LZ4 block of every non-raw buffer, buffer by buffer
+  std::vector<Block> blocks;              // every block of every non-raw buffer, buffer by buffer
+  int32_t codec = 0;                      // 0 LZ4_FRAME, 1 ZSTD
+  std::vector<zstd::BlockInfo> zblocks;   // ZSTD: one per entry of `blocks`
+  uint32_t literal_scratch = 0;           // ZSTD: bytes of decoded literals (BlockInfo::lit_pos of non-raw literals counts from 0)
 };
+//! Walks one ZSTD frame (one IPC buffer) from its headers.  false = a frame the device path does not take (dictionary,
+//! content checksum, several frames, anything malformed): the host decompressor handles it and reports what is wrong.
+bool WalkZstdFrame(const uint8_t* body, int64_t frame_off, int64_t frame_len, uint32_t buffer_index, int64_t declared_len,
+                   DeferredLz4Body::Buffer* buf, std::vector<DeferredLz4Body::Block>* blocks, std::vector<zstd::BlockInfo>* infos,
+                   uint32_t* literal_scratch);
 
 //! What GetNextBatch produces: the buffers of every (projected) top-level column of one message.
 struct DecodedBatch {
@@ -144,6 +154,8 @@ class IPCStreamReader {
   //! LZ4_FRAME record batches (not dictionary batches, not big-endian streams) are handed out still compressed, with the
   //! frame / block tables a GPU decompressor needs (DecodedBatch::deferred); everything else is decompressed here as before
   void SetDeferLz4(bool on) { defer_lz4 = on; }
+  //! the same for ZSTD record batches (frames with a dictionary id or a content checksum stay with the host library)
+  void SetDeferZstd(bool on) { defer_zstd = on; }
 
   static int64_t CountFields(const ArrowField& field) { return field.CountFields(); }
   static constexpr uint32_t kContinuationToken = 0xFFFFFFFF;
@@ -165,7 +177,7 @@ class IPCStreamReader {
   //! Replaces cur_ptr/cur_size with the decompressed body and rewrites meta->buffers (ZSTD, per buffer; the CPU step the
   //! reference performs in DuckDBDecompressZstd, base_stream_reader.cpp:11-32)
   void DecompressBody(RecordBatchMeta* meta);
-  bool defer_lz4 = false;
+  bool defer_lz4 = false, defer_zstd = false;
   std::shared_ptr<const DeferredLz4Body> cur_deferred;   // set by DecompressBody when the current body stays compressed
   //! Big-endian stream: every multi-byte number of the body is swapped in place (after decompression), so the rest of the
   //! path sees little-endian buffers (what nanoarrow's decoder does for the reference, base_stream_reader.cpp:68-69)

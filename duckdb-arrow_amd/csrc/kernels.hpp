@@ -62,7 +62,7 @@ struct Lz4BlockDev {
   uint32_t comp_off, comp_size;   // the block's bytes inside the compressed body
   uint32_t buffer;                // index into Lz4Args::buffers
   uint32_t stored;                // 1 = the block holds its bytes uncompressed
-  uint32_t seq_base, seq_cap;     // its slice of the sequence-descriptor scratch: 256 lanes x (ceil(comp_size / 256) / 3 + 2)
+  uint32_t seq_base, seq_cap;     // its slice of the sequence-descriptor scratch, 256 equal parts: LZ4 256 x (ceil(comp_size / 256) / 3 + 2), ZSTD count + 1 rounded up
 };
 struct Lz4BufferDev {
   uint64_t out_off, out_len;      // where the buffer lies in the decompressed body, and its declared length
@@ -91,6 +91,11 @@ struct Lz4Args {
   uint32_t* skel;                 // the skeleton list: up to one entry per decompressed byte
   uint32_t* round_left;           // 40 words, zeroed
   uint32_t* status;               // MI_ST_DECOMPRESS
+  // ZSTD batches (NULL for LZ4): one zstd::BlockInfo per block (zstd_format.hpp); the decoded literals of a block go to
+  // literals[BlockInfo::lit_pos ..] -- the same allocation as `comp`, behind the compressed body, so that a sequence's literal
+  // source is one position whichever section it came from
+  const void* zblocks;
+  uint8_t* literals;
 };
 inline uint32_t Lz4SeqCapacity(uint32_t comp_size) { return 256u * (((comp_size + 255u) / 256u) / 3u + 2u); }
 hipError_t LaunchLz4Decompress(const Lz4Args& args, int num_cus, hipStream_t stream);

@@ -33,6 +33,7 @@
 
 #include "device_common.hpp"
 #include "kernels.hpp"
+#include "zstd_format.hpp"
 
 namespace miarrow {
 namespace device {
@@ -355,6 +356,8 @@ __global__ __launch_bounds__(kParseLanes) void lz4_parse(Lz4Args a) {
   }
 }
 
+#include "kernels_zstd.inl"
+
 __global__ __launch_bounds__(64) void lz4_layout(Lz4Args a) {
   const uint32_t u = blockIdx.x * 64 + threadIdx.x;
   if (u >= a.n_buffers) return;
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(kBlockThreads) void lz4_expand(Lz4Args a) {
   s_lane_n[threadIdx.x] = a.lane_nseq[static_cast<size_t>(bi) * kParseLanes + threadIdx.x];
   if (threadIdx.x == 0) s_lane_out[kParseLanes] = n_out;
   __syncthreads();
-  const uint32_t cap = ((b.comp_size + kParseLanes - 1) / kParseLanes) / 3 + 2;   // slice stride, as in lz4_parse
+  const uint32_t cap = b.seq_cap / kParseLanes;   // slice stride, as lz4_parse / zstd_entropy wrote them
   gptr<const u32x4> seq0 = GC<u32x4>(a.seq) + b.seq_base;
   gptr<const uint32_t> off0 = GC<uint32_t>(a.seq_off) + b.seq_base;
   const bool aligned = (base & 3u) == 0;
@@ -624,13 +627,18 @@ __global__ __launch_bounds__(kBlockThreads) void lz4_emit(Lz4Args a) {
 hipError_t LaunchLz4Decompress(const Lz4Args& a, int num_cus, hipStream_t stream) {
   MI_DROP_STALE_ERROR();
   if (a.n_blocks == 0) return hipSuccess;
-  // compressed blocks below 64 KiB (64 KiB is the default block size of every writer) are walked from an LDS copy
-  static const bool force_global = std::getenv("MI_LZ4_PARSE_GLOBAL") != nullptr;   // tests: the variant for blocks too large for LDS
-  if (!force_global && a.max_block_comp + 32u + 6144u <= (64u << 10))   // 64 KiB of LDS per workgroup without opting in to more (the kernel's own tables: 5 KiB)
-    hipLaunchKernelGGL(lz4_parse<true>, dim3(a.n_blocks), dim3(kParseLanes), ((a.max_block_comp + 15u) & ~15u) + 16u, stream, a);
-  else
-    hipLaunchKernelGGL(lz4_parse<false>, dim3(a.n_blocks), dim3(kParseLanes), 0, stream, a);
-  hipLaunchKernelGGL(lz4_layout, dim3((a.n_buffers + 63) / 64), dim3(64), 0, stream, a);
+  if (a.zblocks) {
+    hipLaunchKernelGGL(zstd_entropy, dim3(a.n_blocks), dim3(kZstdThreads), 0, stream, a);
+    hipLaunchKernelGGL(zstd_layout, dim3((a.n_buffers + 63) / 64), dim3(64), 0, stream, a);
+  } else {
+    // compressed blocks below 64 KiB (64 KiB is the default block size of every writer) are walked from an LDS copy
+    static const bool force_global = std::getenv("MI_LZ4_PARSE_GLOBAL") != nullptr;   // tests: the variant for blocks too large for LDS
+    if (!force_global && a.max_block_comp + 32u + 6144u <= (64u << 10))   // 64 KiB of LDS per workgroup without opting in to more (the kernel's own tables: 5 KiB)
+      hipLaunchKernelGGL(lz4_parse<true>, dim3(a.n_blocks), dim3(kParseLanes), ((a.max_block_comp + 15u) & ~15u) + 16u, stream, a);
+    else
+      hipLaunchKernelGGL(lz4_parse<false>, dim3(a.n_blocks), dim3(kParseLanes), 0, stream, a);
+    hipLaunchKernelGGL(lz4_layout, dim3((a.n_buffers + 63) / 64), dim3(64), 0, stream, a);
+  }
   hipLaunchKernelGGL(lz4_expand, dim3(a.n_blocks), dim3(kBlockThreads), 0, stream, a);
   // chains only run backwards inside one buffer, and after lz4_resolve_local every hop that is left crosses a boundary of
   // its 8 KiB tiles: depth <= tiles the longest buffer touches, rounds <= log5(depth) + 1 (5 for a 3 MB buffer)

@@ -127,6 +127,7 @@ void ArrowScan::OpenSource(size_t i) {
   // bodies are decompressed by the reader's host threads: on this platform D2H copies run as copy kernels, which then
   // queue up with the K8 kernels instead of overlapping them (SF10: 0.85 s against 0.68 s, tools/lz4_bench.py)
   s.reader->SetDeferLz4(opts.host_decompress < 0 || (opts.host_decompress == 0 && opts.device_resident != 0));
+  s.reader->SetDeferZstd(opts.host_decompress < 0 || (opts.host_decompress == 0 && opts.device_resident != 0));
   s.reader->GetBaseSchema();
   s.opened = true;
 }
@@ -890,9 +891,14 @@ void ArrowScan::EnqueueLz4(Slot& s) {
   size_t at = 0;
   auto take = [&](size_t bytes) { const size_t o = at; at += RoundUp(bytes + 16, 256); return o; };
   const size_t o_blocks = take(nb * sizeof(device::Lz4BlockDev)), o_buffers = take(nf * sizeof(device::Lz4BufferDev));
+  const bool is_zstd = d.codec == 1;
+  const size_t o_zblocks = take(is_zstd ? nb * sizeof(zstd::BlockInfo) : 0);
   const size_t tables_bytes = at;
   uint64_t total_seq = 0, max_len = 0;
-  for (auto& blk : d.blocks) total_seq += device::Lz4SeqCapacity(blk.comp_size);
+  for (auto& blk : d.blocks) total_seq += is_zstd ? blk.seq_cap : device::Lz4SeqCapacity(blk.comp_size);
+  // ZSTD: the decoded literals of every block lie behind the compressed body, in the same allocation
+  const size_t lit_base = RoundUp(static_cast<size_t>(d.comp_size) + 64, 256);
+  const size_t comp_need = is_zstd ? lit_base + d.literal_scratch + 64 : static_cast<size_t>(d.comp_size) + 64;
   const size_t o_bsize = take(nb * 4), o_bnseq = take(nb * 4), o_bbase = take(nb * 8), o_bufok = take(nf * 4), o_round = take(40 * 4),
                o_status = take(4), o_mark = take(out_size + 16);
   const size_t counters_end = at;
@@ -905,10 +911,10 @@ void ArrowScan::EnqueueLz4(Slot& s) {
     s.d_lz4_cap = RoundUp(std::max(at, s.d_lz4_cap + s.d_lz4_cap / 2), 1 << 20);
     MI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s.d_lz4), s.d_lz4_cap));
   }
-  if (static_cast<size_t>(d.comp_size) + 64 > s.d_comp_cap) {
+  if (comp_need > s.d_comp_cap) {
     if (s.d_comp) MI_HIP_CHECK(hipFree(s.d_comp));
     s.d_comp = nullptr;
-    s.d_comp_cap = RoundUp(std::max(static_cast<size_t>(d.comp_size) + 64, s.d_comp_cap + s.d_comp_cap / 2), 1 << 16);
+    s.d_comp_cap = RoundUp(std::max(comp_need, s.d_comp_cap + s.d_comp_cap / 2), 1 << 16);
     MI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s.d_comp), s.d_comp_cap));
   }
   if (tables_bytes > s.h_lz4_cap) {
@@ -927,8 +933,16 @@ void ArrowScan::EnqueueLz4(Slot& s) {
     hb[i].buffer = blk.buffer;
     hb[i].stored = blk.stored;
     hb[i].seq_base = seq_at;
-    hb[i].seq_cap = device::Lz4SeqCapacity(blk.comp_size);
+    hb[i].seq_cap = is_zstd ? blk.seq_cap : device::Lz4SeqCapacity(blk.comp_size);
     seq_at += hb[i].seq_cap;
+  }
+  if (is_zstd) {
+    auto* hz = reinterpret_cast<zstd::BlockInfo*>(s.h_lz4 + o_zblocks);
+    for (size_t i = 0; i < nb; i++) {
+      hz[i] = d.zblocks[i];
+      const bool in_scratch = hz[i].type == 1 || (hz[i].type == 2 && hz[i].lit_type != 0);
+      if (in_scratch) hz[i].lit_pos += static_cast<uint32_t>(lit_base);
+    }
   }
   for (size_t i = 0; i < nf; i++) {
     const auto& f = d.buffers[i];
@@ -950,7 +964,8 @@ void ArrowScan::EnqueueLz4(Slot& s) {
     MI_HIP_CHECK(hipMemcpyAsync(s.d_comp + lo, d.comp + lo, static_cast<size_t>(hi - lo), hipMemcpyHostToDevice, ctx->h2d_stream));
     stats.h2d_bytes += hi - lo;
   };
-  stats.lz4_batches_on_device++;
+  if (is_zstd) stats.zstd_batches_on_device++;
+  else stats.lz4_batches_on_device++;
   stats.decompressed_bytes += b.body_size;
   for (const auto& r : ranges) {
     if (lo >= 0 && r.first <= hi + (64 << 10)) {
@@ -997,6 +1012,8 @@ void ArrowScan::EnqueueLz4(Slot& s) {
   a.mark = s.d_lz4 + o_mark;
   a.skel = reinterpret_cast<uint32_t*>(s.d_lz4 + o_skel);
   a.status = reinterpret_cast<uint32_t*>(s.d_lz4 + o_status);
+  a.zblocks = is_zstd ? s.d_lz4 + o_zblocks : nullptr;
+  a.literals = s.d_comp;
   MI_HIP_CHECK(device::LaunchLz4Decompress(a, ctx->num_cus, q));
   MI_HIP_CHECK(hipMemcpyAsync(&s.h_status[2], a.status, sizeof(uint32_t), hipMemcpyDeviceToHost, q));
   MI_HIP_CHECK(hipMemcpyAsync(&s.h_status[4], a.round_left + 37, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, q));
@@ -1692,6 +1709,7 @@ void ArrowScan::Stats(mi_scan_stats* out) {
   out->lz4_blocks += stats.lz4_blocks;
   out->lz4_parse_rounds += stats.lz4_parse_rounds;
   out->lz4_parse_rounds_max = std::max(out->lz4_parse_rounds_max, stats.lz4_parse_rounds_max);
+  out->zstd_batches_on_device += stats.zstd_batches_on_device;
 }
 
 void MultiDeviceScan::Stats(mi_scan_stats* out) {

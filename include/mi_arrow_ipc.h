@@ -593,7 +593,7 @@ typedef struct mi_scan_stats {
   int64_t lz4_parse_rounds;         /* ... rounds of its 64 speculative lanes, summed over the blocks (2-3 when the guesses
                                      * fall in step, 65 = the serial walk) ... */
   int64_t lz4_parse_rounds_max;     /* ... and the worst block */
-  int64_t _reserved[1];
+  int64_t zstd_batches_on_device;   /* ZSTD bodies decompressed in HBM (K8: entropy stage per block, then the LZ4 copy stages) */
 } mi_scan_stats;
 int mi_scan_get_stats(mi_scan* s, mi_scan_stats* out);
 
