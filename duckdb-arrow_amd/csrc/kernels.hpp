@@ -96,6 +96,7 @@ struct Lz4Args {
   // source is one position whichever section it came from
   const void* zblocks;
   uint8_t* literals;
+  uint32_t* rep_state;            // ZSTD: 4 words per block and slice -- the slice's effect on the repeat offsets, then (zstd_layout) the offsets it starts from
 };
 inline uint32_t Lz4SeqCapacity(uint32_t comp_size) { return 256u * (((comp_size + 255u) / 256u) / 3u + 2u); }
 hipError_t LaunchLz4Decompress(const Lz4Args& args, int num_cus, hipStream_t stream);

@@ -36,6 +36,23 @@
 #include "zstd_format.hpp"
 
 namespace miarrow {
+namespace zstd {
+// zstd_format.hpp's memory accesses through global-address-space pointers (see Mem there)
+template <typename T>
+struct Mem<T __attribute__((address_space(1)))*> {
+  using P = T __attribute__((address_space(1)))*;
+  static __device__ __forceinline__ uint32_t Load32(P aligned) { return *(const uint32_t __attribute__((address_space(1)))*)aligned; }
+  static __device__ __forceinline__ void Store32(P aligned, uint32_t v) { *(uint32_t __attribute__((address_space(1)))*)aligned = v; }
+  static __device__ __forceinline__ uintptr_t Address(P p) { return (uintptr_t)p; }
+};
+template <typename T>
+struct Mem<T __attribute__((address_space(3)))*> {
+  using P = T __attribute__((address_space(3)))*;
+  static __device__ __forceinline__ uint32_t Load32(P aligned) { return *(const uint32_t __attribute__((address_space(3)))*)aligned; }
+  static __device__ __forceinline__ void Store32(P aligned, uint32_t v) { *(uint32_t __attribute__((address_space(3)))*)aligned = v; }
+  static __device__ __forceinline__ uintptr_t Address(P p) { return (uintptr_t)p; }
+};
+}  // namespace zstd
 namespace device {
 namespace {
 
@@ -429,8 +446,15 @@ __global__ __launch_bounds__(kBlockThreads) void lz4_expand(Lz4Args a) {
       }
       si = slo;
     }
+    // ZSTD: an offset may still name the repeat-offset history its slice started from (zstd_layout wrote it per slice)
+    gptr<const u32x4> rep = GC<u32x4>(a.rep_state) + static_cast<size_t>(bi) * kParseLanes;
+    auto offset_of = [&](uint32_t raw, uint32_t slice) -> uint32_t {
+      if (!(raw >> 31)) return raw;
+      const u32x4 h = rep[slice];
+      return zstd::RepResolve(raw, h.x, h.y, h.z);
+    };
     u32x4 d = seq[si];
-    uint32_t offset = seq_off[si];
+    uint32_t offset = offset_of(seq_off[si], k);
     const uint32_t c1 = c0 + kChunk < n_out ? c0 + kChunk : n_out;
 #pragma clang loop unroll(disable)
     for (uint32_t p0 = c0; p0 < c1; p0 += 4) {
@@ -452,7 +476,7 @@ __global__ __launch_bounds__(kBlockThreads) void lz4_expand(Lz4Args a) {
           if (nk == 0) break;                      // cannot happen for p < n_out; never spin
         }
         d = seq[si];
-        offset = seq_off[si];
+        offset = offset_of(seq_off[si], k);
       }
       const uint32_t r = p - lane_base - d.x;
       if (r < d.z) {
@@ -460,7 +484,7 @@ __global__ __launch_bounds__(kBlockThreads) void lz4_expand(Lz4Args a) {
       } else {
         const uint64_t m_at = base + lane_base + d.x + d.z;
         const uint32_t i = r - d.z;
-        if (i >= d.w || offset > m_at - buffer_lo) {   // reaches in front of the buffer: not a frame an encoder writes
+        if (i >= d.w || offset == 0 || offset > m_at - buffer_lo) {   // reaches in front of the buffer: not a frame an encoder writes
           bad = true;
           w[q] = kLinkKnown;
         } else {
@@ -629,7 +653,7 @@ hipError_t LaunchLz4Decompress(const Lz4Args& a, int num_cus, hipStream_t stream
   if (a.n_blocks == 0) return hipSuccess;
   if (a.zblocks) {
     hipLaunchKernelGGL(zstd_entropy, dim3(a.n_blocks), dim3(kZstdThreads), 0, stream, a);
-    hipLaunchKernelGGL(zstd_layout, dim3((a.n_buffers + 63) / 64), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(zstd_layout, dim3(a.n_buffers), dim3(64), 0, stream, a);
   } else {
     // compressed blocks below 64 KiB (64 KiB is the default block size of every writer) are walked from an LDS copy
     static const bool force_global = std::getenv("MI_LZ4_PARSE_GLOBAL") != nullptr;   // tests: the variant for blocks too large for LDS

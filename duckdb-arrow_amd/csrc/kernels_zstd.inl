@@ -8,33 +8,46 @@
 //                  4 lanes into the literal scratch (behind the compressed body, same allocation); wave 1 builds the three FSE
 //                  tables on 3 lanes and decodes the sequences on one: the descriptors {output position, literal source,
 //                  literal length, match length} + offset that lz4_expand reads, in 256 equal slices per block.
-//   zstd_layout    one lane per buffer, its blocks in order: first output byte of every block, the size check of the reference
-//                  (base_stream_reader.cpp:24-29), and the repeat offsets -- the only state that runs from block to block.
+//                  Repeat offsets -- the one state that runs from block to block -- are kept symbolic (zstd_format.hpp, RepStep):
+//                  a slice records its effect on the history as a function of the history it started from.
+//   zstd_layout    one wave per buffer, its blocks in order: first output byte of every block, the size check of the reference
+//                  (base_stream_reader.cpp:24-29), and a prefix scan over the 256 slice functions of each block that gives every
+//                  slice the history it really starts from; lz4_expand resolves a symbolic offset with it in one step.
 // From there on a ZSTD batch is an LZ4 batch: lz4_expand writes the link words, the resolve kernels follow them, lz4_emit
 // writes the bytes.  The serial chains (one table lookup in LDS per symbol) are latency-bound and leave the chip almost idle:
 // the scan runs the batches of several slots side by side.
 
 constexpr int kZstdThreads = 128;
+constexpr int kZstdWindowWords = 256;            // per literal stream: 1 KiB of the stream in LDS at a time
+constexpr int kZstdSeqWindowWords = 1024;        // the sequences' bitstream: 4 KiB at a time
+template <typename T>
+using ldsptr = T __attribute__((address_space(3)))*;
 
 __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a) {
   __shared__ uint16_t s_huf[1u << zstd::kHufMaxBits];
-  __shared__ zstd::FseCell s_ll[512], s_of[256], s_ml[512], s_wcells[64];
+  __shared__ zstd::FseCell s_ll[512], s_of[256], s_ml[512], s_wcells[64];   // 8 bytes a cell
   __shared__ uint8_t s_weights[256];
-  __shared__ int16_t s_counts[4][64];
+  __shared__ int16_t s_counts[5][64];
   __shared__ uint16_t s_next[4][64];
-  __shared__ uint32_t s_al[3], s_huf_bits, s_desc, s_fail;
+  __shared__ uint32_t s_al[3], s_huf_bits, s_desc, s_fail, s_bits_at;
+  __shared__ uint32_t s_win[4][kZstdWindowWords];
+  __shared__ uint32_t s_seqwin[kZstdSeqWindowWords];
   const uint32_t bi = blockIdx.x;
   const zstd::BlockInfo* zb = static_cast<const zstd::BlockInfo*>(a.zblocks);
   const zstd::BlockInfo z = zb[bi];
   const Lz4BlockDev b = a.blocks[bi];
-  const uint8_t* comp = a.comp;
-  uint8_t* arena = a.literals;
-  const uint8_t* c = comp + z.comp_off;
+  // every pointer the serial loops use names its address space: global for the body and the scratch, LDS for the tables (see
+  // zstd::Mem -- one FLAT access in such a loop costs an HBM round trip per symbol)
+  gptr<const uint8_t> comp = GC<uint8_t>(a.comp);
+  gptr<uint8_t> arena = GM<uint8_t>(a.literals);
+  gptr<const uint8_t> c = comp + z.comp_off;
+  ldsptr<uint16_t> huf = (ldsptr<uint16_t>)s_huf;
+  ldsptr<zstd::FseCell> t_ll = (ldsptr<zstd::FseCell>)s_ll, t_of = (ldsptr<zstd::FseCell>)s_of, t_ml = (ldsptr<zstd::FseCell>)s_ml;
   const uint32_t per = b.seq_cap / kParseLanes;   // descriptors per slice
   gptr<u32x4> seq = GM<u32x4>(a.seq) + b.seq_base;
   gptr<uint32_t> seq_off = GM<uint32_t>(a.seq_off) + b.seq_base;
-  uint32_t* lane_out = a.lane_out + static_cast<size_t>(bi) * kParseLanes;
-  uint32_t* lane_nseq = a.lane_nseq + static_cast<size_t>(bi) * kParseLanes;
+  gptr<uint32_t> lane_out = GM<uint32_t>(a.lane_out) + static_cast<size_t>(bi) * kParseLanes;
+  gptr<uint32_t> lane_nseq = GM<uint32_t>(a.lane_nseq) + static_cast<size_t>(bi) * kParseLanes;
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
   if (z.type == 0) {   // raw: lz4_expand copies it (Lz4BlockDev::stored)
     if (tid == 0) {
@@ -66,7 +79,8 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a) {
     if (lane == 0 && z.lit_type >= 2) {
       const zstd::BlockInfo hs = zb[z.huf_src];
       uint32_t bits = 0;
-      const uint32_t desc = zstd::ReadHuffmanTable(comp + hs.comp_off + hs.lit_hdr, hs.lit_comp, s_huf, &bits, s_weights, s_wcells, s_counts[3], s_next[3]);
+      const uint32_t desc = zstd::ReadHuffmanTable(comp + hs.comp_off + hs.lit_hdr, hs.lit_comp, huf, &bits, (ldsptr<uint8_t>)s_weights,
+                                                   (ldsptr<zstd::FseCell>)s_wcells, (ldsptr<int16_t>)s_counts[3], (ldsptr<uint16_t>)s_next[3]);
       if (!desc) s_fail = 1;
       s_desc = z.lit_type == 2 ? desc : 0;
       s_huf_bits = bits;
@@ -75,13 +89,21 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a) {
     const int t = static_cast<int>(lane);
     const zstd::BlockInfo sb = zb[t == 0 ? z.ll_src : t == 1 ? z.of_src : z.ml_src];
     const uint32_t so = sb.seq_pos + sb.seq_hdr;
-    zstd::FseCell* tab = t == 0 ? s_ll : t == 1 ? s_of : s_ml;
-    const uint32_t al = so < sb.comp_size ? zstd::BuildSequenceTable(comp + sb.comp_off + so, sb.comp_size - so, t, tab, s_counts[t], s_next[t]) : ~0u;
+    ldsptr<zstd::FseCell> tab = t == 0 ? t_ll : t == 1 ? t_of : t_ml;
+    const uint32_t al = so < sb.comp_size ? zstd::BuildSequenceTable(comp + sb.comp_off + so, sb.comp_size - so, t, tab, (ldsptr<int16_t>)s_counts[t],
+                                                                      (ldsptr<uint16_t>)s_next[t])
+                                          : ~0u;
     if (al == ~0u) s_fail = 1;
     s_al[t] = al;
+  } else if (lane == 3 && z.nseq) {   // where the block's own bitstream begins: behind its table descriptions
+    const uint32_t so = z.seq_pos + z.seq_hdr;
+    const uint32_t bo = zstd::SequenceBitstreamOffset(c + so, z.comp_size - so, (ldsptr<int16_t>)s_counts[4]);
+    if (bo == 0 || so + bo >= z.comp_size) s_fail = 1;
+    s_bits_at = so + bo;
   }
   __syncthreads();
   const bool failed = s_fail != 0;   // uniform
+  const uint32_t bits_at = z.nseq && !failed ? s_bits_at : 0, bits_len = z.nseq && !failed ? z.comp_size - bits_at : 0;
   // --- streams --------------------------------------------------------------------------------------------------------
   if (wave == 0) {
     if (failed) return;
@@ -92,7 +114,11 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a) {
       uint32_t first, nbytes, out0, nsym;
       bool ok = zstd::LiteralStream(z, c, s_desc, lane, &first, &nbytes, &out0, &nsym);
       ok = ok && first + nbytes <= z.comp_size;
-      ok = ok && zstd::DecodeHuffmanStream(c + first, nbytes, nsym, s_huf, s_huf_bits, arena + z.lit_pos + out0);
+      // the stream is read through a window in LDS that the lane refills itself: between refills the loop touches HBM only to
+      // store (a load would wait for the last store -- one counter for both -- at every refill of the bit buffer)
+      zstd::BackBits<gptr<const uint8_t>, zstd::WindowWords<gptr<const uint8_t>, ldsptr<uint32_t>, kZstdWindowWords>> br;
+      br.src.win = (ldsptr<uint32_t>)s_win[lane];
+      ok = ok && zstd::DecodeHuffmanStream(br, c + first, nbytes, nsym, huf, s_huf_bits, arena + z.lit_pos + out0);
       if (!ok) lz4_fail(a.status);   // the block's size is still reported by wave 1; the batch is rejected through the status word
     }
     return;
@@ -102,11 +128,24 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a) {
   }
   // wave 1, lane 0: the sequences
   uint32_t out_pos = 0, lit_used = 0, k = 0, j = 0, lane_base = 0, n_desc = 0;
+  uint32_t S[3] = {zstd::RepSlot(0), zstd::RepSlot(1), zstd::RepSlot(2)};   // the history, as a function of the slice's start
+  gptr<u32x4> rep_fn = GM<u32x4>(a.rep_state) + static_cast<size_t>(bi) * kParseLanes;
+  auto close_slice = [&]() {
+    u32x4 f;
+    f.x = S[0]; f.y = S[1]; f.z = S[2]; f.w = 0;
+    rep_fn[k] = f;
+    S[0] = zstd::RepSlot(0); S[1] = zstd::RepSlot(1); S[2] = zstd::RepSlot(2);
+  };
   bool ok = !failed;
-  auto put = [&](uint32_t ll, uint32_t ml, uint32_t off) {
+  auto put = [&](uint32_t ll, uint32_t ml, uint32_t code) {
     if (j == 0) {
       lane_base = out_pos;
       lane_out[k] = out_pos;
+    }
+    uint32_t off = 0;
+    if (ml) {
+      off = zstd::RepStep(code, S);
+      if (off == 0) ok = false;
     }
     u32x4 d;
     d.x = out_pos - lane_base;
@@ -120,21 +159,21 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a) {
     n_desc++;
     if (++j == per) {
       lane_nseq[k] = per;
+      close_slice();
       k++;
       j = 0;
     }
   };
   if (ok && z.nseq) {
-    const uint32_t so = z.seq_pos + z.seq_hdr;
-    const uint32_t bo = zstd::SequenceBitstreamOffset(c + so, z.comp_size - so, s_counts[3]);
-    ok = bo != 0 && so + bo < z.comp_size;
-    if (ok)
-      ok = zstd::DecodeSequences(c + so + bo, z.comp_size - so - bo, z.nseq, s_ll, s_al[0], s_of, s_al[1], s_ml, s_al[2],
-                                 [&](uint32_t, uint32_t ll, uint32_t ml, uint32_t off) {
-                                   if (ll > z.lit_regen - lit_used || ll + ml > zstd::kBlockMax - out_pos) return false;
-                                   put(ll, ml, off);
-                                   return true;
-                                 });
+    auto emit = [&](uint32_t, uint32_t ll, uint32_t ml, uint32_t code) {
+      if (ll > z.lit_regen - lit_used || ll + ml > zstd::kBlockMax - out_pos) return false;
+      put(ll, ml, code);
+      return ok;
+    };
+    // like the literal streams: read through a window in LDS, so that the loop's only traffic to HBM is its stores
+    zstd::BackBits<gptr<const uint8_t>, zstd::WindowWords<gptr<const uint8_t>, ldsptr<uint32_t>, kZstdSeqWindowWords>> br;
+    br.src.win = (ldsptr<uint32_t>)s_seqwin;
+    ok = zstd::DecodeSequences(br, c + bits_at, bits_len, z.nseq, t_ll, s_al[0], t_of, s_al[1], t_ml, s_al[2], emit);
   }
   if (ok && lit_used < z.lit_regen) {
     ok = z.lit_regen - lit_used <= zstd::kBlockMax - out_pos;
@@ -147,50 +186,73 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a) {
     k = 0;
     j = 0;
   }
-  if (j) lane_nseq[k++] = j;
-  for (; k < kParseLanes; k++) {   // empty slices begin where the block ends
+  if (j) {
+    lane_nseq[k] = j;
+    close_slice();
+    k++;
+  }
+  S[0] = zstd::RepSlot(0); S[1] = zstd::RepSlot(1); S[2] = zstd::RepSlot(2);
+  for (; k < kParseLanes; k++) {   // empty slices begin where the block ends and leave the history as it is
     lane_out[k] = out_pos;
     lane_nseq[k] = 0;
+    close_slice();
   }
   a.block_out_size[bi] = out_pos;
   a.block_nseq[bi] = n_desc;
 }
 
 __global__ __launch_bounds__(64) void zstd_layout(Lz4Args a) {
-  const uint32_t u = blockIdx.x * 64 + threadIdx.x;
-  if (u >= a.n_buffers) return;
+  const uint32_t u = blockIdx.x, lane = threadIdx.x;   // one wave per buffer
   const Lz4BufferDev f = a.buffers[u];
   const zstd::BlockInfo* zb = static_cast<const zstd::BlockInfo*>(a.zblocks);
   uint64_t at = f.out_off;
-  uint32_t rep[3] = {1, 4, 8};
-  bool ok = true;
+  uint32_t r0 = 1, r1 = 4, r2 = 8;   // the frame's history at its start (uniform across the wave)
   for (uint32_t kb = 0; kb < f.n_blocks; kb++) {
     const uint32_t bi = f.first_block + kb;
-    a.block_out_base[bi] = at;
+    if (lane == 0) a.block_out_base[bi] = at;
     at += a.block_out_size[bi];
-    if (zb[bi].type != 2) continue;
-    // the block's descriptors in order: slice after slice, `per` in each but the last
-    const Lz4BlockDev b = a.blocks[bi];
-    const uint32_t n = a.block_nseq[bi];
-    gptr<uint32_t> so = GM<uint32_t>(a.seq_off) + b.seq_base;   // slices are dense: descriptor i sits at i
-    uint32_t i = 0;
-    for (; i + 4 <= n; i += 4) {   // the loads do not depend on the history: four in flight
-      const uint32_t o0 = so[i], o1 = so[i + 1], o2 = so[i + 2], o3 = so[i + 3];
-      uint32_t r;
-      if (o0) { r = zstd::ResolveRepeat(o0, rep); ok &= r != 0; if (o0 >> 31) so[i] = r; }
-      if (o1) { r = zstd::ResolveRepeat(o1, rep); ok &= r != 0; if (o1 >> 31) so[i + 1] = r; }
-      if (o2) { r = zstd::ResolveRepeat(o2, rep); ok &= r != 0; if (o2 >> 31) so[i + 2] = r; }
-      if (o3) { r = zstd::ResolveRepeat(o3, rep); ok &= r != 0; if (o3 >> 31) so[i + 3] = r; }
+    if (zb[bi].type != 2) continue;   // raw and RLE blocks leave the history alone
+    // 4 slices per lane: their functions, the lane's total, an inclusive scan of the totals over the wave
+    gptr<u32x4> fn = GM<u32x4>(a.rep_state) + static_cast<size_t>(bi) * kParseLanes + 4 * lane;
+    const u32x4 f0 = fn[0], f1 = fn[1], f2 = fn[2], f3 = fn[3];
+    auto after = [](const u32x4& g, uint32_t x, uint32_t y, uint32_t z) {   // g applied to the state (x, y, z)
+      u32x4 r;
+      r.x = zstd::RepResolve(g.x, x, y, z);
+      r.y = zstd::RepResolve(g.y, x, y, z);
+      r.z = zstd::RepResolve(g.z, x, y, z);
+      r.w = 0;
+      return r;
+    };
+    u32x4 t = after(f1, f0.x, f0.y, f0.z);
+    t = after(f2, t.x, t.y, t.z);
+    t = after(f3, t.x, t.y, t.z);
+    u32x4 inc = t;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+      const uint32_t px = __shfl_up(inc.x, d), py = __shfl_up(inc.y, d), pz = __shfl_up(inc.z, d);
+      if (lane >= d) inc = after(inc, px, py, pz);
     }
-    for (; i < n; i++) {
-      const uint32_t o = so[i];
-      if (!o) continue;
-      const uint32_t r = zstd::ResolveRepeat(o, rep);
-      ok &= r != 0;
-      if (o >> 31) so[i] = r;
-    }
+    uint32_t ex = __shfl_up(inc.x, 1), ey = __shfl_up(inc.y, 1), ez = __shfl_up(inc.z, 1);
+    if (lane == 0) { ex = zstd::RepSlot(0); ey = zstd::RepSlot(1); ez = zstd::RepSlot(2); }
+    // the history each of the lane's slices starts from: concrete from here on
+    u32x4 s0;
+    s0.x = zstd::RepResolve(ex, r0, r1, r2);
+    s0.y = zstd::RepResolve(ey, r0, r1, r2);
+    s0.z = zstd::RepResolve(ez, r0, r1, r2);
+    s0.w = 0;
+    const u32x4 s1 = after(f0, s0.x, s0.y, s0.z), s2 = after(f1, s1.x, s1.y, s1.z), s3 = after(f2, s2.x, s2.y, s2.z);
+    fn[0] = s0;
+    fn[1] = s1;
+    fn[2] = s2;
+    fn[3] = s3;
+    const u32x4 end = after(inc, r0, r1, r2);   // lane 63: the whole block
+    r0 = __shfl(end.x, 63);
+    r1 = __shfl(end.y, 63);
+    r2 = __shfl(end.z, 63);
   }
-  ok = ok && at - f.out_off == f.out_len;
-  a.buffer_ok[u] = ok ? 1u : 0u;
-  if (!ok) lz4_fail(a.status);
+  if (lane == 0) {
+    const bool ok = at - f.out_off == f.out_len;
+    a.buffer_ok[u] = ok ? 1u : 0u;
+    if (!ok) lz4_fail(a.status);
+  }
 }

@@ -127,7 +127,9 @@ void ArrowScan::OpenSource(size_t i) {
   // bodies are decompressed by the reader's host threads: on this platform D2H copies run as copy kernels, which then
   // queue up with the K8 kernels instead of overlapping them (SF10: 0.85 s against 0.68 s, tools/lz4_bench.py)
   s.reader->SetDeferLz4(opts.host_decompress < 0 || (opts.host_decompress == 0 && opts.device_resident != 0));
-  s.reader->SetDeferZstd(opts.host_decompress < 0 || (opts.host_decompress == 0 && opts.device_resident != 0));
+  // ZSTD in HBM only on request: its entropy stage is one serial chain per 128 KiB block, so it pays when many record batches
+  // run side by side -- with the HIP runtime's default of 4 hardware queues the reader's host threads are faster
+  s.reader->SetDeferZstd(opts.host_decompress < 0);
   s.reader->GetBaseSchema();
   s.opened = true;
 }
@@ -873,7 +875,8 @@ void ArrowScan::EnqueueLz4(Slot& s) {
     // the slots share kLz4Streams streams (slot i uses stream i mod 3): the K8 kernels of neighbouring record batches overlap
     // -- the token walk is latency-bound and leaves the chip idle -- without every slot holding a hardware queue of its own
     // (one stream: 0.65 s for SF10, two 0.42, three 0.39, one per slot (8) 0.46)
-    constexpr int kLz4Streams = 3;
+    // ZSTD: the entropy stage is one serial chain per block (milliseconds, a few lanes busy): more batches side by side
+    const int kLz4Streams = d.codec == 1 ? 16 : 3;
     const int idx = static_cast<int>(&s - slots.data());
     if (idx >= kLz4Streams) {
       Slot& owner = slots[static_cast<size_t>(idx % kLz4Streams)];
@@ -903,7 +906,7 @@ void ArrowScan::EnqueueLz4(Slot& s) {
                o_status = take(4), o_mark = take(out_size + 16);
   const size_t counters_end = at;
   const size_t o_seq = take(static_cast<size_t>(total_seq) * 16), o_seqoff = take(static_cast<size_t>(total_seq) * 4);
-  const size_t o_lane_out = take(nb * 256 * 4), o_lane_n = take(nb * 256 * 4);
+  const size_t o_lane_out = take(nb * 256 * 4), o_lane_n = take(nb * 256 * 4), o_rep = take(is_zstd ? nb * 256 * 16 : 0);
   const size_t o_link = take(out_size * 4 + 16), o_skel = take(out_size * 4 + 16);
   if (at > s.d_lz4_cap) {
     if (s.d_lz4) MI_HIP_CHECK(hipFree(s.d_lz4));
@@ -998,7 +1001,7 @@ void ArrowScan::EnqueueLz4(Slot& s) {
   a.n_blocks = static_cast<uint32_t>(nb);
   a.n_buffers = static_cast<uint32_t>(nf);
   for (auto& blk : d.blocks)
-    if (!blk.stored) a.max_block_comp = std::max(a.max_block_comp, blk.comp_size);
+    if (!blk.stored && !is_zstd) a.max_block_comp = std::max(a.max_block_comp, blk.comp_size);
   a.seq = s.d_lz4 + o_seq;
   a.seq_off = reinterpret_cast<uint32_t*>(s.d_lz4 + o_seqoff);
   a.lane_out = reinterpret_cast<uint32_t*>(s.d_lz4 + o_lane_out);
@@ -1014,6 +1017,7 @@ void ArrowScan::EnqueueLz4(Slot& s) {
   a.status = reinterpret_cast<uint32_t*>(s.d_lz4 + o_status);
   a.zblocks = is_zstd ? s.d_lz4 + o_zblocks : nullptr;
   a.literals = s.d_comp;
+  a.rep_state = is_zstd ? reinterpret_cast<uint32_t*>(s.d_lz4 + o_rep) : nullptr;
   MI_HIP_CHECK(device::LaunchLz4Decompress(a, ctx->num_cus, q));
   MI_HIP_CHECK(hipMemcpyAsync(&s.h_status[2], a.status, sizeof(uint32_t), hipMemcpyDeviceToHost, q));
   MI_HIP_CHECK(hipMemcpyAsync(&s.h_status[4], a.round_left + 37, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, q));

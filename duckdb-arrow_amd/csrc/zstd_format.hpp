@@ -77,81 +77,119 @@ MI_ZHD int32_t DefaultCount(int type, uint32_t s) {
 MI_ZHD uint32_t DefaultLog(int type) { return type == kOF ? 5u : 6u; }
 MI_ZHD uint32_t DefaultSymbols(int type) { return type == kLL ? 36u : type == kOF ? 29u : 53u; }
 
-// One cell of an FSE decoding table: the state IS the index of the cell.
-struct FseCell {
-  uint32_t base;       // sequences: base value of the code; weights: the symbol
-  uint16_t next;       // next state = next + the `nbits` bits read
-  uint8_t nbits;
-  uint8_t extra;       // sequences: additional bits of the code's value
-};
+// One cell of an FSE decoding table (the state IS the index of the cell), packed into 8 bytes so that a table lives in any
+// address space as plain integers: base value of the code (weights: the symbol) | next << 32 | nbits << 48 | extra << 56, with
+// next state = next + the `nbits` bits read, and `extra` = additional bits of the code's value.
+using FseCell = uint64_t;
+MI_ZHD FseCell MakeCell(uint32_t base, uint32_t next, uint32_t nbits, uint32_t extra) {
+  return static_cast<uint64_t>(base) | (static_cast<uint64_t>(next) << 32) | (static_cast<uint64_t>(nbits) << 48) | (static_cast<uint64_t>(extra) << 56);
+}
+MI_ZHD uint32_t CellBase(FseCell c) { return static_cast<uint32_t>(c); }
+MI_ZHD uint32_t CellNext(FseCell c) { return static_cast<uint32_t>(c >> 32) & 0xFFFFu; }
+MI_ZHD uint32_t CellBits(FseCell c) { return static_cast<uint32_t>(c >> 48) & 0xFFu; }
+MI_ZHD uint32_t CellExtra(FseCell c) { return static_cast<uint32_t>(c >> 56); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Backward bitstream: the last byte's highest set bit ends the stream, bits are taken from just below it towards the first
-// byte.  The stream is consumed strictly front to back (in its own direction), so the 8-byte words are loaded ahead of their
-// use (two words: a load that the next symbol waits for would put HBM / L2 latency into every step of a serial chain).
-// Words are ALIGNED loads: positions are counted from the 8-byte boundary at or before the first byte; what lies in front of
-// the stream reads as zero -- the format's rule for a stream that runs out (the caller sees Left() < 0).
-struct BackBits {
-  const uint64_t* words;   // aligned base
-  int64_t p;               // position of the read head (bits below it are unread), counted from words[0] bit 0
-  int64_t wbase;           // position of lo's bit 0
-  uint32_t bias;           // position of the stream's first bit
-  uint64_t lo, hi, n1, n2; // words at wbase, wbase + 64, wbase - 64, wbase - 128
+// byte.  The unread bits sit at the TOP of a 64-bit buffer (a peek is one shift), a 32-bit word enters below them whenever 32
+// or fewer are left.  Words are ALIGNED loads, counted from the 4-byte boundary at or before the first byte; what lies in front
+// of the stream reads as zero -- the format's rule for a stream that runs out (the caller sees Left() < 0).
+// Where the words come from is a policy: DirectWords loads each one from the stream when it is needed (short streams, streams
+// staged in LDS); WindowWords keeps the next W words in a small window of fast memory that the reader refills itself, W words
+// at a time.  On the GPU the window is LDS: a decode loop that both loads from and stores to HBM would wait for its last store
+// at every refill (loads and stores retire through one counter), with the window it touches HBM once per W words.
 
-  MI_ZHD uint64_t Word(int64_t idx) const {
-    if (idx < 0) return 0;
-    uint64_t w = words[idx];
-    if (idx == 0 && bias) w &= ~uint64_t(0) << bias;
-    return w;
+// How aligned words are loaded / stored through a byte pointer of type P.  Plain pointers here; the device build adds the
+// specialisations for global- and LDS-address-space pointers (kernels_lz4.hip), so that the serial loops below never issue a
+// FLAT access: a flat load or store counts on both wait counters, and every table lookup in LDS would wait for the last store.
+template <typename P>
+struct Mem {
+  static MI_ZHD uint32_t Load32(P aligned) { return *reinterpret_cast<const uint32_t*>(aligned); }
+  static MI_ZHD void Store32(P aligned, uint32_t v) { *reinterpret_cast<uint32_t*>(aligned) = v; }
+  static MI_ZHD uintptr_t Address(P p) { return reinterpret_cast<uintptr_t>(p); }
+};
+
+template <typename BP>
+struct DirectWords {
+  BP base;
+  MI_ZHD void Init(BP b, int32_t) { base = b; }
+  MI_ZHD uint32_t Get(int32_t idx) { return Mem<BP>::Load32(base + 4 * (idx < 0 ? 0 : idx)); }   // always a readable address
+};
+template <typename BP, typename LP, int W>   // LP: pointer to W uint32 of fast memory, set by the caller before Open
+struct WindowWords {
+  BP base;
+  LP win;
+  int32_t lo;   // the window holds the words lo .. lo + W - 1
+  MI_ZHD void Init(BP b, int32_t top) {
+    base = b;
+    lo = top + 1;   // nothing yet
+  }
+  MI_ZHD uint32_t Get(int32_t idx) {   // idx only ever goes down
+    if (idx < lo) {
+      lo = idx - (W - 1);
+      for (int j = 0; j < W; j++) win[j] = Mem<BP>::Load32(base + 4 * (lo + j < 0 ? 0 : lo + j));
+    }
+    return win[idx - lo];
+  }
+};
+
+template <typename BP, typename SRC = DirectWords<BP>>
+struct BackBits {
+  SRC src;
+  uint64_t buf;            // unread bits, the next one in bit 63
+  int32_t cnt;             // valid bits in buf: 33 .. 64 between calls (while the stream lasts)
+  int32_t left;            // unread bits of the stream (negative: more were taken than it holds)
+  int32_t next;            // index of the word that enters at the next refill (negative: in front of the stream)
+  uint32_t first_mask;     // word 0 without the bytes in front of the stream
+
+  MI_ZHD uint32_t Word(int32_t idx) {
+    const uint32_t w = src.Get(idx);
+    return idx > 0 ? w : idx == 0 ? (w & first_mask) : 0u;
+  }
+  MI_ZHD void Refill() {   // cnt <= 32
+    buf |= static_cast<uint64_t>(Word(next)) << (32 - cnt);
+    cnt += 32;
+    next--;
   }
   // false: the stream is empty or its last byte is zero (no end mark)
-  MI_ZHD bool Open(const uint8_t* first, uint32_t nbytes) {
+  MI_ZHD bool Open(BP first, uint32_t nbytes) {
     if (nbytes == 0) return false;
     const uint8_t last = first[nbytes - 1];
     if (last == 0) return false;
-    const uintptr_t addr = reinterpret_cast<uintptr_t>(first);
-    words = reinterpret_cast<const uint64_t*>(addr & ~uintptr_t(7));
-    bias = static_cast<uint32_t>(addr & 7u) * 8u;
-    p = static_cast<int64_t>(bias) + 8 * static_cast<int64_t>(nbytes - 1) + HighBit(last);
-    const int64_t top = (p - 1) >> 6;   // word of the first bit to read (p >= bias, so top >= -1 only when the stream holds no bit)
-    wbase = (top - 1) * 64;
-    hi = Word(top);
-    lo = Word(top - 1);
-    n1 = Word(top - 2);
-    n2 = Word(top - 3);
+    const uint32_t mis = static_cast<uint32_t>(Mem<BP>::Address(first) & 3u);
+    first_mask = ~0u << (8 * mis);
+    left = 8 * static_cast<int32_t>(nbytes - 1) + static_cast<int32_t>(HighBit(last));
+    const int32_t p = left + 8 * static_cast<int32_t>(mis);    // position of the read head, counted from the aligned base
+    const int32_t top = p > 0 ? (p - 1) >> 5 : 0;                // word of the first bit to read
+    const int32_t r = p - 32 * top;                             // bits of that word below the head: 1 .. 32 (0: no bit at all)
+    src.Init(first - mis, top);
+    const uint32_t w = Word(top);
+    buf = r > 0 ? static_cast<uint64_t>(r == 32 ? w : (w & ((1u << r) - 1u))) << (64 - r) : 0;
+    cnt = r;
+    next = top - 1;
+    Refill();
+    if (cnt <= 32) Refill();
     return true;
   }
-  MI_ZHD int64_t Left() const { return p - static_cast<int64_t>(bias); }
-  MI_ZHD uint64_t Window(uint32_t n) const {   // the n bits below the read head, n <= 57
-    const uint32_t off = static_cast<uint32_t>(p - static_cast<int64_t>(n) - wbase);   // 0 .. 127
-    uint64_t v;
-    if (off >= 64) v = hi >> (off - 64);
-    else if (off == 0) v = lo;
-    else v = (lo >> off) | (hi << (64 - off));
-    return v & ((uint64_t(1) << n) - 1);
+  MI_ZHD int32_t Left() const { return left; }
+  MI_ZHD uint32_t Peek(uint32_t n) const { return static_cast<uint32_t>((buf >> 1) >> (63 - n)); }   // n <= 32; 0 gives 0
+  MI_ZHD void Skip(uint32_t n) {   // n <= 32
+    buf <<= n;
+    cnt -= static_cast<int32_t>(n);
+    left -= static_cast<int32_t>(n);
+    if (cnt <= 32) Refill();
   }
-  MI_ZHD void Skip(uint32_t n) {
-    p -= n;
-    if (p <= wbase + 64) {   // the head left the upper word
-      hi = lo;
-      lo = n1;
-      n1 = n2;
-      wbase -= 64;
-      n2 = Word((wbase >> 6) - 2);
-    }
-  }
-  MI_ZHD uint32_t Peek(uint32_t n) const { return n ? static_cast<uint32_t>(Window(n)) : 0u; }   // n <= 32
   MI_ZHD uint32_t Read(uint32_t n) {
-    if (n == 0) return 0;
-    const uint32_t v = static_cast<uint32_t>(Window(n));
+    const uint32_t v = Peek(n);
     Skip(n);
     return v;
   }
 };
 
 // Forward bits of a table description (a few dozen bytes): byte loads, no state worth keeping.
+template <typename BP>
 struct FwdBits {
-  const uint8_t* src;
+  BP src;
   uint32_t pos;
   MI_ZHD uint32_t Peek(uint32_t n) const {   // n <= 16
     const uint32_t b = pos >> 3;
@@ -167,10 +205,11 @@ struct FwdBits {
 
 // FSE table description -> normalized counts (-1 = "less than one").  Returns the bytes it occupies, 0 = malformed.
 // `src` must be readable for 3 bytes past `avail` (the bodies carry that much padding).
-MI_ZHD uint32_t ReadNCount(const uint8_t* src, uint32_t avail, int type, int16_t* counts, uint32_t* log_out, uint32_t* nsym_out) {
+template <typename BP, typename CP>
+MI_ZHD uint32_t ReadNCount(BP src, uint32_t avail, int type, CP counts, uint32_t* log_out, uint32_t* nsym_out) {
   if (avail == 0) return 0;
   const uint32_t max_sym = MaxSym(type);
-  FwdBits f{src, 0};
+  FwdBits<BP> f{src, 0};
   const uint32_t al = 5 + f.Read(4);
   if (al > MaxLog(type)) return 0;
   int32_t remaining = (1 << al) + 1, threshold = 1 << al;
@@ -217,12 +256,13 @@ MI_ZHD uint32_t ReadNCount(const uint8_t* src, uint32_t avail, int type, int16_t
 }
 
 // Normalized counts -> decoding table of 1 << al cells.  `next` is scratch for one uint16 per symbol.
-MI_ZHD bool BuildFseTable(const int16_t* counts, uint32_t nsym, uint32_t al, int type, FseCell* table, uint16_t* next) {
+template <typename CP, typename TP, typename NP>
+MI_ZHD bool BuildFseTable(CP counts, uint32_t nsym, uint32_t al, int type, TP table, NP next) {
   const uint32_t size = 1u << al, mask = size - 1;
   uint32_t high = size - 1;
   for (uint32_t s = 0; s < nsym; s++) {
     if (counts[s] == -1) {
-      table[high--].base = s;
+      table[high--] = s;   // until the last loop a cell holds its symbol
       next[s] = 1;
     } else {
       next[s] = static_cast<uint16_t>(counts[s]);
@@ -232,41 +272,35 @@ MI_ZHD bool BuildFseTable(const int16_t* counts, uint32_t nsym, uint32_t al, int
   uint32_t pos = 0;
   for (uint32_t s = 0; s < nsym; s++) {
     for (int32_t i = 0; i < counts[s]; i++) {
-      table[pos].base = s;
+      table[pos] = s;
       do pos = (pos + step) & mask; while (pos > high);
     }
   }
   if (pos != 0) return false;
   for (uint32_t u = 0; u < size; u++) {
-    const uint32_t s = table[u].base;
-    const uint32_t ns = next[s]++;
+    const uint32_t s = static_cast<uint32_t>(table[u]);
+    const uint32_t ns = next[s];
+    next[s] = static_cast<uint16_t>(ns + 1);
     const uint32_t nbits = al - HighBit(ns);
-    FseCell c;
-    c.nbits = static_cast<uint8_t>(nbits);
-    c.next = static_cast<uint16_t>((ns << nbits) - size);
-    if (type == kLL) { c.base = LlBase(s); c.extra = static_cast<uint8_t>(LlBits(s)); }
-    else if (type == kML) { c.base = MlBase(s); c.extra = static_cast<uint8_t>(MlBits(s)); }
-    else if (type == kOF) { c.base = 1u << s; c.extra = static_cast<uint8_t>(s); }
-    else { c.base = s; c.extra = 0; }
-    table[u] = c;
+    const uint32_t nx = (ns << nbits) - size;
+    if (type == kLL) table[u] = MakeCell(LlBase(s), nx, nbits, LlBits(s));
+    else if (type == kML) table[u] = MakeCell(MlBase(s), nx, nbits, MlBits(s));
+    else if (type == kOF) table[u] = MakeCell(1u << s, nx, nbits, s);
+    else table[u] = MakeCell(s, nx, nbits, 0);
   }
   return true;
 }
-MI_ZHD void BuildRleTable(uint32_t s, int type, FseCell* table) {
-  FseCell c;
-  c.nbits = 0;
-  c.next = 0;
-  if (type == kLL) { c.base = LlBase(s); c.extra = static_cast<uint8_t>(LlBits(s)); }
-  else if (type == kML) { c.base = MlBase(s); c.extra = static_cast<uint8_t>(MlBits(s)); }
-  else { c.base = 1u << s; c.extra = static_cast<uint8_t>(s); }
-  table[0] = c;
+template <typename TP>
+MI_ZHD void BuildRleTable(uint32_t s, int type, TP table) {
+  table[0] = type == kLL ? MakeCell(LlBase(s), 0, 0, LlBits(s)) : type == kML ? MakeCell(MlBase(s), 0, 0, MlBits(s)) : MakeCell(1u << s, 0, 0, s);
 }
 
 // One of the three sequence tables of a block from the block's own bytes.  `seq` = the sequences section behind its count
 // (at the modes byte), `avail` = bytes from there to the end of the block; mode 3 (repeat) is resolved by the caller (it
 // passes the earlier block the table comes from).  Returns the accuracy log, ~0u = malformed.  counts/next: scratch
 // (53 entries are enough).
-MI_ZHD uint32_t BuildSequenceTable(const uint8_t* seq, uint32_t avail, int type, FseCell* table, int16_t* counts, uint16_t* next) {
+template <typename BP, typename TP, typename CP, typename NP>
+MI_ZHD uint32_t BuildSequenceTable(BP seq, uint32_t avail, int type, TP table, CP counts, NP next) {
   if (avail < 1) return ~0u;
   const uint32_t modes = seq[0];
   uint32_t at = 1;
@@ -303,7 +337,8 @@ MI_ZHD uint32_t BuildSequenceTable(const uint8_t* seq, uint32_t avail, int type,
   return ~0u;
 }
 // Where the bitstream of the sequences section begins, counted from the modes byte (0 = malformed).
-MI_ZHD uint32_t SequenceBitstreamOffset(const uint8_t* seq, uint32_t avail, int16_t* counts) {
+template <typename BP, typename CP>
+MI_ZHD uint32_t SequenceBitstreamOffset(BP seq, uint32_t avail, CP counts) {
   if (avail < 1) return 0;
   const uint32_t modes = seq[0];
   if (modes & 3u) return 0;   // reserved bits
@@ -325,8 +360,8 @@ MI_ZHD uint32_t SequenceBitstreamOffset(const uint8_t* seq, uint32_t avail, int1
 // Huffman tree description -> decoding table of 1 << max_bits cells {symbol | nbits << 8}.  Returns the bytes of the
 // description (0 = malformed).  weights: 256 bytes of scratch; cells / counts / next: scratch for the weights' own FSE table
 // (64 cells, 16 counts).
-MI_ZHD uint32_t ReadHuffmanTable(const uint8_t* src, uint32_t avail, uint16_t* table, uint32_t* max_bits_out, uint8_t* weights, FseCell* cells,
-                                 int16_t* counts, uint16_t* next) {
+template <typename BP, typename HP, typename WP, typename TP, typename CP, typename NP>
+MI_ZHD uint32_t ReadHuffmanTable(BP src, uint32_t avail, HP table, uint32_t* max_bits_out, WP weights, TP cells, CP counts, NP next) {
   if (avail < 1) return 0;
   const uint32_t hb = src[0];
   uint32_t n = 0, used;
@@ -342,25 +377,25 @@ MI_ZHD uint32_t ReadHuffmanTable(const uint8_t* src, uint32_t avail, uint16_t* t
     const uint32_t hdr = ReadNCount(src + 1, hb, kWeights, counts, &al, &ns);
     if (!hdr || hdr >= hb) return 0;
     if (!BuildFseTable(counts, ns, al, kWeights, cells, next)) return 0;
-    BackBits br;
+    BackBits<BP> br;
     if (!br.Open(src + 1 + hdr, hb - hdr)) return 0;
     uint32_t s1 = br.Read(al), s2 = br.Read(al);
     if (br.Left() < 0) return 0;
     for (;;) {
       if (n > 253) return 0;
       FseCell c = cells[s1];
-      weights[n++] = static_cast<uint8_t>(c.base);
-      s1 = c.next + br.Read(c.nbits);
+      weights[n++] = static_cast<uint8_t>(CellBase(c));
+      s1 = CellNext(c) + br.Read(CellBits(c));
       if (br.Left() < 0) {
-        weights[n++] = static_cast<uint8_t>(cells[s2].base);
+        weights[n++] = static_cast<uint8_t>(CellBase(cells[s2]));
         break;
       }
       if (n > 253) return 0;
       c = cells[s2];
-      weights[n++] = static_cast<uint8_t>(c.base);
-      s2 = c.next + br.Read(c.nbits);
+      weights[n++] = static_cast<uint8_t>(CellBase(c));
+      s2 = CellNext(c) + br.Read(CellBits(c));
       if (br.Left() < 0) {
-        weights[n++] = static_cast<uint8_t>(cells[s1].base);
+        weights[n++] = static_cast<uint8_t>(CellBase(cells[s1]));
         break;
       }
     }
@@ -395,7 +430,8 @@ MI_ZHD uint32_t ReadHuffmanTable(const uint8_t* src, uint32_t avail, uint16_t* t
 
 // Stream s (0..3, or 0 of 1) of a Huffman-coded literals section: its bytes (from the block's first byte), the literals it
 // decodes and where they go.  desc_bytes = size of the tree description in front of the streams (0: treeless).
-MI_ZHD bool LiteralStream(const BlockInfo& z, const uint8_t* block, uint32_t desc_bytes, uint32_t s, uint32_t* first, uint32_t* nbytes,
+template <typename BP>
+MI_ZHD bool LiteralStream(const BlockInfo& z, BP block, uint32_t desc_bytes, uint32_t s, uint32_t* first, uint32_t* nbytes,
                           uint32_t* out0, uint32_t* nsym) {
   if (desc_bytes >= z.lit_comp) return false;
   const uint32_t at = z.lit_hdr + desc_bytes, total = z.lit_comp - desc_bytes;
@@ -419,37 +455,48 @@ MI_ZHD bool LiteralStream(const BlockInfo& z, const uint8_t* block, uint32_t des
   return true;
 }
 
-// One Huffman-coded stream -> nsym literals.  false = the stream does not end where its symbols do.
-template <typename OUT>
-MI_ZHD bool DecodeHuffmanStream(const uint8_t* first, uint32_t nbytes, uint32_t nsym, const uint16_t* table, uint32_t max_bits, OUT out) {
-  BackBits br;
+// One Huffman-coded stream -> nsym literals.  false = the stream does not end where its symbols do.  `br` is the caller's
+// reader (a WindowWords reader has its window set).  Four literals leave as one aligned 32-bit store.
+template <typename READER, typename BP, typename HP, typename OP>
+MI_ZHD bool DecodeHuffmanStream(READER& br, BP first, uint32_t nbytes, uint32_t nsym, HP table, uint32_t max_bits, OP out) {
   if (!br.Open(first, nbytes)) return false;
+  const uint32_t addr = static_cast<uint32_t>(Mem<OP>::Address(out));
+  uint32_t acc = 0, fill = 0;
   for (uint32_t i = 0; i < nsym; i++) {
     const uint32_t c = table[br.Peek(max_bits)];
-    out[i] = static_cast<uint8_t>(c);
     br.Skip(c >> 8);
+    const uint32_t sym = c & 0xFFu;
+    if (fill == 0 && (((addr + i) & 3u) != 0 || i + 4 > nsym)) {
+      out[i] = static_cast<uint8_t>(sym);
+    } else {
+      acc |= sym << (8 * fill);
+      if (++fill == 4) {
+        Mem<OP>::Store32(out + (i - 3), acc);
+        acc = 0;
+        fill = 0;
+      }
+    }
   }
   return br.Left() == 0;
 }
 
 // The sequences of one block.  emit(i, literal_length, match_length, offset_or_marker); offsets that name a repeat offset
 // leave as kRepMarker | (value - 1 + (literal_length == 0)): the history runs across the blocks of a frame, so they are
-// resolved by whoever walks the frame's blocks in order (ResolveRepeat below).
-template <typename EMIT>
-MI_ZHD bool DecodeSequences(const uint8_t* bits, uint32_t nbytes, uint32_t nseq, const FseCell* tll, uint32_t al_ll, const FseCell* tof,
-                            uint32_t al_of, const FseCell* tml, uint32_t al_ml, EMIT emit) {
-  BackBits br;
+// resolved later (RepStep / RepResolve below).
+template <typename READER, typename BP, typename TP, typename EMIT>
+MI_ZHD bool DecodeSequences(READER& br, BP bits, uint32_t nbytes, uint32_t nseq, TP tll, uint32_t al_ll, TP tof, uint32_t al_of, TP tml,
+                            uint32_t al_ml, EMIT emit) {
   if (!br.Open(bits, nbytes)) return false;
   uint32_t sll = br.Read(al_ll), sof = br.Read(al_of), sml = br.Read(al_ml);
   for (uint32_t i = 0; i < nseq; i++) {
     const FseCell cl = tll[sll], co = tof[sof], cm = tml[sml];
-    const uint32_t ov = co.base + br.Read(co.extra);
-    const uint32_t ml = cm.base + br.Read(cm.extra);
-    const uint32_t ll = cl.base + br.Read(cl.extra);
+    const uint32_t ov = CellBase(co) + br.Read(CellExtra(co));
+    const uint32_t ml = CellBase(cm) + br.Read(CellExtra(cm));
+    const uint32_t ll = CellBase(cl) + br.Read(CellExtra(cl));
     if (i + 1 < nseq) {
-      sll = cl.next + br.Read(cl.nbits);
-      sml = cm.next + br.Read(cm.nbits);
-      sof = co.next + br.Read(co.nbits);
+      sll = CellNext(cl) + br.Read(CellBits(cl));
+      sml = CellNext(cm) + br.Read(CellBits(cm));
+      sof = CellNext(co) + br.Read(CellBits(co));
     }
     if (br.Left() < 0) return false;
     if (!emit(i, ll, ml, ov > 3 ? ov - 3 : (kRepMarker | (ov - 1 + (ll == 0 ? 1u : 0u))))) return false;
@@ -457,24 +504,45 @@ MI_ZHD bool DecodeSequences(const uint8_t* bits, uint32_t nbytes, uint32_t nseq,
   return br.Left() == 0;
 }
 
-// rep[3] = the frame's repeat offsets (1, 4, 8 at its start).  Returns the offset the sequence uses; 0 = malformed.
-MI_ZHD uint32_t ResolveRepeat(uint32_t offset_or_marker, uint32_t* rep) {
-  uint32_t off;
-  if (!(offset_or_marker & kRepMarker)) {
-    off = offset_or_marker;
-    rep[2] = rep[1];
-    rep[1] = rep[0];
-    rep[0] = off;
-    return off;
+// Repeat offsets.  A sequence either brings a fresh offset or names one of the frame's three most recent ones, and that
+// history runs through all blocks of a frame -- but a block is decoded without its predecessors.  So the history is kept
+// SYMBOLICALLY: a state word is either a known offset (bit 31 clear; 0 = invalid) or "slot i of the history at the start of
+// this slice of sequences, minus d" (kRepSym | i << 29 | d).  The decoding lane runs the state machine on such words; what it
+// stores per sequence is the offset itself where that is known, else the symbolic word; what it stores per slice is the state
+// at the slice's end as a function of the state at its start.  Functions compose (RepResolve slot by slot), so a prefix scan
+// over the slices of a frame gives every slice its true starting state, and a symbolic offset resolves in one step.
+constexpr uint32_t kRepSym = 0x80000000u;
+MI_ZHD uint32_t RepSlot(uint32_t i) { return kRepSym | (i << 29); }
+// the value of word `w` once the state it refers to is (f0, f1, f2) -- themselves known or symbolic
+MI_ZHD uint32_t RepResolve(uint32_t w, uint32_t f0, uint32_t f1, uint32_t f2) {
+  if (!(w >> 31)) return w;
+  const uint32_t i = (w >> 29) & 3u, dec = w & 0x1FFFFFFFu;
+  const uint32_t u = i == 0 ? f0 : i == 1 ? f1 : f2;
+  if (!(u >> 31)) return u > dec ? u - dec : 0u;
+  return u + dec;
+}
+// one sequence: `code` as DecodeSequences emits it; S[3] is updated, the offset the sequence uses is returned (0 = invalid)
+MI_ZHD uint32_t RepStep(uint32_t code, uint32_t* S) {
+  const uint32_t s0 = S[0], s1 = S[1], s2 = S[2];   // constant indices only: the three words stay in registers
+  if (!(code & kRepMarker)) {
+    S[0] = code;
+    S[1] = s0;
+    S[2] = s1;
+    return code;
   }
-  const uint32_t idx = offset_or_marker & 3u;
-  if (idx == 0) return rep[0];
-  off = idx == 3 ? rep[0] - 1 : rep[idx];
-  if (off == 0) return 0;
-  if (idx != 1) rep[2] = rep[1];
-  rep[1] = rep[0];
-  rep[0] = off;
-  return off;
+  const uint32_t idx = code & 3u;
+  if (idx == 0) return s0;
+  if (idx == 1) {          // the second most recent moves to the front
+    S[0] = s1;
+    S[1] = s0;
+    return s1;
+  }
+  // the third most recent (idx 2), or the most recent minus one (idx 3), becomes the most recent
+  const uint32_t used = idx == 2 ? s2 : (s0 >> 31) ? s0 + 1u : (s0 > 1u ? s0 - 1u : 0u);
+  S[0] = used;
+  S[1] = s0;
+  S[2] = s1;
+  return used;
 }
 
 }  // namespace zstd

@@ -460,11 +460,15 @@ typedef struct mi_scan_options {
                                  * predicate are never decoded or copied back); 0 = full vectors + a selection vector.
                                  * Needs flat projected columns (no nested types, no string views). */
   int32_t pipeline_depth;       /* record batches in flight on the GPU (pinned + HBM slots); 0 = 3 */
-  int32_t host_decompress;      /* LZ4_FRAME bodies: 0 = auto: a device-resident consumer gets the compressed body shipped over
-                                 * PCIe and decompressed in HBM (K8), a host consumer has it decompressed by the reader's host
-                                 * threads; 1 = host threads always; -1 = K8 also for host consumers (string payloads are copied
-                                 * back beside the vectors).  ZSTD bodies, dictionary batches, big-endian streams and record
-                                 * batches with list columns always take the host threads. */
+  int32_t host_decompress;      /* compressed bodies: 0 = auto: LZ4_FRAME bodies of a device-resident consumer are shipped over
+                                 * PCIe as they are and decompressed in HBM (K8), everything else is decompressed by the
+                                 * reader's host threads; 1 = host threads always; -1 = K8 for LZ4_FRAME and ZSTD bodies,
+                                 * also for host consumers (string payloads are copied back beside the vectors).  ZSTD in HBM
+                                 * is one serial chain per 128 KiB block: it needs many record batches side by side
+                                 * (pipeline_depth 16 and GPU_MAX_HW_QUEUES >= 16 in the process environment) to beat the
+                                 * host threads, hence not the default.  Dictionary batches, big-endian streams, record
+                                 * batches with list columns and ZSTD frames with a dictionary id or a content checksum always
+                                 * take the host threads. */
   int32_t _reserved[3];
 } mi_scan_options;
 

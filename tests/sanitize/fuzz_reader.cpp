@@ -164,6 +164,7 @@ static int Drain(const std::vector<uint8_t>& buf, bool project, std::mt19937_64&
     bufs.push_back(ArrowIPCBuffer{reinterpret_cast<uint64_t>(buf.data()), static_cast<uint64_t>(buf.size())});
     IPCBufferStreamReader rd(bufs);
     rd.SetDeferLz4(rng() % 2 == 0);   // LZ4 bodies handed out compressed, with the block tables of the GPU decompressor
+    rd.SetDeferZstd(rng() % 2 == 0);  // ZSTD bodies too: the host walk of frame / block / section headers (WalkZstdFrame)
     const ArrowSchemaModel& schema = rd.GetBaseSchema();
     {  // the flatbuffer builder under the sanitizers too: re-encode the schema, read it back, same top-level shape
       const std::vector<uint8_t> msg = EncodeSchemaMessage(schema);
@@ -190,6 +191,19 @@ static int Drain(const std::vector<uint8_t>& buf, bool project, std::mt19937_64&
       uint64_t sum = 0;
       std::vector<uint8_t> expanded;
       const uint8_t* body = b.body;
+      if (b.deferred && b.deferred->codec == 1) {
+        // what the kernels rely on: every block, section and table source the walk names lies inside the body / the table
+        const DeferredLz4Body& d = *b.deferred;
+        if (d.zblocks.size() != d.blocks.size()) std::abort();
+        for (size_t i = 0; i < d.zblocks.size(); i++) {
+          const zstd::BlockInfo& z = d.zblocks[i];
+          if (static_cast<int64_t>(z.comp_off) + z.comp_size > d.comp_size) std::abort();
+          if (z.huf_src > i || z.ll_src > i || z.of_src > i || z.ml_src > i) std::abort();
+          if (z.type == 2 && (z.seq_pos + z.seq_hdr > z.comp_size || z.lit_hdr + z.lit_comp > z.comp_size)) std::abort();
+          for (uint32_t k = 0; k < z.comp_size; k += 61) sum += d.comp[z.comp_off + k];
+        }
+        continue;
+      }
       if (b.deferred) {
         try {
           expanded = DecodeDeferred(b);

@@ -23,7 +23,8 @@ static std::vector<uint8_t> Slurp(const char* path) {
 }
 
 static long g_seen[24];
-struct Seq { uint32_t out, lit, ll, ml, off; };
+struct Seq { uint32_t out, lit, ll, ml, off, slice; };
+struct Rep { uint32_t s[3]; };
 
 static bool DecodeFrame(const std::vector<uint8_t>& frame, size_t expect_size, std::vector<uint8_t>* out, std::string* why) {
   // the body as the device sees it: 8-byte aligned, padded
@@ -49,6 +50,7 @@ static bool DecodeFrame(const std::vector<uint8_t>& frame, size_t expect_size, s
   }
   std::vector<uint8_t> lits(scratch_bytes + 16);
   std::vector<std::vector<Seq>> seqs(blocks.size());
+  std::vector<std::vector<Rep>> slice_fn(blocks.size());   // per block: the 256 slices' effect on the repeat offsets, then their starting state
   std::vector<uint32_t> block_out(blocks.size(), 0);
   static uint16_t huf[2048];
   static zstd::FseCell tll[512], tof[256], tml[512], wcells[64];
@@ -62,7 +64,7 @@ static bool DecodeFrame(const std::vector<uint8_t>& frame, size_t expect_size, s
     if (z.type == 0) { block_out[bi] = z.comp_size; continue; }
     if (z.type == 1) {
       lits[z.lit_pos] = c[0];
-      seqs[bi].push_back({0, z.lit_pos, 1, z.regen - 1, 1});
+      seqs[bi].push_back({0, z.lit_pos, 1, z.regen - 1, 1, 0});
       block_out[bi] = z.regen;
       continue;
     }
@@ -76,11 +78,38 @@ static bool DecodeFrame(const std::vector<uint8_t>& frame, size_t expect_size, s
       for (uint32_t s = 0; s < z.lit_streams; s++) {
         uint32_t first, nbytes, out0, nsym;
         if (!zstd::LiteralStream(z, c, z.lit_type == 2 ? desc : 0, s, &first, &nbytes, &out0, &nsym)) { *why = "literal streams of block " + std::to_string(bi); return false; }
-        if (!zstd::DecodeHuffmanStream(c + first, nbytes, nsym, huf, max_bits, lits.data() + z.lit_pos + out0)) { *why = "literal stream " + std::to_string(s) + " of block " + std::to_string(bi); return false; }
+        // the kernels' reader: a window of words refilled by the reader itself (a small one here, to cross it often)
+        uint32_t window[8];
+        zstd::BackBits<const uint8_t*, zstd::WindowWords<const uint8_t*, uint32_t*, 8>> br;
+        br.src.win = window;
+        if (!zstd::DecodeHuffmanStream(br, c + first, nbytes, nsym, huf, max_bits, lits.data() + z.lit_pos + out0)) { *why = "literal stream " + std::to_string(s) + " of block " + std::to_string(bi); return false; }
       }
     }
     uint32_t out_pos = 0, lit_used = 0;
     const bool scratch_lits = z.lit_type != 0;
+    // the kernel's slices: 256 per block, `per` descriptors in each
+    const uint32_t per = blocks[bi].seq_cap / 256;
+    const Rep id = {{zstd::RepSlot(0), zstd::RepSlot(1), zstd::RepSlot(2)}};
+    slice_fn[bi].assign(256, id);
+    Rep S = id;
+    uint32_t n_desc = 0;
+    bool rep_ok = true;
+    auto put = [&](uint32_t ll, uint32_t ml, uint32_t code) {
+      uint32_t off = 0;
+      if (ml) {
+        off = zstd::RepStep(code, S.s);
+        if (!off) rep_ok = false;
+      }
+      const uint32_t k = n_desc / per;
+      seqs[bi].push_back({out_pos, z.lit_pos + lit_used, ll, ml, off, k});
+      lit_used += ll;
+      out_pos += ll + ml;
+      n_desc++;
+      if (n_desc % per == 0) {
+        slice_fn[bi][k] = S;
+        S = id;
+      }
+    };
     if (z.nseq) {
       const zstd::BlockInfo* src[3] = {&infos[z.ll_src], &infos[z.of_src], &infos[z.ml_src]};
       zstd::FseCell* tab[3] = {tll, tof, tml};
@@ -94,37 +123,64 @@ static bool DecodeFrame(const std::vector<uint8_t>& frame, size_t expect_size, s
       const uint32_t so = z.seq_pos + z.seq_hdr;
       const uint32_t bo = zstd::SequenceBitstreamOffset(c + so, z.comp_size - so, counts);
       if (!bo || so + bo >= z.comp_size) { *why = "sequence bitstream of block " + std::to_string(bi); return false; }
-      std::vector<Seq>& v = seqs[bi];
-      const bool ok = zstd::DecodeSequences(c + so + bo, z.comp_size - so - bo, z.nseq, tll, al[0], tof, al[1], tml, al[2],
-                                            [&](uint32_t, uint32_t ll, uint32_t ml, uint32_t off) {
+      uint32_t seq_window[16];
+      zstd::BackBits<const uint8_t*, zstd::WindowWords<const uint8_t*, uint32_t*, 16>> sbr;
+      sbr.src.win = seq_window;
+      const bool ok = zstd::DecodeSequences(sbr, c + so + bo, z.comp_size - so - bo, z.nseq, tll, al[0], tof, al[1], tml, al[2],
+                                            [&](uint32_t, uint32_t ll, uint32_t ml, uint32_t code) {
                                               if (ll > z.lit_regen - lit_used || ll + ml > zstd::kBlockMax - out_pos) return false;
-                                              v.push_back({out_pos, z.lit_pos + lit_used, ll, ml, off});
-                                              lit_used += ll;
-                                              out_pos += ll + ml;
-                                              return true;
+                                              put(ll, ml, code);
+                                              return rep_ok;
                                             });
       if (!ok) { *why = "sequences of block " + std::to_string(bi); return false; }
     }
     if (lit_used < z.lit_regen) {
       if (z.lit_regen - lit_used > zstd::kBlockMax - out_pos) { *why = "block too long"; return false; }
-      seqs[bi].push_back({out_pos, z.lit_pos + lit_used, z.lit_regen - lit_used, 0, 0});
-      out_pos += z.lit_regen - lit_used;
+      put(z.lit_regen - lit_used, 0, 0);
     }
+    if (n_desc % per) slice_fn[bi][n_desc / per] = S;
     (void)scratch_lits;
     block_out[bi] = out_pos;
   }
-  // stage 2: the frame's blocks in order -- output positions and repeat offsets; stage 3: the copies
-  uint32_t rep[3] = {1, 4, 8};
+  // stage 2: the frame's blocks in order -- the repeat offsets every slice starts from; stage 3: the copies
+  Rep R = {{1, 4, 8}};
   out->clear();
   for (size_t bi = 0; bi < blocks.size(); bi++) {
     const zstd::BlockInfo& z = infos[bi];
     if (z.type == 0) { out->insert(out->end(), comp + z.comp_off, comp + z.comp_off + z.comp_size); continue; }
+    if (z.type == 2) {
+      // as zstd_layout does it: 64 lanes, 4 slices each, an inclusive scan of the lanes' totals (shuffles emulated)
+      auto after = [](const Rep& g, const Rep& st) {
+        Rep r;
+        for (int q = 0; q < 3; q++) r.s[q] = zstd::RepResolve(g.s[q], st.s[0], st.s[1], st.s[2]);
+        return r;
+      };
+      std::vector<Rep>& fn = slice_fn[bi];
+      Rep inc[64];
+      for (int l = 0; l < 64; l++) inc[l] = after(fn[4 * l + 3], after(fn[4 * l + 2], after(fn[4 * l + 1], fn[4 * l])));
+      for (int d = 1; d < 64; d <<= 1) {
+        Rep prev[64];
+        for (int l = 0; l < 64; l++) prev[l] = inc[l >= d ? l - d : l];
+        for (int l = d; l < 64; l++) inc[l] = after(inc[l], prev[l]);
+      }
+      std::vector<Rep> start(256);
+      for (int l = 0; l < 64; l++) {
+        const Rep e = l ? inc[l - 1] : Rep{{zstd::RepSlot(0), zstd::RepSlot(1), zstd::RepSlot(2)}};
+        start[4 * l] = after(e, R);
+        for (int q = 1; q < 4; q++) start[4 * l + q] = after(fn[4 * l + q - 1], start[4 * l + q - 1]);
+      }
+      R = after(inc[63], R);
+      fn = start;
+    }
+    if (std::getenv("ZCHECK_DUMP")) std::printf("block %zu type %u ndesc %zu\n", bi, z.type, seqs[bi].size());
     for (Seq& q : seqs[bi]) {
       uint32_t off = q.off;
       if (z.type == 2 && q.ml) {
-        off = zstd::ResolveRepeat(q.off, rep);
-        if (!off) { *why = "repeat offset"; return false; }
+        const Rep& h = slice_fn[bi][q.slice];
+        off = zstd::RepResolve(q.off, h.s[0], h.s[1], h.s[2]);
+        if (!off || (off >> 31)) { *why = "repeat offset"; return false; }
       }
+      if (std::getenv("ZCHECK_DUMP")) std::printf("d %u %u %u %u %u\n", q.out, q.ll, q.ml, q.ml ? off : 0, q.off >> 31);
       const uint8_t* lsrc = (z.type == 2 && z.lit_type == 0) ? comp : lits.data();
       out->insert(out->end(), lsrc + q.lit, lsrc + q.lit + q.ll);
       if (q.ml) {

@@ -38,7 +38,7 @@ def test_zstd_bodies_decompressed_in_hbm_equal_the_host_decompressor(con, tmp_pa
     path = str(tmp_path / (name + ".arrows"))
     _write(path, table, chunk, level)
     want = [canon_python(c) for c in con.read_arrow(path, accept_dictionaries=True, host_decompress=True).fetch_columns()]   # libzstd on host threads
-    got, st = _device_scan(con, path)
+    got, st = _device_scan(con, path, host_decompress="gpu")      # ZSTD in HBM is on request (auto keeps the host threads)
     assert got == want
     nonempty = sum(1 for b in ipc.open_stream(path) if b.num_rows > 0)
     assert st["zstd_batches_on_device"] >= nonempty and st["lz4_batches_on_device"] == 0, st
@@ -47,7 +47,7 @@ def test_zstd_bodies_decompressed_in_hbm_equal_the_host_decompressor(con, tmp_pa
     rel = con.read_arrow(path, accept_dictionaries=True, host_decompress="gpu")      # a host consumer on the K8 path
     assert [canon_python(c) for c in rel.fetch_columns()] == want
     assert (rel.stats()["zstd_batches_on_device"] > 0) == (nonempty > 0)
-    got_host, st_host = _device_scan(con, path, host_decompress=True)
+    got_host, st_host = _device_scan(con, path)                   # auto: host threads for ZSTD
     assert got_host == want and st_host["zstd_batches_on_device"] == 0
 
 
@@ -58,14 +58,14 @@ def test_zstd_golden_files_projection_and_fused_consumers(con, golden_dir, tmp_p
             path = str(tmp_path / ("zstd%d_%s" % (level, rel_path)))
             _write(path, t, 4096 if level == 1 else 60000, level)
             want = [canon_python(c) for c in con.read_arrow(path, accept_dictionaries=True, host_decompress=True).fetch_columns()]
-            got, st = _device_scan(con, path)
+            got, st = _device_scan(con, path, host_decompress="gpu")
             assert got == want, (rel_path, level)
             assert (st["zstd_batches_on_device"] > 0) == (rel_path != "edge_nested.arrows"), rel_path   # list offsets are sampled on the host
     t = ipc.open_stream(os.path.join(golden_dir, "lineitem_sf0_01_q6.arrows")).read_all()
     path = str(tmp_path / "q6_zstd.arrows")
     _write(path, t, 8192)
     plain = os.path.join(golden_dir, "lineitem_sf0_01_q6.arrows")
-    rel = con.read_arrow(path, device_resident=True)
+    rel = con.read_arrow(path, device_resident=True, host_decompress="gpu")
     rel.filter_range("l_shipdate", 8766, 9130)
     a = rel.count(detail=True)
     assert rel.stats()["zstd_batches_on_device"] > 0
@@ -73,13 +73,13 @@ def test_zstd_golden_files_projection_and_fused_consumers(con, golden_dir, tmp_p
     rel2.filter_range("l_shipdate", 8766, 9130)
     b = rel2.count(detail=True)
     assert (a["rows"], a["selected"]) == (b["rows"], b["selected"])
-    s1 = con.read_arrow(path, device_resident=True).sum_product("l_extendedprice", "l_discount", [("l_shipdate", 8766, 9130)])
+    s1 = con.read_arrow(path, device_resident=True, host_decompress="gpu").sum_product("l_extendedprice", "l_discount", [("l_shipdate", 8766, 9130)])
     assert s1 == con.read_arrow(plain).sum_product("l_extendedprice", "l_discount", [("l_shipdate", 8766, 9130)])
     # projection: only the projected columns' frames cross PCIe
     t = ipc.open_stream(os.path.join(golden_dir, "lineitem_sf0_01_head.arrows")).read_all()
     path = str(tmp_path / "zstd_proj.arrows")
     _write(path, t, 4096)
-    rel = con.read_arrow(path, device_resident=True).project(["l_shipdate", "l_quantity"])
+    rel = con.read_arrow(path, device_resident=True, host_decompress="gpu").project(["l_shipdate", "l_quantity"])
     assert rel.count(detail=True)["rows"] == t.num_rows
     assert 0 < rel.stats()["h2d_bytes"] < os.path.getsize(path) * 0.5
 
@@ -112,11 +112,11 @@ def test_damaged_zstd_input_is_an_error_not_a_crash(con, tmp_path):
         p = str(tmp_path / ("bad_%d.arrows" % trial))
         open(p, "wb").write(bytes(bad))
         try:
-            _device_scan(con, p)
+            _device_scan(con, p, host_decompress="gpu")
             outcomes.add("ok")          # the damage hit a raw literal or padding
         except da.MiError as e:
             outcomes.add("error")
             assert e.code in (da._ffi.MI_EIO, da._ffi.MI_EINVAL), (trial, str(e))
     assert "error" in outcomes
-    got, _ = _device_scan(con, path)    # the context still works
+    got, _ = _device_scan(con, path, host_decompress="gpu")    # the context still works
     assert got == [canon_python(c) for c in con.read_arrow(path, host_decompress=True).fetch_columns()]

@@ -12,6 +12,7 @@ def main():
     ap.add_argument("--dir", default="/dev/shm")
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--legs", default="", help="comma-separated leg names to run (default: all)")
+    ap.add_argument("--codec", default="lz4", choices=["lz4", "zstd"], help="zstd: what the reference's benchmark writes (benchmark/lineitem.py:135); leg names keep their lz4_ prefix")
     args = ap.parse_args()
     import pyarrow as pa
     import pyarrow.ipc as ipc
@@ -19,12 +20,12 @@ def main():
     buf, info = da.synth_lineitem_stream(scale_factor=args.sf, seed=42)
     plain = os.path.join(args.dir, "mi_lz4_plain_sf%g.arrows" % args.sf)
     packed = os.path.join(args.dir, "mi_lz4_packed_sf%g.arrows" % args.sf)
-    out = {"rows": info["n_rows"], "plain_bytes": int(buf.size)}
+    out = {"rows": info["n_rows"], "plain_bytes": int(buf.size), "codec": args.codec}
     try:
         buf.tofile(plain)
         t0 = time.perf_counter()
         reader = ipc.open_stream(pa.py_buffer(buf))
-        with ipc.new_stream(packed, reader.schema, options=ipc.IpcWriteOptions(compression="lz4")) as w:
+        with ipc.new_stream(packed, reader.schema, options=ipc.IpcWriteOptions(compression=args.codec)) as w:
             for b in reader:
                 w.write_batch(b)
         out["pyarrow_compress_seconds"] = time.perf_counter() - t0
