@@ -346,6 +346,25 @@ def main():
                     lz4["uncompressed_files"] = {"seconds": best, "rows_per_s": info["n_rows"] / best}
                     legs["lz4_device_resident_scan"] = lz4
                     os.remove(lpath)
+                    # the same for ZSTD (the codec of the reference's benchmark, benchmark/lineitem.py:135).  Its GPU path is one
+                    # serial entropy chain per 128 KiB block: it needs many record batches side by side, so the leg runs in a
+                    # process of its own with 16 slots and GPU_MAX_HW_QUEUES=20 (the HIP runtime reads that once, at start-up;
+                    # with its default of 4 queues the same scan takes 2.6 s at SF10 -- DESIGN 4.2)
+                    import subprocess
+                    env = dict(os.environ, GPU_MAX_HW_QUEUES="20")
+                    run = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "lz4_bench.py"),
+                                          "--codec", "zstd", "--sf", str(args.sf), "--dir", args.shm_dir, "--depth", "16",
+                                          "--legs", "lz4_host_threads,lz4_in_hbm"], env=env, capture_output=True, text=True, timeout=600)
+                    if run.returncode == 0:
+                        z = json.loads(run.stdout.strip().split("\n")[-1])
+                        legs["zstd_device_resident_scan"] = {
+                            "file_bytes": z["lz4_bytes"], "GPU_MAX_HW_QUEUES": 20, "pipeline_depth": 16,
+                            "host_threads": {k: z["lz4_host_threads"][k] for k in ("seconds", "rows_per_s")},
+                            "in_hbm": dict({k: z["lz4_in_hbm"][k] for k in ("seconds", "rows_per_s")},
+                                           h2d_bytes=z["lz4_in_hbm"]["stats"]["h2d_bytes"],
+                                           zstd_batches_on_device=z["lz4_in_hbm"]["stats"]["zstd_batches_on_device"])}
+                    else:
+                        legs["zstd_device_resident_scan"] = {"error": run.stderr[-300:]}
                 except ImportError:
                     pass   # no pyarrow on this box: the leg needs it to write the compressed stream
             con.close()
