@@ -18,8 +18,8 @@
 // the scan runs the batches of several slots side by side.
 
 constexpr int kZstdThreads = 128;
-constexpr int kZstdWindowWords = 256;            // per literal stream: 1 KiB of the stream in LDS at a time
-constexpr int kZstdSeqWindowWords = 1024;        // the sequences' bitstream: 4 KiB at a time
+constexpr int kZstdWindowWords = 128;            // per literal stream: 512 bytes of the stream in LDS at a time
+constexpr int kZstdSeqWindowWords = 256;         // the sequences' bitstream: 1 KiB at a time
 template <typename T>
 using ldsptr = T __attribute__((address_space(3)))*;
 
