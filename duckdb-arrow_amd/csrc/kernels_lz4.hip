@@ -1,4 +1,5 @@
-// kernels_lz4.hip -- K8: LZ4_FRAME buffer decompression in HBM.
+// kernels_lz4.hip -- K8: compressed record-batch bodies decompressed in HBM: LZ4_FRAME here, the ZSTD entropy
+// stage in kernels_zstd.inl (included below), the copy stages shared.
 //
 // The reference decompresses every buffer of a compressed record batch on the CPU before it slices the body
 // (DuckDBDecompressZstd, src/ipc/stream_reader/base_stream_reader.cpp:11-32; LZ4_FRAME is the other codec of Message.fbs
@@ -9,23 +10,27 @@
 // block, and inside a frame with linked blocks -- what LZ4F_compressFrame writes -- a match may reach back into the
 // previous block, so "one wave per block, copy as you parse" serialises a whole buffer.  The work is therefore cut the
 // other way round, into steps that are each data parallel and never wait for another workgroup:
-//   1. lz4_parse    one WAVE per block walks the tokens only (no data is copied): one descriptor per sequence
-//                   {output position in the block, literal source, literal length, match length, match offset} and the
-//                   block's decompressed size.  The 64 lanes walk 64 segments of the block speculatively and repeat until
-//                   their start positions agree (see the kernel).  Every block of every buffer of the batch at once.
+//   1. lz4_parse    one workgroup (256 lanes) per block walks the tokens only (no data is copied): one descriptor per
+//                   sequence {output position, literal source, literal length, match length} + offset, and the block's
+//                   decompressed size.  The lanes walk 256 segments of the block speculatively, exchange where they leave
+//                   them and repeat until their start positions agree (see the kernel).  Every block of every buffer at once.
+//                   (ZSTD: zstd_entropy produces the same descriptors from the Huffman / FSE streams.)
 //   2. lz4_layout   one lane per buffer: first output byte of each of its blocks (running sum), and the check the
 //                   reference makes after decompressing: the sizes must add up to the declared uncompressed length.
-//   3. lz4_expand   one workgroup per block, one thread per sequence: every decompressed byte gets a 32-bit LINK word --
-//                   a literal's word holds the byte itself, a match byte's word the position it copies from (always an
-//                   earlier byte of the buffer).
-//   4. lz4_resolve  pointer jumping over the links, all bytes in parallel and in place: link[j] <- link[link[j]] until
-//                   the word read holds a byte.  A chain of depth d needs ceil(log2 d) + 1 rounds (an overlapping run
-//                   "offset 1, length 60000" is 17); a round that finds nothing left to do makes the later ones
-//                   (launched blindly, no host round trip) return at once.
-//   5. lz4_emit     the bytes leave the link words for the decompressed body.
-// HBM traffic per decompressed byte: 4 B memset + 4 B expand + 4 B read per resolve round (+ 4 B write where a word
-// changed) + 5 B emit.  The token walk of step 1 is the latency-bound part: a few thousand
-// sequences per 64 KiB block, three or four dependent loads each -- hence the 64 speculative lanes.
+//                   (ZSTD: zstd_layout, which also settles the repeat offsets.)
+//   3. lz4_expand   one workgroup per block, output-centric: a thread owns 256 consecutive output bytes, finds its first
+//                   sequence by binary search and walks on from there.  Every decompressed byte gets a 32-bit LINK word -- a
+//                   literal's word holds the byte itself, a match byte's word the position it copies from (always an earlier
+//                   byte of the buffer; an overlapping match links straight into its first period).
+//   4. lz4_resolve_local / lz4_collect / lz4_resolve_skeleton
+//                   pointer jumping over the links, in place: first inside 8 KiB tiles in LDS until nothing moves, then over
+//                   the SKELETON only -- the still-open words that other tiles' open words point at -- four hops per round,
+//                   <= log5(tiles of the longest buffer) + 1 rounds launched blindly (a round that finds nothing left makes
+//                   the later ones return at once).
+//   5. lz4_emit     the last hop of everything outside the skeleton, then the bytes leave the link words for the
+//                   decompressed body; a word still open here is an error, never silent data.
+// HBM traffic per decompressed byte: 4 B memset + 4 B expand + 8 B local pass + 5 B emit (+ the skeleton's few words).  The
+// token walk of step 1 is the latency-bound part -- hence the speculative lanes.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
