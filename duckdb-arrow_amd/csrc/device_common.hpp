@@ -119,6 +119,7 @@ __device__ __forceinline__ bool row_valid(const uint64_t* s_valid, bool need_mas
 // global_load_dwordx4 from an 8-mod-16 address is legal; IPC buffers are only 8-byte aligned (after an odd-length
 // offsets buffer every following buffer of the body is 8 mod 16), the destination vectors are always 16-byte aligned.
 typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
+typedef u32x4 u32x4_a1 __attribute__((aligned(1)));  // ... or on any byte (string payloads)
 
 __device__ __forceinline__ u32x4 ld16(gptr<const u32x4_a4> p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ void st16(gptr<u32x4> p, u32x4 v) { __builtin_nontemporal_store(v, p); }

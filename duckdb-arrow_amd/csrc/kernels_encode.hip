@@ -266,10 +266,9 @@ __device__ __forceinline__ void heap_load13(gptr<const uint8_t> src, uint32_t cn
   W[13] = 0u;
 }
 
-// Bytes [c0, c0 + cnt) of one string -> LDS at dst.  W: the string's first 48 heap bytes (heap_load13 of the string
-// start) when it is a long string; it is used when c0 == 0 and is scratch otherwise.
+// Bytes [c0, c0 + cnt) of one string -> LDS at dst, a long string in pieces of 48 bytes (13 aligned dwords each).
 __device__ __forceinline__ void string_bytes_to_lds(uint8_t* dst, const u32x4& s, gptr<const uint8_t> heap, uint64_t ptr_base,
-                                                    uint32_t c0, uint32_t cnt, uint32_t (&W)[14]) {
+                                                    uint32_t c0, uint32_t cnt) {
   if (s.x <= 12) {
     uint32_t a = s.y, b = s.z, c = s.w;
     if (c0 >= 8) { a = c; b = 0u; c = 0u; }
@@ -281,13 +280,9 @@ __device__ __forceinline__ void string_bytes_to_lds(uint8_t* dst, const u32x4& s
   const uint64_t p = static_cast<uint64_t>(s.z) | (static_cast<uint64_t>(s.w) << 32);
   gptr<const uint8_t> src = heap + (p - ptr_base) + c0;
   const uint32_t mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(src) & 3);
-  uint32_t done = 0;
-  if (c0 == 0) {
-    lds_put_stream<12>(dst, W, mis, cnt < 48u ? cnt : 48u);
-    done = 48;
-  }
+  uint32_t W[14];
 #pragma clang loop unroll(disable)
-  for (; done < cnt; done += 48) {
+  for (uint32_t done = 0; done < cnt; done += 48) {
     heap_load13(src + done, cnt - done, W);
     lds_put_stream<12>(dst + done, W, mis, cnt - done < 48u ? cnt - done : 48u);
   }
@@ -303,10 +298,13 @@ __device__ __forceinline__ void string_bytes_to_lds(uint8_t* dst, const u32x4& s
 //
 // The encode of a tile is the loop the counters shaped (rocprofv3 SQ_INSTS_* in profiles/r01_encode): 256-row sub-blocks,
 // lane = row (coalesced 16-byte string_t loads, coalesced offset stores); the NEXT sub-block's string_t is requested before
-// this one is touched; a long string's first 48 heap bytes arrive as one batch of 13 aligned dword loads; a 6-step DPP wave
-// scan + one LDS exchange of the 4 wave totals places every row; the payload is assembled in LDS with dword stores (two
-// v_alignbyte_b32 funnel shifts, <= 3 head / tail byte stores, predicated straight-line code) in windows of <= 8 KiB on two
-// alternating stage buffers (one barrier per window) and leaves as coalesced 16-byte nontemporal stores.
+// this one is touched; a 6-step DPP wave scan + the group totals of the length pass place every row; the payload is
+// assembled in LDS in windows of <= 8 KiB on two alternating stage buffers (one barrier per window) and leaves as coalesced
+// 16-byte nontemporal stores.  How the bytes reach LDS is decided per wave: when its long strings lie in the heap as they
+// will lie in the data buffer (vectors decoded from Arrow buffers, staged heaps), the span from the first to the last of
+// them is ONE coalesced copy and only the inline strings place themselves; otherwise every row brings its own bytes, 48 at
+// a time as 13 aligned dword loads, with dword stores (two v_alignbyte_b32 funnel shifts, <= 3 head / tail byte stores,
+// predicated straight-line code).  The kernel keeps to 64 VGPRs and 17 KiB of LDS: 8 workgroups per CU.
 //
 // Look-back words: tile_state[tile] bits 62..63 = 0 nothing yet, 1 = sum of this tile, 2 = sum of every tile of the column up
 // to and including this one.  They are read and written with RELAXED agent-scope atomics: the word is the whole message, and
@@ -319,12 +317,12 @@ __device__ __forceinline__ void string_bytes_to_lds(uint8_t* dst, const u32x4& s
 // tile_state[total_tiles + 1 + tile] = 0, or (1 << 63 | first output byte) of a tile left to encode_string_slow: list offsets
 // (no payload) and tiles holding a string of >= 8 MiB (32-bit positions inside a sub-block could wrap).
 constexpr uint32_t kEncBigLen = 1u << 23;
-constexpr int kEncStage5 = 6 * 1024;       // bytes per stage buffer
+constexpr int kEncStage5 = 8 * 1024;       // bytes per stage buffer: a 256-row sub-block of lineitem comments (6.8 KB) is one window
 constexpr int kEncStageBuf = kEncStage5 + 64;
 constexpr uint64_t kStateMask = (1ull << 62) - 1ull;
 constexpr int kLookBack = 4;   // predecessors inspected per look-back step
 
-__global__ __launch_bounds__(kBlockThreads, 6) void encode_string_1p(const mi_col_task* __restrict__ tasks,
+__global__ __launch_bounds__(kBlockThreads, 8) void encode_string_1p(const mi_col_task* __restrict__ tasks,
                                                                      const uint32_t* __restrict__ tile_begin,
                                                                      const uint32_t* __restrict__ tile_task, int n_tasks,
                                                                      uint32_t total_tiles, unsigned long long* __restrict__ tile_state,
@@ -332,7 +330,6 @@ __global__ __launch_bounds__(kBlockThreads, 6) void encode_string_1p(const mi_co
   constexpr int kWaves = kBlockThreads / 64;
   static_assert(kWaves == 4, "wave totals travel as one 16-byte LDS row");
   __shared__ uint64_t s_valid[kTileRows / 64];
-  __shared__ uint32_t s_ex[kTileRows];          // a row's bytes after the start of its (sub-block, wave) group
   __shared__ uint32_t s_wtot[kTileRows / 64];         // bytes of every (sub-block, wave) group: 32 of them
   __shared__ uint32_t s_wbase[kTileRows / 64 + 1];     // ... and their exclusive prefix (+ the tile total)
   __shared__ unsigned long long s_sum[kWaves];
@@ -357,8 +354,8 @@ __global__ __launch_bounds__(kBlockThreads, 6) void encode_string_1p(const mi_co
     gptr<const uint32_t> lens = GC<uint32_t>(t.buf1) + 4 * row0 + (is_list ? 2 : 0);
     unsigned long long local = 0;
     uint32_t longest = 0;
-    // ... and, in the same pass, where every row's bytes go inside the tile: one DPP wave scan per 64 rows now, so that the
-    // encode loop below neither scans nor waits for the other waves' totals (32-bit: tiles that could wrap take the slow path)
+    // ... and, in the same pass, the bytes of every (sub-block, wave) group of 64 rows, so that the encode loop below does
+    // not wait for the other waves' totals (32-bit: tiles that could wrap take the slow path)
 #pragma unroll
     for (int k = 0; k < kTileRows / kBlockThreads; k++) {
       const int r = static_cast<int>(threadIdx.x) + k * kBlockThreads;
@@ -367,7 +364,6 @@ __global__ __launch_bounds__(kBlockThreads, 6) void encode_string_1p(const mi_co
       local += l;
       longest = longest > l ? longest : l;
       const uint32_t incl = wave_inclusive_scan_u32(l);
-      s_ex[r] = incl - l;
       if (lane == 63) s_wtot[k * kWaves + wave] = incl;
     }
 #pragma unroll
@@ -461,15 +457,32 @@ __global__ __launch_bounds__(kBlockThreads, 6) void encode_string_1p(const mi_co
     }
     const bool ok = r < n && ((s_valid[r >> 6] >> (r & 63)) & 1);
     const uint32_t len = ok ? s.x : 0u;
-    uint32_t W[14];
-    if (len > 12) {
-      const uint64_t p = static_cast<uint64_t>(s.z) | (static_cast<uint64_t>(s.w) << 32);
-      heap_load13(heap + (p - t.ptr_base), len, W);
-    }
     // the row's place inside the sub-block, and the sub-block's size, from the tile-wide scan above
     const uint32_t sub0 = s_wbase[k * kWaves];
-    const uint32_t ex = s_wbase[k * kWaves + wave] - sub0 + s_ex[r];
+    // (the scan inside the wave is done again here: 12 VALU instructions per 64 rows, against 8 KiB of LDS -- one occupancy
+    // step -- to carry its result over from the length pass)
+    const uint32_t ex = s_wbase[k * kWaves + wave] - sub0 + (wave_inclusive_scan_u32(len) - len);
     const uint32_t total = s_wbase[k * kWaves + kWaves] - sub0;
+    // Do the long strings of this wave's 64 rows lie in the heap the way they will lie in the data buffer (every one of them
+    // at the same distance from its place in the sub-block)?  Vectors decoded from Arrow buffers do, and so does a staged
+    // heap.  Then the bytes between the first and the last long string are one coalesced copy (16 bytes per lane) instead
+    // of 13 dword loads and as many funnel shifts per row, and only the short rows, whose bytes are inline, place them
+    // themselves -- after the copy, over whatever the heap holds where they go (LDS accesses of one wave execute in program
+    // order).  The bytes between two long strings are < 64 * 12 bytes apart, so they share a 4 KiB page with the end of one
+    // or the start of the other: reading them cannot fault.  Anything else takes the per-row path below.
+    const uint64_t long_mask = __ballot(len > 12);
+    bool contig = false;      // wave-uniform
+    uint64_t cbase = 0;       // heap offset of the sub-block's byte 0, were it all in the heap
+    uint32_t blo = 0, bhi = 0;  // sub-block bytes [blo, bhi): first long string .. end of the last one
+    if (!tiny && long_mask != 0) {
+      const uint64_t cdelta = (static_cast<uint64_t>(s.z) | (static_cast<uint64_t>(s.w) << 32)) - t.ptr_base - ex;
+      const int fl = __builtin_ctzll(long_mask), ll = 63 - __builtin_clzll(long_mask);
+      cbase = static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(cdelta)), fl))) |
+              (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(cdelta >> 32)), fl))) << 32);
+      contig = __ballot(len > 12 && cdelta != cbase) == 0;
+      blo = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ex), fl));
+      bhi = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ex + len), ll));
+    }
     if (r < n) {
       if (large) offp64[r] = base + ex + len;
       else offp[r] = static_cast<int32_t>(base + ex + len);
@@ -486,8 +499,24 @@ __global__ __launch_bounds__(kBlockThreads, 6) void encode_string_1p(const mi_co
         if (len > 1) d[1] = static_cast<uint8_t>(s.y >> 8);
         if (len > 2) d[2] = static_cast<uint8_t>(s.y >> 16);
         if (len > 3) d[3] = static_cast<uint8_t>(s.y >> 24);
-      } else if (lo < hi) {
-        string_bytes_to_lds(st + shiftw + (lo - w0), s, heap, t.ptr_base, lo - ex, hi - lo, W);
+      } else {
+        if (contig) {  // wave-uniform: sub-block bytes [a, b) of this window come straight from the heap
+          const uint32_t a = blo > w0 ? blo : w0, b = bhi < w1 ? bhi : w1;
+          if (a < b) {
+            const uint32_t sa = shiftw + (a - w0), sb = shiftw + (b - w0);        // ... as stage bytes [sa, sb)
+            gptr<const uint8_t> src0 = heap + cbase + w0 - shiftw;                 // src0[i] is what stage byte i holds
+            const uint32_t ca = (sa + 15u) & ~15u, cb = sb & ~15u;                 // whole 16-byte stage rows [ca, cb)
+            for (uint32_t c = ca + 16u * lane; c < cb; c += 16u * 64u)
+              *reinterpret_cast<u32x4*>(st + c) = __builtin_nontemporal_load((gptr<const u32x4_a1>)(src0 + c));
+            // < 16 bytes in front of them and < 16 behind, one byte per lane
+            const uint32_t head_end = ca < sb ? ca : sb, tail0 = ca > cb ? ca : cb;
+            const uint32_t idx = lane < 16 ? sa + lane : tail0 + (lane - 16);
+            const bool mine = lane < 16 ? idx < head_end : (lane < 32 && idx < sb);
+            if (mine) st[idx] = src0[idx];
+          }
+        }
+        if (lo < hi && !(contig && len > 12))
+          string_bytes_to_lds(st + shiftw + (lo - w0), s, heap, t.ptr_base, lo - ex, hi - lo);
       }
       __syncthreads();
       // stage bytes [shiftw, end) -> gbase[shiftw, end); gbase is 16-byte aligned

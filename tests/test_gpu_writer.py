@@ -201,6 +201,74 @@ def test_encode_string_windows_and_huge_strings_match_oracle(con, torch, shape):
     assert plan.null_counts()[0] == int(n - ok.sum())
 
 
+@pytest.mark.parametrize("layout", ["arrow_like", "nulls_take_no_heap", "long_strings_only", "every_other_wave_shuffled",
+                                    "long_mean_90_arrow_like"])
+def test_encode_string_heap_layouts_match_oracle(con, torch, layout):
+    """K7d picks, per wave of 64 rows, between one coalesced copy of the heap bytes between the first and the last long
+    string (when the long strings lie in the heap as they will lie in the data buffer) and the per-row path.  Layouts:
+    an Arrow-like heap (every row's bytes in row order; the slots of inline strings hold garbage here, the inline bytes
+    must win), NULL rows that own no heap bytes, a heap of long strings only (DuckDB's own), waves with shuffled
+    pointers next to contiguous ones, and sub-blocks whose contiguous run crosses several LDS windows."""
+    rng = np.random.default_rng({"arrow_like": 21, "nulls_take_no_heap": 22, "long_strings_only": 23,
+                                 "every_other_wave_shuffled": 24, "long_mean_90_arrow_like": 25}[layout])
+    n = 9000
+    lens = rng.integers(0, 181, n) if layout == "long_mean_90_arrow_like" else rng.integers(0, 61, n)
+    ok = np.ones(n, bool) if layout in ("arrow_like", "long_mean_90_arrow_like") else rng.random(n) < 0.9
+    if layout == "long_strings_only":
+        lens[rng.random(n) < 0.5] = 20    # runs of long strings back to back: contiguous waves exist in this layout too
+        lens[2048:2048 + 640] = 33
+    text = [rng.integers(97, 123, int(l), dtype=np.uint8) for l in lens]
+    heap_len = {"arrow_like": lambda i: lens[i], "long_mean_90_arrow_like": lambda i: lens[i],
+                "nulls_take_no_heap": lambda i: lens[i] if ok[i] else 0,
+                "long_strings_only": lambda i: lens[i] if lens[i] > 12 else 0,
+                "every_other_wave_shuffled": lambda i: lens[i]}[layout]
+    order = np.arange(n)
+    if layout == "every_other_wave_shuffled":
+        for w in range(0, n // 64, 2):
+            order[64 * w: 64 * w + 64] = rng.permutation(order[64 * w: 64 * w + 64])
+    starts = np.zeros(n, np.int64)
+    pos = 7                                   # an odd heap start: source and destination phases differ
+    for i in order:
+        starts[i] = pos
+        pos += int(heap_len(i))
+    heap = np.full(pos + 64, 0xAA, np.uint8)  # 0xAA wherever no long string lives (incl. the slots of inline strings)
+    str16 = np.zeros((n, 16), np.uint8)
+    str16[:, :4] = lens.astype(np.uint32).view(np.uint8).reshape(n, 4)
+    for i in range(n):
+        l = int(lens[i])
+        if l <= 12:
+            str16[i, 4: 4 + l] = text[i]
+        else:
+            heap[starts[i]: starts[i] + l] = text[i]
+            str16[i, 4:8] = text[i][:4]
+            str16[i, 8:16] = np.frombuffer(np.uint64(starts[i]).tobytes(), np.uint8)
+    valid = np.packbits(np.concatenate([ok, np.ones((-n) % 64, bool)]), bitorder="little").view(np.uint64).copy()
+    payload = int(lens[ok].sum())
+    d_valid = torch.from_numpy(valid.view(np.uint8).copy()).cuda()
+    d_src = torch.from_numpy(str16.reshape(-1).copy()).cuda()
+    d_heap = torch.from_numpy(heap).cuda()
+    o_valid = torch.zeros((n + 7) // 8 + 16, dtype=torch.uint8, device="cuda")
+    o_off = torch.zeros(4 * (n + 1) + 16, dtype=torch.uint8, device="cuda")
+    o_data = torch.full((payload + 64,), 0xEE, dtype=torch.uint8, device="cuda")
+    t = da.make_task(_ffi.K_ENC_STR32, n, d_src.data_ptr(), o_off.data_ptr(), validity=d_valid.data_ptr(),
+                     out_validity=o_valid.data_ptr(), out_aux=o_data.data_ptr(), buf2=d_heap.data_ptr(), ptr_base=0,
+                     buf2_len=heap.size)
+    plan = da.Plan(con.ctx, [t])
+    plan.launch(torch.cuda.current_stream().cuda_stream)
+    assert plan.status() == 0
+    want_off = np.zeros(n + 1, np.int32)
+    want_data = np.zeros(payload + 1, np.uint8)
+    rc = po.lib().orc_enc_varchar32(str16.ctypes.data, valid.ctypes.data, n, 0, 0, heap.ctypes.data, want_off.ctypes.data,
+                                    want_data.ctypes.data)
+    assert rc == 0
+    assert np.array_equal(want_data[:payload], np.concatenate([text[i] for i in range(n) if ok[i]] + [np.zeros(0, np.uint8)]))
+    assert np.array_equal(o_off.cpu().numpy()[: 4 * (n + 1)].view(np.int32), want_off)
+    got = o_data.cpu().numpy()
+    assert np.array_equal(got[:payload], want_data[:payload])
+    assert np.all(got[payload:] == 0xEE)          # nothing written past the payload
+    assert plan.null_counts()[0] == int(n - ok.sum())
+
+
 # ---------------------------------------------------------------------------------------- test_arrow_ipc_writer.py
 def create_table():
     return da.Table(["f0", "f1", "f2"], ["INTEGER", "VARCHAR", "BOOLEAN"],
