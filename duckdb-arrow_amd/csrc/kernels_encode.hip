@@ -288,6 +288,25 @@ __device__ __forceinline__ void string_bytes_to_lds(uint8_t* dst, const u32x4& s
   }
 }
 
+// Stage bytes [shiftw, end) -> gbase[shiftw, end) by the whole workgroup (end > shiftw); gbase is 16-byte aligned:
+// coalesced 16-byte nontemporal stores, the (at most two) partial 16-byte rows one byte per lane.
+__device__ __forceinline__ void stage_to_data(const uint8_t* st, uint32_t shiftw, uint32_t end, gptr<uint8_t> gbase) {
+  const uint32_t nch = (end + 15) >> 4;
+  for (uint32_t c = threadIdx.x; c < nch; c += kBlockThreads) {
+    const uint32_t clo = c << 4;
+    if (clo >= shiftw && clo + 16 <= end)
+      __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(st + clo), (gptr<u32x4>)(gbase + clo));
+  }
+  if (threadIdx.x < 32) {
+    const uint32_t lastlo = (end - 1) & ~15u;
+    const uint32_t idx = threadIdx.x < 16 ? threadIdx.x : lastlo + (threadIdx.x - 16);
+    const bool first_partial = shiftw != 0 || end < 16;
+    const bool last_partial = (end & 15u) != 0 && lastlo != 0;
+    const bool mine = threadIdx.x < 16 ? first_partial : last_partial;
+    if (mine && idx >= shiftw && idx < end) gbase[idx] = st[idx];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------- K7d, single pass
 // string_t rows (or list_entry_t rows: offsets only) -> Arrow offsets + data in ONE pass over HBM: every tile first adds up
 // its own lengths (a pass over the length fields, whose cache lines the main loop then finds in L2), publishes the sum and
@@ -348,10 +367,13 @@ __global__ __launch_bounds__(kBlockThreads, 8) void encode_string_1p(const mi_co
   // the first sub-block's rows are on their way while the tile adds up its lengths
   u32x4 nxt = __builtin_nontemporal_load(str + (static_cast<int>(threadIdx.x) < n ? static_cast<int>(threadIdx.x) : n - 1));
   __syncthreads();  // s_valid
+  uint32_t pre_len[kTileRows / kBlockThreads], pre_bytes[kTileRows / kBlockThreads];
   // ---- the tile's payload size: the length field of every valid row (dword 0 of a string_t, the low dword of a
   // list_entry_t's length), 64 bits so that it is exact whatever the strings hold
   {
-    gptr<const uint32_t> lens = GC<uint32_t>(t.buf1) + 4 * row0 + (is_list ? 2 : 0);
+    // (two dwords per row: the second is a string_t's first four bytes, all there is to a string of <= 4 bytes -- a tile of
+    // flags or codes is encoded below from these registers alone)
+    gptr<const u32x2> lens = (gptr<const u32x2>)(GC<uint32_t>(t.buf1) + 4 * row0 + (is_list ? 2 : 0));
     unsigned long long local = 0;
     uint32_t longest = 0;
     // ... and, in the same pass, the bytes of every (sub-block, wave) group of 64 rows, so that the encode loop below does
@@ -359,12 +381,15 @@ __global__ __launch_bounds__(kBlockThreads, 8) void encode_string_1p(const mi_co
 #pragma unroll
     for (int k = 0; k < kTileRows / kBlockThreads; k++) {
       const int r = static_cast<int>(threadIdx.x) + k * kBlockThreads;
-      uint32_t l = 0;
-      if (r < n && ((s_valid[r >> 6] >> (r & 63)) & 1)) l = lens[4 * r];
+      u32x2 ly = {0u, 0u};
+      if (r < n && ((s_valid[r >> 6] >> (r & 63)) & 1)) ly = lens[2 * r];  // not nontemporal: the encode loop finds the rows of a tile with longer strings in L2
+      const uint32_t l = ly.x;
       local += l;
       longest = longest > l ? longest : l;
       const uint32_t incl = wave_inclusive_scan_u32(l);
       if (lane == 63) s_wtot[k * kWaves + wave] = incl;
+      pre_len[k] = l;
+      pre_bytes[k] = ly.y;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) local += __shfl_down(local, d, 64);
@@ -445,6 +470,26 @@ __global__ __launch_bounds__(kBlockThreads, 8) void encode_string_1p(const mi_co
     if (large) offp64[-1] = 0;
     else offp[-1] = 0;
   }
+  if (tiny) {  // uniform.  <= 8 KiB for the tile: one window over both stage buffers, one barrier, nothing more to load
+    const uint32_t shiftw = static_cast<uint32_t>(tile_base & 15);
+#pragma unroll
+    for (int k = 0; k < kTileRows / kBlockThreads; k++) {
+      const int r = static_cast<int>(threadIdx.x) + k * kBlockThreads;
+      const uint32_t len = pre_len[k], ex = s_wbase[k * kWaves + wave] + (wave_inclusive_scan_u32(pre_len[k]) - pre_len[k]), y = pre_bytes[k];
+      if (r < n) {
+        if (large) offp64[r] = tile_base + ex + len;
+        else offp[r] = static_cast<int32_t>(tile_base + ex + len);
+      }
+      uint8_t* d = stage + shiftw + ex;
+      if (len > 0) d[0] = static_cast<uint8_t>(y);
+      if (len > 1) d[1] = static_cast<uint8_t>(y >> 8);
+      if (len > 2) d[2] = static_cast<uint8_t>(y >> 16);
+      if (len > 3) d[3] = static_cast<uint8_t>(y >> 24);
+    }
+    __syncthreads();
+    if (tile_total > 0) stage_to_data(stage, shiftw, shiftw + static_cast<uint32_t>(tile_total), data + tile_base - shiftw);
+    return;
+  }
   const int nsub = (n + kBlockThreads - 1) / kBlockThreads;
   uint32_t buf = 0;
 #pragma clang loop unroll(disable)
@@ -474,7 +519,7 @@ __global__ __launch_bounds__(kBlockThreads, 8) void encode_string_1p(const mi_co
     bool contig = false;      // wave-uniform
     uint64_t cbase = 0;       // heap offset of the sub-block's byte 0, were it all in the heap
     uint32_t blo = 0, bhi = 0;  // sub-block bytes [blo, bhi): first long string .. end of the last one
-    if (!tiny && long_mask != 0) {
+    if (long_mask != 0) {
       const uint64_t cdelta = (static_cast<uint64_t>(s.z) | (static_cast<uint64_t>(s.w) << 32)) - t.ptr_base - ex;
       const int fl = __builtin_ctzll(long_mask), ll = 63 - __builtin_clzll(long_mask);
       cbase = static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(cdelta)), fl))) |
@@ -493,13 +538,7 @@ __global__ __launch_bounds__(kBlockThreads, 8) void encode_string_1p(const mi_co
       const uint32_t w1 = total - w0 < room ? total : w0 + room;
       uint8_t* st = stage + buf * kEncStageBuf;
       const uint32_t lo = ex > w0 ? ex : w0, hi = ex + len < w1 ? ex + len : w1;
-      if (tiny) {  // uniform; <= 1 KiB per sub-block: always one window
-        uint8_t* d = st + shiftw + ex;
-        if (len > 0) d[0] = static_cast<uint8_t>(s.y);
-        if (len > 1) d[1] = static_cast<uint8_t>(s.y >> 8);
-        if (len > 2) d[2] = static_cast<uint8_t>(s.y >> 16);
-        if (len > 3) d[3] = static_cast<uint8_t>(s.y >> 24);
-      } else {
+      {
         if (contig) {  // wave-uniform: sub-block bytes [a, b) of this window come straight from the heap
           const uint32_t a = blo > w0 ? blo : w0, b = bhi < w1 ? bhi : w1;
           if (a < b) {
@@ -519,23 +558,7 @@ __global__ __launch_bounds__(kBlockThreads, 8) void encode_string_1p(const mi_co
           string_bytes_to_lds(st + shiftw + (lo - w0), s, heap, t.ptr_base, lo - ex, hi - lo);
       }
       __syncthreads();
-      // stage bytes [shiftw, end) -> gbase[shiftw, end); gbase is 16-byte aligned
-      const uint32_t end = shiftw + (w1 - w0);
-      gptr<uint8_t> gbase = data + (base + w0) - shiftw;
-      const uint32_t nch = (end + 15) >> 4;
-      for (uint32_t c = threadIdx.x; c < nch; c += kBlockThreads) {
-        const uint32_t clo = c << 4;
-        if (clo >= shiftw && clo + 16 <= end)
-          __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(st + clo), (gptr<u32x4>)(gbase + clo));
-      }
-      if (threadIdx.x < 32) {  // the (at most two) partial 16-byte rows, one byte per lane
-        const uint32_t lastlo = (end - 1) & ~15u;
-        const uint32_t idx = threadIdx.x < 16 ? threadIdx.x : lastlo + (threadIdx.x - 16);
-        const bool first_partial = shiftw != 0 || end < 16;
-        const bool last_partial = (end & 15u) != 0 && lastlo != 0;
-        const bool mine = threadIdx.x < 16 ? first_partial : last_partial;
-        if (mine && idx >= shiftw && idx < end) gbase[idx] = st[idx];
-      }
+      stage_to_data(st, shiftw, shiftw + (w1 - w0), data + (base + w0) - shiftw);
       buf ^= 1u;
       w0 = w1;
     }
