@@ -362,18 +362,28 @@ __global__ __launch_bounds__(kBlockThreads, 8) void encode_string_1p(const mi_co
   MI_TILE_PROLOGUE();
   const bool is_list = t.kind == MI_K_ENC_LIST32;
   const bool large = (t.flags & 1) != 0;  // LargeUtf8 / LargeList: int64 offsets (arrow_large_buffer_size)
+  // The length pass reads two dwords per row (the length field: dword 0 of a string_t, the low dword of a list_entry_t's
+  // length; and the dword behind it: a string_t's first four bytes, all there is to a string of <= 4 bytes -- a tile of
+  // flags or codes is encoded below from these registers alone).  The loads leave before the validity words are even
+  // asked for: the length of a NULL row is read and then ignored.
+  uint32_t pre_len[kTileRows / kBlockThreads], pre_bytes[kTileRows / kBlockThreads];
+  {
+    gptr<const u32x2> lens = (gptr<const u32x2>)(GC<uint32_t>(t.buf1) + 4 * row0 + (is_list ? 2 : 0));
+#pragma unroll
+    for (int k = 0; k < kTileRows / kBlockThreads; k++) {
+      const int r = static_cast<int>(threadIdx.x) + k * kBlockThreads;
+      const u32x2 ly = lens[2 * (r < n ? r : n - 1)];  // not nontemporal: the encode loop finds the rows of a tile with longer strings in L2
+      pre_len[k] = ly.x;
+      pre_bytes[k] = ly.y;
+    }
+  }
   enc_tile_validity(t, row0, n, null_counts, s_valid);
   gptr<const u32x4> str = GC<u32x4>(t.buf1) + row0;
   // the first sub-block's rows are on their way while the tile adds up its lengths
   u32x4 nxt = __builtin_nontemporal_load(str + (static_cast<int>(threadIdx.x) < n ? static_cast<int>(threadIdx.x) : n - 1));
   __syncthreads();  // s_valid
-  uint32_t pre_len[kTileRows / kBlockThreads], pre_bytes[kTileRows / kBlockThreads];
-  // ---- the tile's payload size: the length field of every valid row (dword 0 of a string_t, the low dword of a
-  // list_entry_t's length), 64 bits so that it is exact whatever the strings hold
+  // ---- the tile's payload size: the length field of every valid row, 64 bits so that it is exact whatever the strings hold
   {
-    // (two dwords per row: the second is a string_t's first four bytes, all there is to a string of <= 4 bytes -- a tile of
-    // flags or codes is encoded below from these registers alone)
-    gptr<const u32x2> lens = (gptr<const u32x2>)(GC<uint32_t>(t.buf1) + 4 * row0 + (is_list ? 2 : 0));
     unsigned long long local = 0;
     uint32_t longest = 0;
     // ... and, in the same pass, the bytes of every (sub-block, wave) group of 64 rows, so that the encode loop below does
@@ -381,15 +391,12 @@ __global__ __launch_bounds__(kBlockThreads, 8) void encode_string_1p(const mi_co
 #pragma unroll
     for (int k = 0; k < kTileRows / kBlockThreads; k++) {
       const int r = static_cast<int>(threadIdx.x) + k * kBlockThreads;
-      u32x2 ly = {0u, 0u};
-      if (r < n && ((s_valid[r >> 6] >> (r & 63)) & 1)) ly = lens[2 * r];  // not nontemporal: the encode loop finds the rows of a tile with longer strings in L2
-      const uint32_t l = ly.x;
+      const uint32_t l = (r < n && ((s_valid[r >> 6] >> (r & 63)) & 1)) ? pre_len[k] : 0u;
       local += l;
       longest = longest > l ? longest : l;
       const uint32_t incl = wave_inclusive_scan_u32(l);
       if (lane == 63) s_wtot[k * kWaves + wave] = incl;
       pre_len[k] = l;
-      pre_bytes[k] = ly.y;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) local += __shfl_down(local, d, 64);
