@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--no-validity", action="store_true", help="pyarrow-style stream without validity bitmaps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-operator-path", action="store_true", help="skip the /dev/shm operator-path legs")
+    ap.add_argument("--no-encode-leg", action="store_true", help="skip the K7 encode kernels over the decoded vectors (config 4)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (decode; the encode leg gets half)")
     ap.add_argument("--prewarm-seconds", type=float, default=1.5, help="untimed clock ramp before the warmup steps")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the "
@@ -251,6 +252,20 @@ def main():
                                              "orc_encode_stream: chunk concatenation + ArrowAppender loops + body copy; every produced "
                                              "buffer equals the source stream's" % (st["batches"], st["rows"]),
                                    "seconds": st["seconds"], "GBps_out": st["bytes_out"] / st["seconds"] / 1e9}
+    # ---- secondary, never `value`: BASELINE config 4 at kernel level -- the K7 encode kernels over the vectors this run has
+    # just decoded (DuckDB vectors resident in HBM -> Arrow buffers), one plan for the table, HIP events per kernel class ----
+    encode_kernels = None
+    if rank == 0 and world == 1 and not args.no_encode_leg:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+        from encode_bench import encode_leg
+        from duckdb_arrow_amd import _ffi
+        e = encode_leg(torch, da, _ffi, ctx, hs, buf, info, rounds=5)
+        for k in e["kernels"]:
+            k["frac_of_8TBps"] = k["GBps"] / 8000.0
+        encode_kernels = dict(e, note="secondary figure, not `value`: COPY TO's Vector -> Arrow encode (ArrowAppender semantics) of the "
+                                      "same table, kernels only; offsets and data buffers of the first record batch compared with the "
+                                      "source stream's (payload_matches_source); rocprofv3 stats + FETCH/WRITE passes of "
+                                      "tools/encode_bench.py: profiles/r02/encode/")
     hs.close()
     del hs
 
@@ -413,6 +428,7 @@ def main():
             "cpu_baseline_encode": cpu_baseline_encode,
             "parity": parity,
             "reference_shaped": ref_shaped,
+            "config4_encode_kernels": encode_kernels,
             "operator_path": operator_path,
             "setup_seconds": {"generate": t_gen, "parse_upload_plan": t_upload},
         }

@@ -12,23 +12,11 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--sf", type=float, default=1.0)
-    ap.add_argument("--rounds", type=int, default=5)
-    ap.add_argument("--per-column", action="store_true", help="also time one plan per column (diagnostic)")
-    args = ap.parse_args()
-    import torch
-    import duckdb_arrow_amd as da
-    from duckdb_arrow_amd import _ffi
-    from duckdb_arrow_amd.hbm import HbmStream
-    torch.cuda.set_device(0)
-    buf, info = da.synth_lineitem_stream(scale_factor=args.sf, seed=42)
-    ctx = da.Context(0)
-    hs = HbmStream(ctx, buf)
-    hs.launch()
-    assert hs.status() == 0
-    torch.cuda.synchronize()
+def encode_leg(torch, da, _ffi, ctx, hs, buf, info, rounds=5, per_column=False):
+    """K7 over the decoded vectors of `hs` (an HbmStream that has been launched): one plan for the whole table, HIP-event
+    time per kernel class, algorithmic GB/s, and a check of the first record batch's offsets and data buffers against the
+    source stream.  Used by this tool and by bench.py's `config4_encode_kernels` block."""
+    args = argparse.Namespace(rounds=rounds, per_column=per_column)
     in_base, out_base = hs.in_ptr, hs.out_ptr
     enc_kind = {_ffi.K_COPY: _ffi.K_ENC_COPY, _ffi.K_DEC128: _ffi.K_ENC_DEC128, _ffi.K_STR32: _ffi.K_ENC_STR32}
     total = 0
@@ -67,12 +55,16 @@ def main():
             b = c["bytes_read"] + c["bytes_written"]
             out["kernels"].append({"kernel": c["kernel"], "ms": float(med[i]), "algorithmic_bytes": b, "GBps": b / (med[i] * 1e-3) / 1e9})
     out["rows_per_s"] = info["n_rows"] / (out["ms_total"] * 1e-3)
-    # spot check: first batch, every buffer equals the source stream's buffer
-    lay, e, offs, sz = spans[15]
-    got = arena[offs[2]: offs[2] + sz[2]].cpu().numpy()
-    body = lay["body_off"]
-    want = buf[body + e["buffers"][2][0]: body + e["buffers"][2][0] + sz[2]]
-    out["payload_matches_source"] = bool(np.array_equal(got, want))
+    # check: first record batch, the offsets and data buffers of every column equal the source stream's buffers
+    ok = True
+    for lay, e, offs, sz in spans[: len(hs.layout[0]["columns"])]:
+        body = lay["body_off"]
+        for b in (1, 2):
+            if sz[b]:
+                got = arena[offs[b]: offs[b] + sz[b]].cpu().numpy()
+                want = buf[body + e["buffers"][b][0]: body + e["buffers"][b][0] + sz[b]]
+                ok = ok and bool(np.array_equal(got, want))
+    out["payload_matches_source"] = ok
     if args.per_column:
         out["per_column"] = {}
         for nm in dict.fromkeys(names):
@@ -83,7 +75,29 @@ def main():
             ms = float(np.median(ts.sum(axis=1)))
             out["per_column"][nm] = {"ms": ms, "GBps": (st["bytes_read"] + st["bytes_written"]) / ms / 1e6}
             p1.close()
-    print(json.dumps(out))
+    plan.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sf", type=float, default=1.0)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--per-column", action="store_true", help="also time one plan per column (diagnostic)")
+    args = ap.parse_args()
+    import torch
+    import duckdb_arrow_amd as da
+    from duckdb_arrow_amd import _ffi
+    from duckdb_arrow_amd.hbm import HbmStream
+    torch.cuda.set_device(0)
+    buf, info = da.synth_lineitem_stream(scale_factor=args.sf, seed=42)
+    ctx = da.Context(0)
+    hs = HbmStream(ctx, buf)
+    hs.launch()
+    assert hs.status() == 0
+    torch.cuda.synchronize()
+    print(json.dumps(encode_leg(torch, da, _ffi, ctx, hs, buf, info, args.rounds, args.per_column)))
+
 
 
 if __name__ == "__main__":

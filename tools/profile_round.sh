@@ -13,7 +13,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 for w in $workloads; do
   case $w in
-    decode)  full="bench.py --no-operator-path"; short="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-operator-path" ;;
+    decode)  full="bench.py --no-operator-path"; short="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-operator-path --no-encode-leg" ;;
     encode)  full="tools/encode_bench.py --sf 10 --per-column"; short="tools/encode_bench.py --sf 10 --rounds 3" ;;
     commits) full="tools/commits_bench.py"; short="tools/commits_bench.py" ;;
     filter)  full="tools/filter_bench.py"; short="tools/filter_bench.py" ;;
