@@ -274,3 +274,34 @@ def test_lz4_blocks_walked_from_global_memory(tmp_path):
     """) % (ROOT, ROOT, str(tmp_path / "g.arrows"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, MI_LZ4_PARSE_GLOBAL="1"), timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_lz4_one_stream_per_slot_with_hardware_queues_to_spare(tmp_path):
+    """With GPU_MAX_HW_QUEUES >= slots + 3 in the process environment the K8 kernels of every slot run on a stream of their
+    own (scan_operator.cpp EnqueueLz4) instead of three shared ones: many small record batches in flight, the same vectors."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r)
+        import numpy as np, pyarrow as pa, pyarrow.ipc as ipc
+        import duckdb_arrow_amd as da
+        rng = np.random.default_rng(9)
+        n = 200000
+        t = pa.table({"k": pa.array(np.arange(n, dtype=np.int64) * 3), "s": pa.array(["row %%d %%s" %% (i %% 977, "y" * (i %% 19)) for i in range(n)]),
+                      "q": pa.array(rng.integers(0, 50, n).astype(np.int32)), "d": pa.array(rng.integers(8000, 10500, n).astype(np.int32), pa.date32())})
+        p = %r
+        with ipc.new_stream(p, t.schema, options=ipc.IpcWriteOptions(compression="lz4")) as w:
+            w.write_table(t, max_chunksize=10000)       # 20 record batches over 8 or 12 slots
+        con = da.Connection(0)
+        want = con.read_arrow(p, host_decompress=True).fetch_columns()
+        for depth in (8, 12):
+            rel = con.read_arrow(p, host_decompress="gpu", pipeline_depth=depth)
+            got = rel.fetch_columns()
+            assert got == want and rel.stats()["lz4_batches_on_device"] == 20
+            rel = con.read_arrow(p, device_resident=True, pipeline_depth=depth)
+            assert rel.count(detail=True)["rows"] == n and rel.stats()["lz4_batches_on_device"] == 20
+        print("ok")
+    """) % (ROOT, str(tmp_path / "q.arrows"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, GPU_MAX_HW_QUEUES="20"), timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
