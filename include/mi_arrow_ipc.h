@@ -273,7 +273,10 @@ int mi_device_count(void);
 typedef struct mi_col_task {
   const void* validity;   /* Arrow validity bitmap, or NULL when absent (buffer length 0) */
   const void* buf1;       /* fixed-width data / offsets / dictionary indices / (encode) DuckDB vector data */
-  const void* buf2;       /* string data / (encode) string heap */
+  const void* buf2;       /* string data / (encode) string heap: the bytes long string_t rows point into (ptr - ptr_base).
+                             Any layout is encoded exactly; when the long strings of 64 consecutive rows lie there as they
+                             will lie in the Arrow data buffer (an Arrow data buffer itself, or a heap staged in row order
+                             with the slots of inline strings left open) they are moved as one coalesced copy. */
   void* out_data;         /* DuckDB vector data, nrows * out_width bytes (encode: Arrow buffer 1) */
   void* out_validity;     /* mi_validity_t[ceil(nrows/64)] or NULL to skip (encode: Arrow bitmap) */
   void* out_aux;          /* encode: Arrow buffer 2 (string data); decode: validity words of the PARENT vector when NULLs
