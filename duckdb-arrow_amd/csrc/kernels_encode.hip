@@ -18,16 +18,27 @@ namespace {
 
 // K7a: DuckDB validity words have Arrow's bit order and polarity, so the bitmap is a byte copy of the words with
 // the pad bits of the last byte forced to 1 (ResizeValidity fills with 0xFF) and NULLs counted on the way.
-__device__ __forceinline__ void enc_tile_validity(const mi_col_task& t, int64_t row0, int n, int64_t* null_counts,
-                                                  uint64_t* s_valid = nullptr) {
+// In two halves, so that a kernel can put its own loads between the request for the validity word and its use.
+struct EncValidity {
+  uint64_t w;
+  bool active;
+};
+__device__ __forceinline__ EncValidity enc_tile_validity_load(const mi_col_task& t, int64_t row0, int n, const uint64_t* s_valid = nullptr) {
+  EncValidity v{~0ull, false};
+  if (threadIdx.x >= 64 || (t.out_validity == nullptr && s_valid == nullptr)) return v;  // wave 0, uniform
+  const int lane = threadIdx.x;
+  v.active = lane < ((n + 63) >> 6);
+  if (v.active && t.validity != nullptr) v.w = GC<uint64_t>(t.validity)[(row0 >> 6) + lane];
+  return v;
+}
+__device__ __forceinline__ void enc_tile_validity_finish(const mi_col_task& t, int64_t row0, int n, int64_t* null_counts, EncValidity v,
+                                                         uint64_t* s_valid = nullptr) {
   if (threadIdx.x >= 64 || (t.out_validity == nullptr && s_valid == nullptr)) return;  // wave 0, uniform
   const int lane = threadIdx.x;
-  const int nwords = (n + 63) >> 6;
-  const bool active = lane < nwords;
-  uint64_t w = ~0ull;
+  const bool active = v.active;
+  uint64_t w = v.w;
   const int rem = n - 64 * lane;
   if (active) {
-    if (t.validity != nullptr) w = GC<uint64_t>(t.validity)[(row0 >> 6) + lane];
     if (rem < 64) w |= ~0ull << rem;
     if (s_valid) s_valid[lane] = w;
   }
@@ -45,6 +56,10 @@ __device__ __forceinline__ void enc_tile_validity(const mi_col_task& t, int64_t 
   } else {
     for (int k = 0; k < nbytes; k++) out[k] = static_cast<uint8_t>(w >> (8 * k));
   }
+}
+__device__ __forceinline__ void enc_tile_validity(const mi_col_task& t, int64_t row0, int n, int64_t* null_counts,
+                                                  uint64_t* s_valid = nullptr) {
+  enc_tile_validity_finish(t, row0, n, null_counts, enc_tile_validity_load(t, row0, n, s_valid), s_valid);
 }
 
 __device__ __forceinline__ bool enc_row_valid(gptr<const uint64_t> v, bool has, int64_t row) {
@@ -89,7 +104,9 @@ __global__ __launch_bounds__(kBlockThreads) void encode_fixed(const mi_col_task*
                                                               uint32_t total_tiles, int64_t* __restrict__ null_counts) {
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     MI_TILE_PROLOGUE();
-    enc_tile_validity(t, row0, n, null_counts);
+    // wave 0 asks for the tile's validity words, moves its share of the data, and only then turns the words into bitmap
+    // bytes and a NULL count: one round trip for the wave instead of two
+    const EncValidity tv = enc_tile_validity_load(t, row0, n);
     switch (t.kind) {
       case MI_K_ENC_COPY: {  // NULL slots copy whatever the source slot holds, like ArrowScalarData::Append
         const int w = static_cast<int>(t.param);
@@ -104,6 +121,7 @@ __global__ __launch_bounds__(kBlockThreads) void encode_fixed(const mi_col_task*
       case MI_K_ENC_BOOL: enc_tile_bool(t, row0, n); break;
       default: break;
     }
+    enc_tile_validity_finish(t, row0, n, null_counts, tv);
   }
 }
 
