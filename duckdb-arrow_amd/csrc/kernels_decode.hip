@@ -85,17 +85,25 @@ __device__ __forceinline__ void tile_string(const mi_col_task& t, int64_t row0, 
   const int64_t data_len = t.buf2_len;
   const int lane = threadIdx.x & 63;
   OFF a[R], b[R];
+  // (the wave-edge loads of off[r+1] leave together with the others: asked for only once the neighbours' values are in --
+  // they feed a shuffle -- they were a round trip of their own in front of the payload loads)
 #pragma unroll
   for (int k = 0; k < R; k++) {
     const int r = threadIdx.x + k * kBlockThreads;
+    const bool edge = lane == 63 || r == n - 1;
     a[k] = r < n ? off[r] : 0;
+    if (sizeof(OFF) == 4) b[k] = (r < n && edge) ? off[r + 1] : 0;  // (int64 offsets: 16 more registers at this point, an occupancy step)
   }
 #pragma unroll
   for (int k = 0; k < R; k++) {
     const int r = threadIdx.x + k * kBlockThreads;
     const OFF from_neighbour = __shfl_down(a[k], 1, 64);
     const bool edge = lane == 63 || r == n - 1;
-    b[k] = (r < n && edge) ? off[r + 1] : from_neighbour;
+    if (sizeof(OFF) == 4) {
+      if (!(r < n && edge)) b[k] = from_neighbour;
+    } else {
+      b[k] = (r < n && edge) ? off[r + 1] : from_neighbour;
+    }
   }
   uint32_t err = 0;
   u32x4 s[R];
