@@ -64,6 +64,31 @@ def roofline_of(kernels, alg_bytes, ms_per_step):
             "whole_step_frac": alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
+def cpu_multifile_baseline(paths):
+    """oracle_scan.c (body copy + FULL offset validation + 2048-row pull loop) over the files of the operator-path legs,
+    one file per thread; the files are read into memory first (untimed: they sit in the page cache, and the scan's body copy
+    stands for the reference's ReadData).  ctypes releases the GIL around the C call."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import pyoracle as po
+    bufs = [np.fromfile(p, dtype=np.uint8) for p in paths]
+    n_threads = max(1, min(len(bufs), os.cpu_count() or 1))
+
+    def one(b):
+        rc, st = po.scan_stream(b)
+        assert rc == 0
+        return st["rows"]
+
+    dt = None
+    with ThreadPoolExecutor(n_threads) as ex:
+        for _ in range(2):   # the first pass also touches every thread's scratch for the first time
+            t1 = time.perf_counter()
+            rows = sum(ex.map(one, bufs))
+            d1 = time.perf_counter() - t1
+            dt = d1 if dt is None else min(dt, d1)
+    return {"value": rows / dt, "unit": "rows/s", "cores": n_threads, "kind": "port", "seconds": dt, "rows": rows,
+            "sample": "the whole table: %d files, one oracle_scan.c scan per thread" % len(bufs), "host_cpus": os.cpu_count()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -310,6 +335,13 @@ def main():
                 assert rows_all == info["n_rows"], (rows_all, info["n_rows"])
                 legs[leg] = {"seconds": best, "rows_per_s": rows_all / best, "rows": rows_all, "selected": sel_all,
                              "file_GBps": sum(os.path.getsize(p) for p in paths) / best / 1e9}
+            if world == 1 and not args.no_cpu_baseline:
+                # the CPU beside the multi-file legs (min(files, cores) threads, one file per thread -- the reference
+                # scans one file per thread, src/file_scanner/arrow_file_scan.cpp:35-42): the oracle port over the same 8 files
+                try:
+                    legs["cpu_baseline_multifile"] = cpu_multifile_baseline(paths)
+                except Exception as e:   # a secondary figure must not cost the line
+                    legs["cpu_baseline_multifile"] = {"error": repr(e)[:200]}
             if world == 1:
                 # BASELINE config 4 through the operator: COPY (FROM read_arrow(files)) TO 'out.arrows' (row_group_size 122880);
                 # decode and encode both on the GPU, only the finished IPC bodies travel back (mi_writer_sink_scan)

@@ -111,13 +111,14 @@ static uint64_t fold(const uint8_t* p, int64_t n) {
 int orc_scan_stream(const uint8_t* buf, int64_t size, int32_t max_batches, int32_t want_checksum,
                     orc_scan_stats* st) {
   memset(st, 0, sizeof(*st));
-  static orc_msg msgs[1 << 16];
+  /* scratch tables are thread-local: bench.py's multi-file CPU baseline runs one scan per thread */
+  static _Thread_local orc_msg msgs[1 << 16];
   int32_t nmsg = 0;
   char err[128];
   int rc = orc_walk_stream(buf, size, msgs, 1 << 16, &nmsg, err, sizeof(err));
   if (rc) return rc;
   if (nmsg == 0 || msgs[0].type != ORC_MSG_SCHEMA) return ORC_EIO;
-  static orc_field fields[MAX_FIELDS];
+  static _Thread_local orc_field fields[MAX_FIELDS];
   int32_t nf = 0, ntop = 0, endian = 0;
   rc = orc_decode_schema(buf + msgs[0].meta_off, msgs[0].meta_len, fields, MAX_FIELDS, &nf, &ntop, &endian);
   if (rc) return rc;
@@ -134,8 +135,8 @@ int orc_scan_stream(const uint8_t* buf, int64_t size, int32_t max_batches, int32
   uint64_t chunk_valid[ORC_VECTOR_SIZE / 64];
   for (int32_t c = 0; c < nf; c++) chunk_data[c] = (uint8_t*)malloc((size_t)ORC_VECTOR_SIZE * 16);
 
-  static orc_node nodes[MAX_FIELDS];
-  static orc_buf bufs[MAX_BUFS];
+  static _Thread_local orc_node nodes[MAX_FIELDS];
+  static _Thread_local orc_buf bufs[MAX_BUFS];
   int32_t done = 0;
   for (int32_t m = 1; m < nmsg && done < max_batches; m++) {
     if (msgs[m].type != ORC_MSG_RECORD_BATCH) { rc = ORC_EIO; break; } /* "Expected RecordBatch Arrow IPC message but got ..." */
@@ -241,13 +242,13 @@ static double now_seconds(void) {
 
 int orc_encode_stream(const uint8_t* buf, int64_t size, int32_t max_batches, int32_t verify, orc_encode_stats* st) {
   memset(st, 0, sizeof(*st));
-  static orc_msg msgs[1 << 16];
+  static _Thread_local orc_msg msgs[1 << 16];
   int32_t nmsg = 0;
   char err[128];
   int rc = orc_walk_stream(buf, size, msgs, 1 << 16, &nmsg, err, sizeof(err));
   if (rc) return rc;
   if (nmsg == 0 || msgs[0].type != ORC_MSG_SCHEMA) return ORC_EIO;
-  static orc_field fields[MAX_FIELDS];
+  static _Thread_local orc_field fields[MAX_FIELDS];
   int32_t nf = 0, ntop = 0, endian = 0;
   rc = orc_decode_schema(buf + msgs[0].meta_off, msgs[0].meta_len, fields, MAX_FIELDS, &nf, &ntop, &endian);
   if (rc) return rc;
@@ -259,8 +260,8 @@ int orc_encode_stream(const uint8_t* buf, int64_t size, int32_t max_batches, int
     if (rc) return rc;
     if (kind[c] != ORC_K_COPY && kind[c] != ORC_K_DEC128 && kind[c] != ORC_K_STR32 && kind[c] != ORC_K_BOOL) return ORC_ENOTSUP;
   }
-  static orc_node nodes[MAX_FIELDS];
-  static orc_buf bufs[MAX_BUFS];
+  static _Thread_local orc_node nodes[MAX_FIELDS];
+  static _Thread_local orc_buf bufs[MAX_BUFS];
   int32_t done = 0;
   for (int32_t m = 1; m < nmsg && done < max_batches && rc == ORC_OK; m++) {
     if (msgs[m].type != ORC_MSG_RECORD_BATCH) return ORC_EIO;
