@@ -215,3 +215,17 @@ def test_scan_stream_driver_counts(golden_dir):
     assert st2["checksum"] == st["checksum"]
     rc3, st3 = po.scan_stream(buf, max_batches=3)
     assert st3["batches"] == 3 and st3["rows"] == 3072
+
+
+def test_scan_stream_from_several_threads_equals_the_single_thread_scan():
+    """bench.py's cpu_baseline_multifile runs one oracle scan per thread (one per file): the scan's scratch tables are
+    thread-local, so concurrent scans of different streams give what each gives alone (rows, bytes, checksum)."""
+    from concurrent.futures import ThreadPoolExecutor
+    import duckdb_arrow_amd as da
+    streams = [da.synth_lineitem_stream(scale_factor=0.01 * (i + 1), seed=7 + i, rows_per_batch=5000 + 700 * i)[0] for i in range(4)]
+    alone = [po.scan_stream(b, want_checksum=True) for b in streams]
+    assert all(rc == 0 and st["rows"] > 0 for rc, st in alone)
+    with ThreadPoolExecutor(4) as ex:
+        for _ in range(3):
+            together = list(ex.map(lambda b: po.scan_stream(b, want_checksum=True), streams * 2))
+    assert together == alone * 2
