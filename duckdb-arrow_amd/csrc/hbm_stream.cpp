@@ -43,6 +43,11 @@ class HbmStream {
       if (b.compression != -1) throw NotImplementedException("mi_hbm_open takes uncompressed streams (compressed bodies go through the scan operator)");
       if (b.is_dictionary) {
         if (b.is_delta) throw NotImplementedException("delta dictionaries are handled by the scan operator, not by the HBM-resident mode");
+        // one dictionary per id for the whole resident stream: a replacement that arrives after record batches (legal in the
+        // stream format) would silently re-interpret the indices of the batches before it
+        if (!batches.empty() && dict_batches.count(b.dict_id))
+          throw NotImplementedException("dictionary " + std::to_string(b.dict_id) + " is replaced in mid-stream: dictionary versions are handled by "
+                                        "the scan operator, not by the HBM-resident mode");
         dict_batches[b.dict_id] = std::move(b);
       } else {
         batches.push_back(std::move(b));

@@ -959,7 +959,9 @@ void ArrowScan::EnqueueLz4(Slot& s) {
   for (size_t i = 0; i < nf; i++) {
     const auto& f = d.buffers[i];
     hf[i].out_off = static_cast<uint64_t>(f.out_off);
-    hf[i].out_len = static_cast<uint64_t>(f.out_len);
+    // a raw buffer (length prefix -1: Arrow C++ with min_space_savings, arrow-rs, Arrow Java) has no blocks: the layout
+    // kernels check "sum of the block sizes == out_len", which for it is 0 == 0; its bytes are copied below
+    hf[i].out_len = f.raw ? 0 : static_cast<uint64_t>(f.out_len);
     hf[i].first_block = f.first_block;
     hf[i].n_blocks = f.raw ? 0 : f.n_blocks;
     hf[i].block_max = f.block_max;

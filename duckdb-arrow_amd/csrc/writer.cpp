@@ -838,7 +838,9 @@ int SinkThreads() {
 // encodes it and writes it -- claims of the file range happen in row-group order, so the file equals the one-thread file.
 void PumpScanParallel(mi_writer* w, ArrowScan* scan, int threads, int64_t* rows_out, const BatchRef* first = nullptr) {
   struct Piece { int batch; int32_t w0, w1; };        // windows [w0, w1) of held batch `batch`
-  struct Job { std::vector<Piece> pieces; int64_t seq = 0; };
+  // `spilled`: rows of this row group the pump has already staged itself (see spill_cur below); the worker that takes the
+  // job appends the remaining pieces to it and flushes it instead of its own state
+  struct Job { std::vector<Piece> pieces; int64_t seq = 0; std::unique_ptr<mi_writer_local> spilled; };
   struct Held { BatchRef ref; int pieces_open = 0; bool fully_cut = false; };
   if (!first) scan->EnsurePipelineDepth(threads + 4);   // with a batch already acquired the caller has done it
   std::mutex mu;
@@ -871,6 +873,7 @@ void PumpScanParallel(mi_writer* w, ArrowScan* scan, int threads, int64_t* rows_
             job = std::move(jobs.front());
             jobs.pop_front();
           }
+          mi_writer_local* sink = job.spilled ? job.spilled.get() : local.get();
           for (const Piece& pc : job.pieces) {
             BatchRef ref;
             {
@@ -879,7 +882,7 @@ void PumpScanParallel(mi_writer* w, ArrowScan* scan, int threads, int64_t* rows_
             }
             for (int32_t wi = pc.w0; wi < pc.w1; wi++) {
               scan->BuildChunk(ref, wi, &storage, &chunk);
-              local->buffer->Append(chunk);
+              sink->buffer->Append(chunk);
             }
             std::lock_guard<std::mutex> lk(mu);
             Held& h = held[static_cast<size_t>(pc.batch)];
@@ -888,7 +891,7 @@ void PumpScanParallel(mi_writer* w, ArrowScan* scan, int threads, int64_t* rows_
               cv.notify_all();
             }
           }
-          local->FlushRowGroup(
+          sink->FlushRowGroup(
               [&] {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return error || next_claim == job.seq; });
@@ -917,8 +920,9 @@ void PumpScanParallel(mi_writer* w, ArrowScan* scan, int threads, int64_t* rows_
       }
       return b;
     }());
+    int64_t n_released = 0;           // batches given back to the scan so far
     auto dispatch = [&] {
-      if (cur.pieces.empty()) return;
+      if (cur.pieces.empty() && !cur.spilled) return;
       cur.seq = seq++;
       {
         std::lock_guard<std::mutex> lk(mu);
@@ -938,8 +942,35 @@ void PumpScanParallel(mi_writer* w, ArrowScan* scan, int threads, int64_t* rows_
         const BatchRef ref = held[static_cast<size_t>(tok)].ref;
         lk.unlock();
         scan->ReleaseBatch(ref);
+        n_released++;
         lk.lock();
       }
+    };
+    // A row group that spans more record batches than the scan has slots: every slot is held by a piece of the row group
+    // still being cut, which no sink thread will see before it is full.  The pump then stages those rows itself (a sink
+    // state of its own that travels with the job) and gives the slots back; the worker that gets the job appends the rest.
+    ChunkStorage spill_storage;
+    mi_data_chunk spill_chunk;
+    auto spill_cur = [&] {
+      if (!cur.spilled) cur.spilled = MakeLocal(w);
+      for (const Piece& pc : cur.pieces) {
+        const BatchRef ref = held[static_cast<size_t>(pc.batch)].ref;   // only the pump thread grows `held`
+        for (int32_t wi = pc.w0; wi < pc.w1; wi++) {
+          scan->BuildChunk(ref, wi, &spill_storage, &spill_chunk);
+          cur.spilled->buffer->Append(spill_chunk);
+        }
+        bool give_back;
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          Held& h = held[static_cast<size_t>(pc.batch)];
+          give_back = --h.pieces_open == 0 && h.fully_cut;
+        }
+        if (give_back) {
+          scan->ReleaseBatch(ref);
+          n_released++;
+        }
+      }
+      cur.pieces.clear();
     };
     while (true) {
       release_ready(false);
@@ -949,7 +980,19 @@ void PumpScanParallel(mi_writer* w, ArrowScan* scan, int threads, int64_t* rows_
         first = nullptr;
       } else if (!scan->AcquireBatch(&ref)) {
         if (scan->Exhausted()) break;
-        release_ready(true);   // every slot is held by a sink thread: wait for one to come back
+        // every slot is held.  Batches whose pieces all went to sink threads come back by themselves; the ones that only
+        // the undispatched row group refers to never would
+        std::vector<int> cur_toks;
+        for (const Piece& pc : cur.pieces)
+          if (std::find(cur_toks.begin(), cur_toks.end(), pc.batch) == cur_toks.end()) cur_toks.push_back(pc.batch);
+        bool with_workers;
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          with_workers = static_cast<int64_t>(held.size()) - n_released - static_cast<int64_t>(cur_toks.size()) > 0;
+        }
+        if (with_workers) release_ready(true);
+        else if (!cur.pieces.empty()) spill_cur();
+        else throw InternalException("COPY pump: no record batch can be acquired and none is held");
         continue;
       }
       scan->EnsureHostVectors(ref);

@@ -499,6 +499,9 @@ MI_ZHD bool DecodeSequences(READER& br, BP bits, uint32_t nbytes, uint32_t nseq,
       sof = CellNext(co) + br.Read(CellBits(co));
     }
     if (br.Left() < 0) return false;
+    // bit 31 of the emitted word means "repeat offset": an offset code of 31 (only a damaged frame has one; offsets reach
+    // 2^31 + 2^31 - 1 with it) must not be mistaken for one
+    if (ov > 3 && ov - 3 >= kRepMarker) return false;
     if (!emit(i, ll, ml, ov > 3 ? ov - 3 : (kRepMarker | (ov - 1 + (ll == 0 ? 1u : 0u))))) return false;
   }
   return br.Left() == 0;

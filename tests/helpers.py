@@ -129,3 +129,81 @@ def canon_stream(fields, batches, heap, heap_base=0):
         for c in b["columns"]:
             out[c["name"]].extend(canon_oracle_column(by_name[c["name"]], c, b["nrows"], heap, heap_base))
     return out
+
+
+# ------------------------------------------------------------------------------------------ pyarrow as the value oracle
+def pyarrow_value(t, v):
+    """A pyarrow python value in the form the package's host mirror returns (stored integers for DATE / DECIMAL, tuples for
+    map entries): pyarrow is the oracle of the reference's own python tests (test/python/test_integration.py:32-61)."""
+    import datetime
+    import pyarrow as pa
+    if v is None:
+        return None
+    if pa.types.is_dictionary(t):
+        return pyarrow_value(t.value_type, v)
+    if pa.types.is_date32(t):
+        return (v - datetime.date(1970, 1, 1)).days if not isinstance(v, int) else v
+    if pa.types.is_decimal(t):
+        return int(v.scaleb(t.scale).to_integral_value())
+    if pa.types.is_floating(t):
+        return "nan" if v != v else float(v)
+    if pa.types.is_map(t):
+        return [(k, pyarrow_value(t.item_type, x)) for k, x in v]
+    if pa.types.is_fixed_size_list(t) or pa.types.is_list(t) or pa.types.is_large_list(t):
+        return [pyarrow_value(t.value_type, x) for x in v]
+    if pa.types.is_struct(t):
+        return {t.field(i).name: pyarrow_value(t.field(i).type, v[t.field(i).name]) for i in range(t.num_fields)}
+    return v
+
+
+def pyarrow_columns(table):
+    """Every column of a pyarrow table as canonical values (canon_python form)."""
+    return [canon_python([pyarrow_value(f.type, v) for v in table.column(i).to_pylist()]) for i, f in enumerate(table.schema)]
+
+
+# ------------------------------------------------------------------------------------------ raw (-1) compressed buffers
+def rewrite_buffers_raw(stream_bytes, pick):
+    """A compressed IPC stream with some of its buffers stored RAW: length prefix -1 followed by the uncompressed bytes, what
+    Arrow C++ (IpcWriteOptions::min_space_savings), arrow-rs and Arrow Java write for incompressible buffers.  pyarrow's
+    Python writer never emits them, so the stream is rewritten here: bodies re-laid out, RecordBatch.buffers and
+    Message.bodyLength patched in place in the flatbuffer (same metadata size).  pick(batch_index, buffer_index, length)
+    chooses the buffers.  Returns the new stream as bytes."""
+    import struct
+    import pyarrow as pa
+    a = np.frombuffer(stream_bytes, dtype=np.uint8)
+    out = bytearray()
+    at = 0
+    bi = 0
+    for m in po.walk_stream(a):
+        out += a[at: m["prefix_off"]].tobytes()
+        head = bytearray(a[m["prefix_off"]: m["body_off"]].tobytes())
+        body = a[m["body_off"]: m["body_off"] + m["body_len"]].tobytes()
+        at = m["body_off"] + m["body_len"]
+        if m["type"] != po.MSG_RECORD_BATCH or m["body_len"] == 0:
+            out += head + body
+            continue
+        rb = po.decode_record_batch(a[m["meta_off"]: m["meta_off"] + m["meta_len"]])
+        assert rb["compression"] in (0, 1)
+        codec = pa.Codec("lz4" if rb["compression"] == 0 else "zstd")
+        new_body, new_bufs = bytearray(), []
+        for k, (off, ln) in enumerate(rb["buffers"]):
+            piece = body[off: off + ln]
+            if ln > 8 and pick(bi, k, ln):
+                (ulen,) = struct.unpack("<q", piece[:8])
+                if ulen != -1:
+                    piece = struct.pack("<q", -1) + codec.decompress(piece[8:], decompressed_size=ulen).to_pybytes()
+            new_bufs.append((len(new_body), len(piece)))
+            new_body += piece + b"\0" * ((-len(piece)) % 8)
+        old_vec = b"".join(struct.pack("<qq", o, l) for o, l in rb["buffers"])
+        new_vec = b"".join(struct.pack("<qq", o, l) for o, l in new_bufs)
+        where = bytes(head).find(old_vec)
+        assert where >= 0 and bytes(head).find(old_vec, where + 1) < 0, "RecordBatch.buffers not found exactly once"
+        head[where: where + len(old_vec)] = new_vec
+        old_len = struct.pack("<q", m["body_len"])
+        hits = [i for i in range(0, len(head) - 7) if bytes(head[i: i + 8]) == old_len and not (where <= i < where + len(old_vec))]
+        assert len(hits) == 1, "Message.bodyLength not found exactly once"
+        head[hits[0]: hits[0] + 8] = struct.pack("<q", len(new_body))
+        out += head + new_body
+        bi += 1
+    out += a[at:].tobytes()
+    return bytes(out)

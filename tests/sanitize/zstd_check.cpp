@@ -192,8 +192,36 @@ static bool DecodeFrame(const std::vector<uint8_t>& frame, size_t expect_size, s
   return true;
 }
 
+// A damaged frame: offset code 31 (RLE offset table) with all extra bits set gives an offset value of 2^32 - 1; minus 3 it has
+// bit 31 set, which the emitted word reserves for "repeat offset".  libzstd reports corruption_detected; so must this decoder.
+static bool OffsetCode31IsRejected() {
+  const uint8_t section[] = {0x54, 0, 31, 0, 0xFF, 0xFF, 0xFF, 0xFF};   // modes: LL / OF / ML all RLE; symbols; one sequence's bits
+  zstd::FseCell tll[1 << 9], tof[1 << 8], tml[1 << 9];
+  int16_t counts[64];
+  uint16_t next[64];
+  zstd::FseCell* tab[3] = {tll, tof, tml};
+  uint32_t al[3];
+  for (int t = 0; t < 3; t++) {
+    al[t] = zstd::BuildSequenceTable(section, sizeof(section), t, tab[t], counts, next);
+    if (al[t] != 0) return false;
+  }
+  const uint32_t bo = zstd::SequenceBitstreamOffset(section, sizeof(section), counts);
+  if (bo != 4) return false;
+  uint32_t seq_window[16];
+  zstd::BackBits<const uint8_t*, zstd::WindowWords<const uint8_t*, uint32_t*, 16>> sbr;
+  sbr.src.win = seq_window;
+  bool emitted = false;
+  const bool ok = zstd::DecodeSequences(sbr, section + bo, static_cast<uint32_t>(sizeof(section)) - bo, 1, tll, al[0], tof, al[1], tml, al[2],
+                                        [&](uint32_t, uint32_t, uint32_t, uint32_t) { emitted = true; return true; });
+  return !ok && !emitted;
+}
+
 int main(int argc, char** argv) {
   int bad = 0, n = 0;
+  if (!OffsetCode31IsRejected()) {
+    std::printf("FAIL offset code 31 was decoded as a repeat offset\n");
+    bad++;
+  }
   for (int i = 1; i + 1 < argc; i += 2) {
     const std::vector<uint8_t> frame = Slurp(argv[i]), expect = Slurp(argv[i + 1]);
     std::vector<uint8_t> got;

@@ -13,7 +13,7 @@ import pyarrow.ipc as ipc
 import pytest
 
 import duckdb_arrow_amd as da
-from helpers import canon_python
+from helpers import canon_python, pyarrow_columns, rewrite_buffers_raw
 from test_gpu_scan_operator import _mirror_device_vector
 
 pytestmark = pytest.mark.gpu
@@ -72,6 +72,7 @@ def test_lz4_bodies_decompressed_in_hbm_equal_the_host_decompressor(con, tmp_pat
     want = [canon_python(c) for c in con.read_arrow(path, accept_dictionaries=True, host_decompress=True).fetch_columns()]   # liblz4 on host threads
     got, st = _device_scan(con, path)
     assert got == want
+    assert got == pyarrow_columns(table)      # and both equal pyarrow's reading of the table that was written
     # a host consumer can take the K8 path too (host_decompress = -1): vectors and the string payloads (a pinned mirror of the
     # body) come back; by default its bodies are decompressed by the reader's host threads
     assert con.read_arrow(path, accept_dictionaries=True).count(detail=True)["rows"] == table.num_rows
@@ -88,6 +89,31 @@ def test_lz4_bodies_decompressed_in_hbm_equal_the_host_decompressor(con, tmp_pat
     assert got_host == want and st_host["lz4_batches_on_device"] == 0
 
 
+@pytest.mark.parametrize("codec", ["lz4", "zstd"])
+def test_raw_buffers_inside_compressed_bodies(con, tmp_path, codec):
+    """Buffers stored raw inside a compressed body (length prefix -1; Arrow C++ with min_space_savings, arrow-rs and Arrow
+    Java write them for incompressible data, nanoarrow copies them so the reference reads such files): on the K8 path they
+    are copied into place beside the buffers the kernels expand.  Every second buffer raw; all buffers raw; none."""
+    name, table, chunk = next(t for t in _tables() if t[0] == "mixed")
+    table = table.slice(0, 150000)
+    sink = pa.BufferOutputStream()
+    with ipc.new_stream(sink, table.schema, options=ipc.IpcWriteOptions(compression=codec)) as w:
+        w.write_table(table, max_chunksize=60000)
+    packed = sink.getvalue().to_pybytes()
+    want = pyarrow_columns(table)
+    gpu = {} if codec == "lz4" else {"host_decompress": "gpu"}
+    for tag, pick in (("alternate", lambda bi, k, ln: k % 2 == 1), ("all", lambda bi, k, ln: True), ("first_batch", lambda bi, k, ln: bi == 0)):
+        path = str(tmp_path / ("raw_%s_%s.arrows" % (codec, tag)))
+        raw = rewrite_buffers_raw(packed, pick)
+        assert ipc.open_stream(pa.py_buffer(raw)).read_all().equals(table)
+        open(path, "wb").write(raw)
+        got, st = _device_scan(con, path, **gpu)
+        assert got == want, tag
+        assert st["lz4_batches_on_device" if codec == "lz4" else "zstd_batches_on_device"] == 3, (tag, st)
+        assert [canon_python(c) for c in con.read_arrow(path, host_decompress=True).fetch_columns()] == want, tag
+        assert [canon_python(c) for c in con.read_arrow(path, host_decompress="gpu").fetch_columns()] == want, tag
+
+
 def test_lz4_golden_files_and_projection(con, golden_dir, tmp_path):
     for rel_path in ("lineitem_sf0_01_head.arrows", "edge_types.arrows", "edge_nested.arrows", "edge_dict.arrows"):
         t = ipc.open_stream(os.path.join(golden_dir, rel_path)).read_all()
@@ -96,6 +122,8 @@ def test_lz4_golden_files_and_projection(con, golden_dir, tmp_path):
         want = [canon_python(c) for c in con.read_arrow(path, accept_dictionaries=True, host_decompress=True).fetch_columns()]
         got, st = _device_scan(con, path)
         assert got == want, rel_path
+        if rel_path == "lineitem_sf0_01_head.arrows":
+            assert got == pyarrow_columns(t)
         assert [canon_python(c) for c in con.read_arrow(path, accept_dictionaries=True, host_decompress="gpu").fetch_columns()] == want, rel_path
         # list / map columns keep the host decompressor: the planner samples their offsets on the host
         assert (st["lz4_batches_on_device"] > 0) == (rel_path != "edge_nested.arrows"), rel_path

@@ -262,6 +262,29 @@ def test_delta_and_replacement_dictionaries(con, tmp_path):
     assert got == [(r["k"], r["v"]) for r in ipc.open_stream(p).read_all().to_pylist()]
 
 
+def test_hbm_resident_mode_refuses_a_dictionary_replaced_in_mid_stream(con):
+    """mi_hbm_open keeps ONE dictionary per id for the whole resident stream; a replacement after a record batch has used the
+    id would re-interpret the earlier batches' indices, so it is refused (the scan operator versions dictionaries instead:
+    test_delta_and_replacement_dictionaries).  A stream whose dictionaries do not change is accepted."""
+    from duckdb_arrow_amd.hbm import HbmStream
+    sch = pa.schema([("k", pa.dictionary(pa.int8(), pa.string()))])
+
+    def stream(dicts):
+        sink = pa.BufferOutputStream()
+        with ipc.new_stream(sink, sch) as w:
+            for d in dicts:
+                w.write_batch(pa.record_batch([pa.DictionaryArray.from_arrays(pa.array([0, 1, 0], pa.int8()), pa.array(d))], schema=sch))
+        return np.frombuffer(sink.getvalue().to_pybytes(), np.uint8)
+
+    with pytest.raises(da.MiError, match="replaced in mid-stream") as e:
+        HbmStream(con.ctx, stream([["a", "b"], ["x", "y"]]), accept_dictionaries=True)
+    assert e.value.code == _ffi.MI_ENOTSUP
+    hs = HbmStream(con.ctx, stream([["a", "b"], ["a", "b"]]), accept_dictionaries=True)   # pyarrow re-sends nothing: one DictionaryBatch
+    hs.launch()
+    assert hs.status() == 0
+    hs.close()
+
+
 def test_device_resident_chunks(con, golden_dir):
     """device_resident = 1: vectors stay in HBM for a GPU consumer (no D2H); pointers are device addresses."""
     import torch

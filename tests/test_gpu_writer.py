@@ -611,6 +611,32 @@ def test_parallel_copy_pump_writes_the_one_thread_file(con, tmp_path, monkeypatc
         assert sum(sizes) == n and all(x >= rgs for x in sizes[:-1]) and all(x < rgs + 2048 for x in sizes)
 
 
+@pytest.mark.timeout(180, method="thread")   # a hang inside the C call must end the process, not the box's time limit
+def test_copy_pump_row_group_spans_more_batches_than_slots(con, tmp_path, monkeypatch):
+    """One row group made of far more record batches than the scan has pipeline slots (pyarrow max_chunksize=1000 against
+    row_group_size 40960 = 41 batches per group, 6 sink threads -> 10 slots): the pump stages the rows of the unfinished row
+    group itself and gives the slots back instead of waiting for a release that cannot come.  Same file as the one-thread sink."""
+    rng = np.random.default_rng(5)
+    n = 130000
+    t = pa.table({"k": pa.array(np.arange(n, dtype=np.int64)),
+                  "s": pa.array(["row %d %s" % (i, "z" * int(k)) for i, k in enumerate(rng.integers(0, 30, n))], mask=rng.random(n) < 0.1),
+                  "d": pa.array(rng.integers(8000, 11000, n).astype(np.int32), pa.date32())})
+    src = str(tmp_path / "small_batches.arrows")
+    with ipc.new_stream(src, t.schema) as w:
+        w.write_table(t, max_chunksize=1000)
+    outs = []
+    for threads in ("1", "6", "2"):
+        monkeypatch.setenv("MI_WRITER_THREADS", threads)
+        out = str(tmp_path / ("out_%s.arrows" % threads))
+        con.copy_to(con.read_arrow(src), out, row_group_size=40960)
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1] == outs[2]
+    got = ipc.open_stream(pa.BufferReader(outs[1]))
+    sizes = [b.num_rows for b in got]
+    assert sum(sizes) == n and all(x >= 40960 for x in sizes[:-1])
+    assert ipc.open_stream(pa.BufferReader(outs[1])).read_all().equals(t)
+
+
 def test_local_sink_states_from_several_threads(con, tmp_path):
     """mi_writer_local_*: every thread buffers, encodes and writes its own row groups (ArrowWriteSink with per-thread local
     state, write_arrow_stream.cpp:141-159); row groups land in completion order, every row exactly once."""

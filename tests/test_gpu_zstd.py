@@ -13,7 +13,7 @@ import pyarrow.ipc as ipc
 import pytest
 
 import duckdb_arrow_amd as da
-from helpers import canon_python
+from helpers import canon_python, pyarrow_columns
 from test_gpu_lz4 import _device_scan, _frames, _tables
 
 pytestmark = pytest.mark.gpu
@@ -40,6 +40,7 @@ def test_zstd_bodies_decompressed_in_hbm_equal_the_host_decompressor(con, tmp_pa
     want = [canon_python(c) for c in con.read_arrow(path, accept_dictionaries=True, host_decompress=True).fetch_columns()]   # libzstd on host threads
     got, st = _device_scan(con, path, host_decompress="gpu")      # ZSTD in HBM is on request (auto keeps the host threads)
     assert got == want
+    assert got == pyarrow_columns(table)      # and both equal pyarrow's reading of the table that was written
     nonempty = sum(1 for b in ipc.open_stream(path) if b.num_rows > 0)
     assert st["zstd_batches_on_device"] >= nonempty and st["lz4_batches_on_device"] == 0, st
     if nonempty:
@@ -60,6 +61,8 @@ def test_zstd_golden_files_projection_and_fused_consumers(con, golden_dir, tmp_p
             want = [canon_python(c) for c in con.read_arrow(path, accept_dictionaries=True, host_decompress=True).fetch_columns()]
             got, st = _device_scan(con, path, host_decompress="gpu")
             assert got == want, (rel_path, level)
+            if rel_path == "lineitem_sf0_01_head.arrows":
+                assert got == pyarrow_columns(t)
             assert (st["zstd_batches_on_device"] > 0) == (rel_path != "edge_nested.arrows"), rel_path   # list offsets are sampled on the host
     t = ipc.open_stream(os.path.join(golden_dir, "lineitem_sf0_01_q6.arrows")).read_all()
     path = str(tmp_path / "q6_zstd.arrows")

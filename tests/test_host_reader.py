@@ -270,6 +270,31 @@ def test_lz4_frame_bodies_are_decompressed():
     assert e.value.code == _ffi.MI_EIO
 
 
+@pytest.mark.parametrize("codec", ["lz4", "zstd"])
+def test_raw_buffers_with_length_prefix_minus_one(codec):
+    """A compressed body may store single buffers raw (length prefix -1: Arrow C++ with min_space_savings, arrow-rs, Arrow
+    Java); nanoarrow copies them, so the reference reads such files (base_stream_reader.cpp:11-32 sees only real frames).
+    pyarrow's writer never emits them: helpers.rewrite_buffers_raw makes the stream, pyarrow reads it back as the table."""
+    from helpers import rewrite_buffers_raw
+    rng = np.random.default_rng(4)
+    t = pa.table({"a": rng.integers(0, 1 << 60, 30000), "s": ["row %d" % (i % 97) for i in range(30000)],
+                  "n": pa.array([None if i % 5 == 0 else float(i) for i in range(30000)])})
+    plain = _stream(t)
+    packed = rewrite_buffers_raw(_stream(t, compression=codec), lambda bi, k, ln: k % 3 != 2)
+    assert ipc.open_stream(pa.py_buffer(packed)).read_all().equals(t)
+    ra, rb = da.Reader(buffers=[plain]), da.Reader(buffers=[packed])
+    n = 0
+    while True:
+        x, y = ra.next_batch(), rb.next_batch()
+        assert (x is None) == (y is None)
+        if x is None:
+            break
+        n += x["length"]
+        for (xo, xl), (yo, yl) in zip(x["buffers"], y["buffers"]):
+            assert xl == yl and (x["body"][xo: xo + xl] == y["body"][yo: yo + yl]).all()
+    assert n == 30000
+
+
 def test_corrupt_zstd_frame_is_an_io_error():
     t = pa.table({"a": list(range(5000))})
     buf = bytearray(_stream(t, compression="zstd"))
