@@ -12,6 +12,10 @@ barrier and the max-over-ranks reduction.
   N > 1   one process per GPU (torch.distributed / RCCL only for the barrier and the max-over-ranks reduction):
           record batches shard embarrassingly, so every rank scans its own SF10-sized shard of an SF(10*N) table
           (weak scaling, no data-path collective); value = rows of all ranks / max-over-ranks time.
+          Launch contract: under a launcher (torch.distributed.run sets WORLD_SIZE / RANK / LOCAL_RANK / MASTER_*) the process
+          is one rank.  WITHOUT one, `python bench.py --gpus N` starts the N ranks itself: the parent -- which never touches
+          the GPU and never imports torch -- spawns N fresh child processes with those variables set, relays rank 0's JSON
+          line and exits non-zero if any child does.  `n_gpus` is the number of ranks that ran.
 
 Besides the contract's fields the JSON line carries
   roofline           HBM roofline of the dominant kernel, from HIP-event timings taken live (mi_hbm_launch_timed)
@@ -25,6 +29,9 @@ Besides the contract's fields the JSON line carries
                      single-file scan) timed on a bounded sample of the same stream, rank 0 / N=1 only
   cpu_baseline_encode  the same for the COPY TO direction (K7), beside BASELINE config 4's kernel numbers
   parity             sampled record batches of the measured run compared bit for bit with the oracle
+  sf100              secondary, N = 1 only: the configuration north_star states its target on (TPC-H SF100, one GPU), run in a
+                     child process after the SF10 legs when HBM and host memory allow
+  north_star_read_roofline   the north star's own yardstick (bytes READ per second / 8 TB/s, target 0.6) and why it is not met
 """
 import argparse
 import json
@@ -54,14 +61,26 @@ def kernel_table(cstats, per_class, pmc, same_workload):
     return kernels
 
 
-def roofline_of(kernels, alg_bytes, ms_per_step):
+def roofline_of(kernels, alg_bytes, ms_per_step, traffic_stale=False):
     dom = max(kernels, key=lambda k: k["ms"])
     return {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": dom["frac_of_8TBps"], "traffic": dom["traffic"],
+            "traffic_stale": bool(traffic_stale) if dom["traffic"] else None,   # the kernel sources changed after the PMC passes
             "traffic_source": "profiles/pmc_traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
                               "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch)" if dom["traffic"] else None,
             "algorithmic_bytes": dom["algorithmic_bytes"],
             "whole_step_frac": alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+
+def read_roofline(rows_per_s_per_gpu, read_bytes_per_row, written_bytes_per_row):
+    """north_star's yardstick: Arrow bytes READ per second against the 8 TB/s peak, target 0.6."""
+    frac = rows_per_s_per_gpu * read_bytes_per_row / 1e9 / HBM_PEAK_GBS
+    need = 0.6 * HBM_PEAK_GBS * (read_bytes_per_row + written_bytes_per_row) / read_bytes_per_row
+    return {"frac": frac, "target": 0.6, "met": bool(frac >= 0.6), "read_GBps": rows_per_s_per_gpu * read_bytes_per_row / 1e9,
+            "why": None if frac >= 0.6 else
+            "every row read (%.1f B) is also written as DuckDB vectors (%.1f B): 60 %% of the READ roofline would need %.0f GB/s of total "
+            "HBM traffic, %.2fx the chip's %.0f GB/s peak; the whole step runs at `roofline.whole_step_frac` of that peak"
+            % (read_bytes_per_row, written_bytes_per_row, need, need / HBM_PEAK_GBS, HBM_PEAK_GBS)}
 
 
 def cpu_multifile_baseline(paths):
@@ -89,6 +108,73 @@ def cpu_multifile_baseline(paths):
             "sample": "the whole table: %d files, one oracle_scan.c scan per thread" % len(bufs), "host_cpus": os.cpu_count()}
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: N fresh child processes, one rank each.  The parent makes no GPU call
+    (it does not even import torch); rank 0's stdout is the result line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    run_id = "%d_%d" % (os.getpid(), port)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), MI_BENCH_RUN_ID=run_id, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode]
+    for p in procs[1:]:
+        try:
+            codes.append(p.wait(timeout=120 if codes[0] == 0 else 5))
+        except subprocess.TimeoutExpired:   # a rank that outlives rank 0: end exactly that process
+            p.kill()
+            codes.append(p.wait())
+    line = [ln for ln in (out0 or "").strip().split("\n") if ln.startswith("{")]
+    if line:
+        print(line[-1])
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad or not line:
+        print("bench.py: ranks failed (rank, exit code): %s%s" % (bad, "" if line else "; rank 0 printed no result line"), file=sys.stderr)
+        sys.exit(1)
+    sys.exit(0)
+
+
+def run_sf100_child(args, torch):
+    """The configuration north_star states its target on -- TPC-H SF100 lineitem on ONE GPU (105 GB of Arrow buffers + 95 GB
+    of vectors resident in the 288 GB of HBM) -- as a child process of its own after the SF10 legs: fresh HBM, and the
+    105 GB host copy of the stream goes away with it."""
+    import subprocess
+    free_hbm, _ = torch.cuda.mem_get_info()
+    avail_host = 0
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                avail_host = int(ln.split()[1]) * 1024
+    except OSError:
+        pass
+    if free_hbm < 210e9 or avail_host < 150e9:
+        return {"skipped": "needs 210 GB of free HBM and 150 GB of host memory; free: %.0f GB HBM, %.0f GB host" % (free_hbm / 1e9, avail_host / 1e9)}
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--sf", "100", "--steps", "5", "--warmup", "2", "--no-operator-path",
+           "--no-cpu-baseline", "--no-encode-leg", "--no-sf100", "--seed", str(args.seed)]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    try:
+        run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+    except subprocess.TimeoutExpired:
+        return {"error": "timed out after 420 s"}
+    line = [ln for ln in run.stdout.strip().split("\n") if ln.startswith("{")]
+    if run.returncode != 0 or not line:
+        return {"error": (run.stderr or "")[-300:]}
+    z = json.loads(line[-1])
+    rs = z.get("reference_shaped") or {}
+    return {"workload": z["config"]["workload"], "steps": z["steps"], "warmup": z["warmup"],
+            "ms_per_step": z["ms_per_step"], "rows_per_s": z["value"], "achieved_hbm_GBps_whole_step": z["achieved_hbm_GBps_whole_step"],
+            "roofline": z["roofline"], "read_roofline_frac": z["north_star_read_roofline"]["frac"], "parity": z["parity"],
+            "reference_shaped": {k: rs.get(k) for k in ("ms_per_step", "rows_per_s", "achieved_GBps", "roofline", "read_roofline_frac")},
+            "setup_seconds": z["setup_seconds"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,7 +193,11 @@ def main():
                                                       "multi-process path with all ranks on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--shm-dir", default="/dev/shm", help="where the operator-path legs put their files")
+    ap.add_argument("--no-sf100", action="store_true", help="skip the SF100 block (N = 1; a child process after the SF10 legs)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus, sys.argv[1:])   # never returns; nothing above has touched the GPU or imported torch
 
     import torch
     import torch.distributed as dist
@@ -127,9 +217,9 @@ def main():
             dist.init_process_group(args.backend)
     else:
         torch.cuda.set_device(local_rank)
-    n_gpus = world
+    n_gpus = world   # the ranks that run
     if args.gpus != world and rank == 0:
-        print("note: --gpus %d but WORLD_SIZE=%d; using the launcher's world size" % (args.gpus, world), file=sys.stderr)
+        print("note: --gpus %d but the launcher started WORLD_SIZE=%d ranks; n_gpus = %d" % (args.gpus, world, world), file=sys.stderr)
 
     import duckdb_arrow_amd as da
     from duckdb_arrow_amd.hbm import HbmStream
@@ -204,7 +294,11 @@ def main():
 
     per_class = per_class_ms(hs)
     traffic_src = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
-    pmc = json.load(open(traffic_src)).get("traffic_bytes_per_launch", {}) if os.path.exists(traffic_src) else {}
+    pmc_doc = json.load(open(traffic_src)) if os.path.exists(traffic_src) else {}
+    pmc = pmc_doc.get("traffic_bytes_per_launch", {})
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_sha import kernel_source_sha
+    traffic_stale = bool(pmc) and pmc_doc.get("kernel_source_sha") != kernel_source_sha()
     same_workload = args.sf == 10.0 and not args.rows and not args.no_validity
 
     # ---- secondary, never `value`: the reference-shaped layout over the same resident stream -- plain fixed-width columns
@@ -221,6 +315,7 @@ def main():
         ref_shaped = {"ms_per_step": dz / args.steps * 1e3, "rows_per_s": info["n_rows"] * args.steps / dz,
                       "algorithmic_bytes_per_row": {"read": zst["bytes_read"] / info["n_rows"], "written": zst["bytes_written"] / info["n_rows"]},
                       "achieved_GBps": z_alg * args.steps / dz / 1e9,
+                      "read_roofline_frac": info["n_rows"] * args.steps / dz * (stats["bytes_read"] / info["n_rows"]) / 1e9 / HBM_PEAK_GBS,
                       "roofline": roofline_of(zk, z_alg, dz / args.steps * 1e3), "kernels": zk,
                       "tasks": zs.n_tasks, "of_tasks": hs.n_tasks, "aliased_columns": aliased, "columns_without_validity_words": unmasked,
                       "note": "secondary figure, not `value`: mi_hbm_options.zero_copy_direct + unset_all_valid = the shape of the "
@@ -228,23 +323,28 @@ def main():
                               "NULLs leaves the ValidityMask unset); what a device-resident consumer gets by default"}
         zs.close()
 
-    # ---- parity of the measured run: sampled batches vs the oracle (rank 0) ----
+    # ---- parity of the measured run: sampled batches of EVERY rank's shard vs the oracle ----
     parity = cpu_baseline = cpu_baseline_encode = None
+    from oracle import pyoracle as po
+    msgs = [m for m in po.walk_stream(buf) if m["type"] == po.MSG_RECORD_BATCH]
+    sample = sorted(set([0, len(msgs) // 2, len(msgs) - 1]))
+    got = hs.fetch(batches=sample)
+    ok = True
+    for bi in sample:
+        m = msgs[bi]
+        sub = np.concatenate([buf[: msgs[0]["prefix_off"]], buf[m["prefix_off"]: m["body_off"] + m["body_len"]]])
+        shift = m["prefix_off"] - msgs[0]["prefix_off"]
+        _, want = po.decode_stream(sub, ptr_base_of=lambda i, body_off, boff: body_off + boff + shift)
+        for gc, wc in zip(got[bi]["columns"], want[0]["columns"]):
+            ok = ok and np.array_equal(gc["data"], wc["data"]) and np.array_equal(gc["validity"], wc["validity"])
+    del got
+    ranks_ok = 1 if ok else 0
+    if world > 1:
+        t = torch.tensor([ranks_ok], dtype=torch.int64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t)
+        ranks_ok = int(t.item())
+    parity = {"checked_batches": sample, "bit_exact": bool(ranks_ok == world), "ranks_bit_exact": ranks_ok, "ranks": world}
     if rank == 0:
-        from oracle import pyoracle as po
-        msgs = [m for m in po.walk_stream(buf) if m["type"] == po.MSG_RECORD_BATCH]
-        sample = sorted(set([0, len(msgs) // 2, len(msgs) - 1]))
-        got = hs.fetch(batches=sample)
-        ok = True
-        for bi in sample:
-            m = msgs[bi]
-            sub = np.concatenate([buf[: msgs[0]["prefix_off"]], buf[m["prefix_off"]: m["body_off"] + m["body_len"]]])
-            shift = m["prefix_off"] - msgs[0]["prefix_off"]
-            _, want = po.decode_stream(sub, ptr_base_of=lambda i, body_off, boff: body_off + boff + shift)
-            for gc, wc in zip(got[bi]["columns"], want[0]["columns"]):
-                ok = ok and np.array_equal(gc["data"], wc["data"]) and np.array_equal(gc["validity"], wc["validity"])
-        parity = {"checked_batches": sample, "bit_exact": bool(ok)}
-        del got
         if not args.no_cpu_baseline and world == 1:
             # bounded sample: time 2 batches, then as many as fit the budget
             rc, st = po.scan_stream(buf, max_batches=2)
@@ -297,7 +397,9 @@ def main():
     # ---- secondary, never `value`: the scan OPERATOR over files (BASELINE config 3) ----
     operator_path = None
     if not args.no_operator_path:
-        d = os.path.join(args.shm_dir, "mi_bench_%d" % (os.getppid() if world > 1 else os.getpid()))
+        # one directory per run, the same name on every rank: the self-launcher's run id, else the launcher's rendezvous port
+        run_id = os.environ.get("MI_BENCH_RUN_ID") or ("port%s" % os.environ.get("MASTER_PORT", "0") if world > 1 else str(os.getpid()))
+        d = os.path.join(args.shm_dir, "mi_bench_%s" % run_id)
         n_files = 8
         paths = [os.path.join(d, "lineitem_%d.arrows" % i) for i in range(n_files)]
         try:
@@ -427,7 +529,7 @@ def main():
                 except ImportError:
                     pass   # no pyarrow on this box: the leg needs it to write the compressed stream
             con.close()
-            operator_path = dict(legs, scaling="strong", files=n_files, table="TPC-H SF%g lineitem (%d rows) in %s" % (args.sf, info["n_rows"], args.shm_dir),
+            operator_path = dict(legs, scaling="strong", files=n_files, rows=legs["full_scan_host_consumer"]["rows"], table="TPC-H SF%g lineitem (%d rows) in %s" % (args.sf, info["n_rows"], args.shm_dir),
                                  rows_per_s=legs["full_scan_host_consumer"]["rows_per_s"],
                                  note="secondary figures, never `value`: PCIe / page-cache inclusive; one table shared by all ranks, every "
                                       "rank takes the record batches k with k mod world == rank (mi_scan_options.rank / world)")
@@ -440,6 +542,9 @@ def main():
                 if os.path.isdir(d):
                     os.rmdir(d)
 
+    sf100 = None
+    if rank == 0 and world == 1 and args.sf == 10.0 and not args.rows and not args.no_sf100:
+        sf100 = run_sf100_child(args, torch)
     if rank == 0:
         total_rows = info["n_rows"] * world
         ms_per_step = elapsed / args.steps * 1e3
@@ -466,7 +571,8 @@ def main():
                        "sharding": "row groups, no collective"},
             "achieved_hbm_GBps_whole_step": alg_bytes * world / (elapsed / args.steps) / 1e9,
             "algorithmic_bytes_per_row": {"read": stats["bytes_read"] / info["n_rows"], "written": stats["bytes_written"] / info["n_rows"]},
-            "roofline": roofline_of(kernels, alg_bytes, ms_per_step),
+            "roofline": roofline_of(kernels, alg_bytes, ms_per_step, traffic_stale),
+            "north_star_read_roofline": read_roofline(rows_per_s / world, stats["bytes_read"] / info["n_rows"], stats["bytes_written"] / info["n_rows"]),
             "kernels": kernels,
             "cpu_baseline": cpu_baseline,
             "cpu_baseline_encode": cpu_baseline_encode,
@@ -474,6 +580,7 @@ def main():
             "reference_shaped": ref_shaped,
             "config4_encode_kernels": encode_kernels,
             "operator_path": operator_path,
+            "sf100": sf100,
             "setup_seconds": {"generate": t_gen, "parse_upload_plan": t_upload},
         }
         print(json.dumps(out))

@@ -17,6 +17,10 @@ import json
 import os
 import re
 import shutil
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_sha import kernel_source_sha
 
 KERNELS = ("transcode_copy", "transcode_dec128", "transcode_string", "transcode_misc", "encode_fixed", "encode_string")
 
@@ -67,6 +71,7 @@ def main():
         doc = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes). " + a.note +
                        " Values are KB per dispatch; on gfx950 FETCH_SIZE counts 1/2 of wide coalesced reads "
                        "(MI355X_MICROARCH.md, HBM) so read bytes = 2*FETCH_SIZE*1024.",
+               "kernel_source_sha": kernel_source_sha(),   # bench.py: traffic_stale when the kernels have changed since
                "FETCH_SIZE": fetch, "WRITE_SIZE": write, "traffic_bytes_per_launch": traffic}
         targets = [os.path.join(a.out, "pmc_traffic.json")]
         if a.latest:   # the headline workload: bench.py picks `roofline.traffic` up from here
