@@ -537,8 +537,7 @@ class Relation:
         """mi_scan_get_stats: record batches submitted, LZ4 bodies decompressed in HBM, bytes over PCIe, bytes decompressed."""
         st = _ffi.ScanStats()
         _ffi.check(_ffi.lib().mi_scan_get_stats(self._h, C.byref(st)))
-        return {k: getattr(st, k) for k in ("record_batches", "lz4_batches_on_device", "h2d_bytes", "decompressed_bytes", "lz4_blocks",
-                                            "lz4_parse_rounds", "lz4_parse_rounds_max", "zstd_batches_on_device")}
+        return {k: getattr(st, k) for k, _ in _ffi.ScanStats._fields_}
 
     def close(self):
         if self._h:

@@ -162,7 +162,8 @@ class WriteOptions(C.Structure):
 class ScanStats(C.Structure):
     _fields_ = [("record_batches", C.c_int64), ("lz4_batches_on_device", C.c_int64), ("h2d_bytes", C.c_int64),
                 ("decompressed_bytes", C.c_int64), ("lz4_blocks", C.c_int64), ("lz4_parse_rounds", C.c_int64),
-                ("lz4_parse_rounds_max", C.c_int64), ("zstd_batches_on_device", C.c_int64)]
+                ("lz4_parse_rounds_max", C.c_int64), ("zstd_batches_on_device", C.c_int64), ("d2h_bytes", C.c_int64),
+                ("aliased_bytes", C.c_int64)]
 
 
 class SynthOptions(C.Structure):
@@ -245,6 +246,7 @@ SIGNATURES = {
     "mi_writer_row_groups": (C.c_int64, [P]),
     "mi_writer_file_size": (C.c_int64, [P]),
     "mi_writer_rotate_next_file": (C.c_int, [P, C.c_int64]),
+    "mi_writer_append_message": (C.c_int, [P, P, C.c_int64]),
     "mi_ipc_serializer_create": (C.c_int, [P, C.POINTER(Field), C.c_int32, PP]),
     "mi_ipc_serialize_schema": (C.c_int, [P, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "mi_ipc_serialize_chunks": (C.c_int, [P, C.POINTER(DataChunk), C.c_int32, C.POINTER(C.c_void_p),

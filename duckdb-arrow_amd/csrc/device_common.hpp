@@ -109,6 +109,87 @@ __device__ __forceinline__ void tile_validity(const mi_col_task& t, int64_t row0
   if (need_mask) __syncthreads();
 }
 
+// ---- the same words WITHOUT the LDS round trip (the kernels of the common kinds).  tile_validity() above makes every data
+// lane of the tile wait for bitmap load -> LDS store -> barrier before its own loads may leave: a second dependent round trip
+// per tile on every column that has NULLs.  Below, the words a wave needs are requested together with its data loads.
+//
+// (a) wave-uniform word j of the tile (rows [row0 + 64 j, row0 + 64 j + 64) = the 64 rows a wave handles in one step of a
+//     row-per-lane loop).  The Arrow bitmap is read through the constant address space with a uniform index: scalar loads
+//     into SGPRs (the body is never written during a launch), a scalar funnel shift, no VGPRs, no barrier.
+typedef const uint64_t __attribute__((address_space(4)))* kptr64;
+
+__device__ __forceinline__ uint64_t bitmap_word(const mi_col_task& t, int64_t row0, int j) {
+  kptr64 W = (kptr64)t.validity;
+  const int64_t bit = t.row_offset + row0 + 64 * static_cast<int64_t>(j);
+  const int64_t q = bit >> 6;
+  const int sh = static_cast<int>(bit & 63);
+  const int64_t last_q = (t.row_offset + t.nrows - 1) >> 6;  // last 8-byte word that holds a bit of this column
+  const uint64_t lo = W[q];
+  const uint64_t hi = (sh != 0 && q + 1 <= last_q) ? W[q + 1] : 0ull;
+  return sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+}
+
+// Word j (< ceil(n / 64), wave-uniform) of the tile's combined validity, pad bits canonical.  `lds` (non-NULL only for
+// children of fixed-size lists, whose parent rows are r / list_size: tile_validity() has built the tile's words in LDS and
+// stored them) overrides; a struct child's parent word is the same word of the parent's validity, written by an earlier
+// launch of the same plan (tasks run in depth order).
+__device__ __forceinline__ uint64_t tile_valid_word(const mi_col_task& t, int64_t row0, int n, int j, const uint64_t* lds) {
+  if (lds != nullptr) return lds[j];
+  uint64_t w = ~0ull;
+  if (t.validity != nullptr && t.null_count != 0) w = bitmap_word(t, row0, j);
+  if (t.out_aux != nullptr) w &= GC<uint64_t>(t.out_aux)[(row0 >> 6) + j];
+  const int rem = n - 64 * j;
+  if (rem < 64) w |= ~0ull << rem;
+  return w;
+}
+// the tiles that need the LDS words (uniform)
+__device__ __forceinline__ bool tile_words_from_lds(const mi_col_task& t) { return t.out_aux != nullptr && t.flags > 1; }
+
+// (b) one lane per output word (lane < ceil(n / 64)), for kernels whose data lanes do not own whole 64-row groups: the loads
+//     leave in lane_validity_begin -- before the tile's data loads -- and are only looked at in lane_validity_end, after the
+//     data has been moved.
+struct LaneValid {
+  uint64_t lo, hi, parent;
+};
+__device__ __forceinline__ LaneValid lane_validity_begin(const mi_col_task& t, int64_t row0, int n) {
+  LaneValid v{~0ull, 0ull, ~0ull};
+  const int lane = threadIdx.x;
+  if (t.out_validity == nullptr || lane >= ((n + 63) >> 6)) return v;
+  if (t.validity != nullptr && t.null_count != 0) {
+    gptr<const uint64_t> W = GC<uint64_t>(t.validity);
+    const int64_t bit = t.row_offset + row0 + 64 * lane;
+    const int64_t q = bit >> 6;
+    const int64_t last_q = (t.row_offset + t.nrows - 1) >> 6;
+    v.lo = W[q];
+    v.hi = ((bit & 63) != 0 && q + 1 <= last_q) ? W[q + 1] : 0ull;
+  }
+  if (t.out_aux != nullptr && t.flags <= 1) v.parent = GC<uint64_t>(t.out_aux)[(row0 >> 6) + lane];
+  return v;
+}
+__device__ __forceinline__ void lane_validity_end(const mi_col_task& t, int64_t row0, int n, const LaneValid& v) {
+  const int lane = threadIdx.x;
+  if (t.out_validity == nullptr || lane >= ((n + 63) >> 6)) return;
+  uint64_t w = ~0ull;
+  if (t.validity != nullptr && t.null_count != 0) {
+    const int sh = static_cast<int>((t.row_offset + row0 + 64 * lane) & 63);
+    w = sh ? ((v.lo >> sh) | (v.hi << (64 - sh))) : v.lo;
+  }
+  w &= v.parent;
+  if (t.out_aux != nullptr && t.flags > 1) {
+    gptr<const uint64_t> P = GC<uint64_t>(t.out_aux);
+    const int64_t r = row0 + 64 * lane, div = t.flags;
+    uint64_t pw = 0;
+    for (int i = 0; i < 64; i++) {
+      const int64_t pr = (r + i) / div;
+      pw |= ((P[pr >> 6] >> (pr & 63)) & 1ull) << i;
+    }
+    w &= pw;
+  }
+  const int rem = n - 64 * lane;
+  if (rem < 64) w |= ~0ull << rem;  // canonical pad bits
+  GM<uint64_t>(t.out_validity)[(row0 >> 6) + lane] = w;
+}
+
 // Row validity for the data lanes: the combined tile mask in LDS (null_count == 0 and no parent => every row valid,
 // the bitmap is not even read: GetValidityMask).
 __device__ __forceinline__ bool row_valid(const uint64_t* s_valid, bool need_mask, int r) {

@@ -288,6 +288,8 @@ void Plan::Set(const mi_col_task* in_tasks, int32_t n_tasks, hipStream_t upload_
         if (tiles > 0xFFFFFFF0ull) throw InvalidInputException("plan has too many tiles");
         tile_task.insert(tile_task.end(), static_cast<size_t>(nt), local_task);
         if (c == device::kClassMisc) sl.misc_groups |= 1u << device::MiscGroupOfKind(t.kind);
+        if (c == device::kClassDec128 || c == device::kClassString)   // which of the two kernel instances has tiles (device: tile_needs_mask)
+          sl.misc_groups |= ((t.validity != nullptr && t.null_count != 0) || t.out_aux != nullptr) ? 2u : 1u;
         if (c == device::kClassEncString && t.kind == MI_K_ENC_LIST32) sl.misc_groups |= 2u;
         order[i] = {static_cast<int>(slices.size()), static_cast<int32_t>(local_task)};
         local_task++;

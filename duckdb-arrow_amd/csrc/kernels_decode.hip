@@ -23,49 +23,94 @@ __global__ __launch_bounds__(kBlockThreads) void transcode_copy(const mi_col_tas
                                                                 uint32_t total_tiles, uint32_t* __restrict__ status) {
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     MI_TILE_PROLOGUE_ROWS(kCopyTileRows);
-    tile_validity(t, row0, n);
+    static_assert(kCopyTileRows / 64 <= kBlockThreads, "one lane per validity word");
+    // the lanes that own a validity word ask for it, move their share of the data, and only then shift / pad / store the
+    // word: one round trip instead of two (NULL rows keep their source bytes: DirectConversion)
+    const LaneValid tv = lane_validity_begin(t, row0, n);
     const int w = static_cast<int>(t.param);
     copy_bytes(GC<uint8_t>(t.buf1) + (t.row_offset + row0) * w, GM<uint8_t>(t.out_data) + row0 * w, n * w);
+    lane_validity_end(t, row0, n, tv);
   }
 }
 
 // ---------------------------------------------------------------------------------------------------- K3b
 // decimal128 {u64 lower, i64 upper} -> int16/32/64 for valid rows (Hugeint::TryCast: value fits by precision);
 // NULL rows canonical 0.  Each lane reads the whole 16-byte value (the upper half is what proves the range).
-template <typename OUT>
-__device__ __forceinline__ void tile_dec128(const mi_col_task& t, int64_t row0, int n, uint32_t* status, const uint64_t* s_valid) {
+template <typename OUT, bool NULLS>
+__device__ __forceinline__ void tile_dec128(const mi_col_task& t, int64_t row0, int n, uint32_t* status, const uint64_t* lds) {
+  constexpr int R = kDecTileRows / kBlockThreads, G = 4;   // rows per lane; loads in flight per lane
+  static_assert(R % G == 0, "whole groups");
   gptr<const uint8_t> src = GC<uint8_t>(t.buf1) + (t.row_offset + row0) * 16;
   gptr<OUT> out = GM<OUT>(t.out_data) + row0;
-  const bool has_nulls = tile_needs_mask(t);
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int nwords = (n + 63) >> 6;
   uint32_t err = 0;
-#pragma unroll 4
-  for (int r = threadIdx.x; r < n; r += kBlockThreads) {
-    const u32x4 v = ld16((gptr<const u32x4_a4>)(src + 16 * static_cast<int64_t>(r)));  // 8-byte aligned source: unaligned-access mode
-    const uint64_t lower = static_cast<uint64_t>(v.x) | (static_cast<uint64_t>(v.y) << 32);
-    const int64_t upper = static_cast<int64_t>(static_cast<uint64_t>(v.z) | (static_cast<uint64_t>(v.w) << 32));
-    OUT o = 0;
-    if (row_valid(s_valid, has_nulls, r)) {
-      o = static_cast<OUT>(lower);
-      const int64_t sext = static_cast<int64_t>(o);
-      if (static_cast<uint64_t>(sext) != lower || upper != (sext >> 63)) err = MI_ST_DECIMAL_RANGE;
+#pragma clang loop unroll(disable)
+  for (int k0 = 0; k0 < R; k0 += G) {
+    if (k0 * kBlockThreads >= n) break;  // uniform
+    // the wave's rows of step k are rows [64 j, 64 j + 64) of the tile, j = wave + 4 k: their validity word is wave-uniform and
+    // is requested (scalar loads) together with the data, not in a round trip of its own in front of it
+    u32x4 v[G];
+#pragma unroll
+    for (int k = 0; k < G; k++) {
+      const int r = threadIdx.x + (k0 + k) * kBlockThreads;
+      v[k] = u32x4{0u, 0u, 0u, 0u};
+      if (r < n) v[k] = ld16((gptr<const u32x4_a4>)(src + 16 * static_cast<int64_t>(r)));  // 8-byte aligned source: unaligned-access mode
     }
-    __builtin_nontemporal_store(o, out + r);
+    uint32_t okbits = ~0u;   // bit k: this lane's row of step k0 + k is valid (the words leave for the vector as soon as they are in)
+    if (NULLS) {
+#pragma clang loop unroll(disable)   // one word's SGPRs at a time: the scalar loads hide behind the vector loads in flight anyway
+      for (int k = 0; k < G; k++) {
+        const int j = wave + (kBlockThreads / 64) * (k0 + k);
+        if (j < nwords) {  // uniform
+          const uint64_t w = tile_valid_word(t, row0, n, j, lds);
+          if (!((w >> lane) & 1ull)) okbits &= ~(1u << k);
+          if (lane == 0 && t.out_validity != nullptr && lds == nullptr) GM<uint64_t>(t.out_validity)[(row0 >> 6) + j] = w;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < G; k++) {
+      const int r = threadIdx.x + (k0 + k) * kBlockThreads;
+      if (r < n) {
+        const uint64_t lower = static_cast<uint64_t>(v[k].x) | (static_cast<uint64_t>(v[k].y) << 32);
+        const int64_t upper = static_cast<int64_t>(static_cast<uint64_t>(v[k].z) | (static_cast<uint64_t>(v[k].w) << 32));
+        OUT o = 0;
+        if (!NULLS || ((okbits >> k) & 1u)) {
+          o = static_cast<OUT>(lower);
+          const int64_t sext = static_cast<int64_t>(o);
+          if (static_cast<uint64_t>(sext) != lower || upper != (sext >> 63)) err = MI_ST_DECIMAL_RANGE;
+        }
+        __builtin_nontemporal_store(o, out + r);
+      }
+    }
   }
+  // a column without NULLs: every word is all ones (pad bits included), one coalesced store behind the data
+  if (!NULLS && t.out_validity != nullptr && static_cast<int>(threadIdx.x) < nwords) GM<uint64_t>(t.out_validity)[(row0 >> 6) + threadIdx.x] = ~0ull;
   raise(status, err);
 }
 
-__global__ __launch_bounds__(kBlockThreads) void transcode_dec128(const mi_col_task* __restrict__ tasks,
+// Two instances (see transcode_string): NULLS = false for the tiles of columns without NULLs, NULLS = true for the others.
+// (amdgpu_num_sgpr(96): the scalar validity words would otherwise push the kernel over the 96 SGPRs that 8 waves per SIMD
+// allow; the few values that do not fit live in VGPR lanes, of which there are plenty)
+template <bool NULLS>
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(96))) void transcode_dec128(const mi_col_task* __restrict__ tasks,
                                                                   const uint32_t* __restrict__ tile_begin,
                                                                   const uint32_t* __restrict__ tile_task, int n_tasks,
                                                                   uint32_t total_tiles, uint32_t* __restrict__ status) {
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     MI_TILE_PROLOGUE_ROWS(kDecTileRows);
+    if (tile_needs_mask(t) != NULLS) continue;  // uniform: the other instance owns this tile
     __shared__ uint64_t s_valid[kDecTileRows / 64];
-    if (tile_needs_mask(t)) __syncthreads();  // the previous tile's lanes are done with the mask
-    tile_validity(t, row0, n, s_valid);
-    if (t.param == 8) tile_dec128<int64_t>(t, row0, n, status, s_valid);
-    else if (t.param == 4) tile_dec128<int32_t>(t, row0, n, status, s_valid);
-    else tile_dec128<int16_t>(t, row0, n, status, s_valid);
+    const uint64_t* lds = nullptr;
+    if (NULLS && tile_words_from_lds(t)) {  // child of a fixed-size list: the rare path keeps the LDS mask
+      __syncthreads();
+      tile_validity(t, row0, n, s_valid);
+      lds = s_valid;
+    }
+    if (t.param == 8) tile_dec128<int64_t, NULLS>(t, row0, n, status, lds);
+    else if (t.param == 4) tile_dec128<int32_t, NULLS>(t, row0, n, status, lds);
+    else tile_dec128<int16_t, NULLS>(t, row0, n, status, lds);
   }
 }
 
@@ -75,15 +120,16 @@ __global__ __launch_bounds__(kBlockThreads) void transcode_dec128(const mi_col_t
 // offset loads, then up to 8 x 4 payload dwords), so one wave has 8 rows in flight (-8 % time against 2 in flight).
 // off[r+1] comes from the neighbouring lane (one permute) except at the wave edge and at the last row.  One 16-byte
 // nontemporal store per row (1 KiB per wave store).
-template <typename OFF>
-__device__ __forceinline__ void tile_string(const mi_col_task& t, int64_t row0, int n, uint32_t* status, const uint64_t* s_valid) {
+template <typename OFF, bool NULLS>
+__device__ __forceinline__ void tile_string(const mi_col_task& t, int64_t row0, int n, uint32_t* status, const uint64_t* lds) {
   constexpr int R = kTileRows / kBlockThreads;
   gptr<const OFF> off = GC<OFF>(t.buf1) + t.row_offset + row0;
   gptr<const uint8_t> data = GC<uint8_t>(t.buf2);
   gptr<u32x4> out = GM<u32x4>(t.out_data) + row0;
-  const bool has_nulls = tile_needs_mask(t);
   const int64_t data_len = t.buf2_len;
   const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int nwords = (n + 63) >> 6;
   OFF a[R], b[R];
   // (the wave-edge loads of off[r+1] leave together with the others: asked for only once the neighbours' values are in --
   // they feed a shuffle -- they were a round trip of their own in front of the payload loads)
@@ -93,6 +139,22 @@ __device__ __forceinline__ void tile_string(const mi_col_task& t, int64_t row0, 
     const bool edge = lane == 63 || r == n - 1;
     a[k] = r < n ? off[r] : 0;
     if (sizeof(OFF) == 4) b[k] = (r < n && edge) ? off[r + 1] : 0;  // (int64 offsets: 16 more registers at this point, an occupancy step)
+  }
+  // NULLs (the kernel instance for tiles that have any).  The validity word of the wave's 64 rows of step k (rows [64 j,
+  // 64 j + 64), j = wave + 4 k) is wave-uniform: scalar loads (tile_valid_word) issued here, behind the offset loads that are
+  // already in flight -- the LDS mask they replace cost every lane of the tile a round trip (bitmap -> LDS -> barrier) in
+  // front of its first load.  One bit per row stays in a VGPR; the words leave for the vector at once.
+  uint32_t okbits = ~0u;
+  if (NULLS) {
+#pragma clang loop unroll(disable)   // one word's SGPRs at a time
+    for (int k = 0; k < R; k++) {
+      const int j = wave + (kBlockThreads / 64) * k;
+      if (j < nwords) {  // uniform
+        const uint64_t w = tile_valid_word(t, row0, n, j, lds);
+        if (!((w >> lane) & 1ull)) okbits &= ~(1u << k);
+        if (lane == 0 && t.out_validity != nullptr && lds == nullptr) GM<uint64_t>(t.out_validity)[(row0 >> 6) + j] = w;
+      }
+    }
   }
 #pragma unroll
   for (int k = 0; k < R; k++) {
@@ -118,7 +180,7 @@ __device__ __forceinline__ void tile_string(const mi_col_task& t, int64_t row0, 
         err |= MI_ST_BAD_OFFSETS;
       } else if (sizeof(OFF) == 8 && bb > 0xFFFFFFFFll) {
         err |= MI_ST_STRING_TOO_LARGE;
-      } else if (row_valid(s_valid, has_nulls, r)) {
+      } else if (!NULLS || ((okbits >> k) & 1u)) {
         s[k] = make_string_t(data, aa, static_cast<uint32_t>(bb - aa), t.ptr_base);
       }
     }
@@ -130,36 +192,56 @@ __device__ __forceinline__ void tile_string(const mi_col_task& t, int64_t row0, 
       __builtin_nontemporal_store(s[k], out + r);
     }
   }
+  // a column without NULLs: every word is all ones (pad bits included), one coalesced store behind the data
+  if (!NULLS && t.out_validity != nullptr && static_cast<int>(threadIdx.x) < nwords) GM<uint64_t>(t.out_validity)[(row0 >> 6) + threadIdx.x] = ~0ull;
   raise(status, err);
 }
 
 // fixed_size_binary(width) -> string_t
-__device__ __forceinline__ void tile_fixed_binary(const mi_col_task& t, int64_t row0, int n, const uint64_t* s_valid) {
+__device__ __forceinline__ void tile_fixed_binary(const mi_col_task& t, int64_t row0, int n, const uint64_t* lds) {
   gptr<const uint8_t> data = GC<uint8_t>(t.buf1);
   gptr<u32x4> out = GM<u32x4>(t.out_data) + row0;
-  const bool has_nulls = tile_needs_mask(t);
+  const bool need_words = tile_needs_mask(t) || t.out_validity != nullptr;   // (the rare kind: words always through the wave path)
   const int64_t width = t.param;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int nwords = (n + 63) >> 6;
 #pragma unroll 2
-  for (int r = threadIdx.x; r < n; r += kBlockThreads) {
-    u32x4 s = {0u, 0u, 0u, 0u};
-    if (row_valid(s_valid, has_nulls, r))
-      s = make_string_t(data, (t.row_offset + row0 + r) * width, static_cast<uint32_t>(width), t.ptr_base);
-    out[r] = s;
+  for (int k = 0; k < kTileRows / kBlockThreads; k++) {
+    if (k * kBlockThreads >= n) break;  // uniform
+    const int r = threadIdx.x + k * kBlockThreads;
+    const int j = wave + (kBlockThreads / 64) * k;
+    const uint64_t vw = (need_words && j < nwords) ? tile_valid_word(t, row0, n, j, lds) : ~0ull;
+    if (r < n) {
+      u32x4 s = {0u, 0u, 0u, 0u};
+      if ((vw >> lane) & 1ull) s = make_string_t(data, (t.row_offset + row0 + r) * width, static_cast<uint32_t>(width), t.ptr_base);
+      out[r] = s;
+    }
+    if (lane == 0 && j < nwords && t.out_validity != nullptr && lds == nullptr) GM<uint64_t>(t.out_validity)[(row0 >> 6) + j] = vw;
   }
 }
 
-__global__ __launch_bounds__(kBlockThreads) void transcode_string(const mi_col_task* __restrict__ tasks,
+// Two instances, each launched only when the plan has tiles for it: NULLS = false takes the tiles of columns without NULLs
+// (no bitmap is read, the validity words are all ones) and keeps the register budget of the plain loop -- the headline
+// workload runs this one alone; NULLS = true takes the tiles that need a mask.  A tile of the other instance returns at once.
+template <bool NULLS>
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(96))) void transcode_string(const mi_col_task* __restrict__ tasks,
                                                                   const uint32_t* __restrict__ tile_begin,
                                                                   const uint32_t* __restrict__ tile_task, int n_tasks,
                                                                   uint32_t total_tiles, uint32_t* __restrict__ status) {
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     MI_TILE_PROLOGUE();
+    if (tile_needs_mask(t) != NULLS) continue;  // uniform: the other instance owns this tile
     __shared__ uint64_t s_valid[kTileRows / 64];
-    if (tile_needs_mask(t)) __syncthreads();
-    tile_validity(t, row0, n, s_valid);
-    if (t.kind == MI_K_STR32) tile_string<int32_t>(t, row0, n, status, s_valid);
-    else if (t.kind == MI_K_STR64) tile_string<int64_t>(t, row0, n, status, s_valid);
-    else tile_fixed_binary(t, row0, n, s_valid);
+    const uint64_t* lds = nullptr;
+    if (NULLS && tile_words_from_lds(t)) {  // child of a fixed-size list: the rare path keeps the LDS mask
+      __syncthreads();
+      tile_validity(t, row0, n, s_valid);
+      lds = s_valid;
+    }
+    if (t.kind == MI_K_STR32) tile_string<int32_t, NULLS>(t, row0, n, status, lds);
+    else if (t.kind == MI_K_STR64) tile_string<int64_t, NULLS>(t, row0, n, status, lds);
+    else tile_fixed_binary(t, row0, n, lds);
   }
 }
 
@@ -356,8 +438,9 @@ __device__ __forceinline__ int misc_group_of(int32_t kind) {
 constexpr int kLightThreads = 64;
 
 // out[r] = f(r, src[r]) for r < n <= 2048 by one wave; GROUP passes of 64 x V rows are in flight at a time.
-template <typename IN, typename OUT, int V, int GROUP, typename F>
-__device__ __forceinline__ void light_map(gptr<const IN> src, gptr<OUT> out, int n, F&& f) {
+// mask(base) = validity bits of rows [base, base + V) (bit k = row base + k), requested with the data loads of its pass.
+template <typename IN, typename OUT, int V, int GROUP, typename M, typename F>
+__device__ __forceinline__ void light_map(gptr<const IN> src, gptr<OUT> out, int n, M&& mask, F&& f) {
   typedef IN in_vec __attribute__((ext_vector_type(V)));
   typedef in_vec in_vec_a __attribute__((aligned(sizeof(IN))));                 // Arrow buffers: element aligned only
   typedef OUT out_vec __attribute__((ext_vector_type(V)));
@@ -369,9 +452,11 @@ __device__ __forceinline__ void light_map(gptr<const IN> src, gptr<OUT> out, int
   for (int g = 0; g < PASSES; g += GROUP) {
     if ((g * kLightThreads) * V >= n) break;  // uniform
     in_vec vin[GROUP];
+    uint32_t ok[GROUP];
 #pragma unroll
     for (int p = 0; p < GROUP; p++) {
       const int base = ((g + p) * kLightThreads + lane) * V;
+      ok[p] = base < n ? mask(base) : 0u;
       if (base + V <= n) {
         vin[p] = __builtin_nontemporal_load((gptr<const in_vec_a>)(src + base));
       } else {
@@ -384,7 +469,7 @@ __device__ __forceinline__ void light_map(gptr<const IN> src, gptr<OUT> out, int
       const int base = ((g + p) * kLightThreads + lane) * V;
       out_vec vout;
 #pragma unroll
-      for (int k = 0; k < V; k++) vout[k] = f(base + k, vin[p][k]);
+      for (int k = 0; k < V; k++) vout[k] = f(((ok[p] >> k) & 1u) != 0, vin[p][k]);
       if (base + V <= n) {
         __builtin_nontemporal_store(vout, (gptr<out_vec_a>)(out + base));
       } else {
@@ -439,21 +524,43 @@ __global__ __launch_bounds__(kLightThreads) void transcode_misc_light(const mi_c
   for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     MI_TILE_PROLOGUE();
     if (misc_group_of(t.kind) != (WIDE ? 3 : 0)) continue;  // uniform: another group's launch owns this tile
-    if (tile_needs_mask(t)) __syncthreads();
-    tile_validity<kLightThreads>(t, row0, n, s_valid);
+    // NULLs of the column itself: lane L asks for dword L of the tile's 2048 validity bits BEFORE the data loads leave; a data
+    // lane gets the bits of its 4 rows from the lane that holds them (one ds_bpermute, no memory access), and the same dwords
+    // are the tile's validity words, stored behind the data -- the tile stays ONE round trip.  Children of structs /
+    // fixed-size lists (the parent's NULLs come on top) keep the LDS mask.
+    const bool nested = t.out_aux != nullptr;
     const bool has_nulls = tile_needs_mask(t);
-    auto valid = [&](int r) { return row_valid(s_valid, has_nulls, r); };
+    const int lane = threadIdx.x;
+    uint32_t vd = ~0u;
+    if (nested) {
+      __syncthreads();
+      tile_validity<kLightThreads>(t, row0, n, s_valid);
+    } else if (has_nulls && 32 * lane < n) {
+      gptr<const uint32_t> W = GC<uint32_t>(t.validity);
+      const int64_t bit = t.row_offset + row0 + 32 * lane;
+      const int64_t q = bit >> 5;
+      const int sh = static_cast<int>(bit & 31);
+      const int64_t last_q = (t.row_offset + t.nrows - 1) >> 5;   // last dword that holds a bit of this column
+      const uint32_t lo = W[q];
+      const uint32_t hi = (sh != 0 && q + 1 <= last_q) ? W[q + 1] : 0u;
+      vd = sh ? __builtin_amdgcn_alignbit(hi, lo, static_cast<uint32_t>(sh)) : lo;
+    }
+    auto valid4 = [&](int base) -> uint32_t {   // rows base .. base + 3 (base is a multiple of 4: inside one dword)
+      if (!has_nulls) return 0xFu;
+      if (nested) return static_cast<uint32_t>(s_valid[base >> 6] >> (base & 63)) & 0xFu;
+      return (static_cast<uint32_t>(__shfl(static_cast<int>(vd), base >> 5, 64)) >> (base & 31)) & 0xFu;
+    };
     uint32_t err = 0;
     switch (WIDE ? t.kind : 0) {
       case MI_K_DATE64:
-        light_map<int64_t, int32_t, 4, 4>(GC<int64_t>(t.buf1) + t.row_offset + row0, GM<int32_t>(t.out_data) + row0, n,
-                                          [&](int, int64_t v) { return static_cast<int32_t>(v / 86400000ll); });
+        light_map<int64_t, int32_t, 4, 4>(GC<int64_t>(t.buf1) + t.row_offset + row0, GM<int32_t>(t.out_data) + row0, n, [](int) { return 0xFu; },
+                                          [&](bool, int64_t v) { return static_cast<int32_t>(v / 86400000ll); });
         break;
       case MI_K_MUL_I64: {
         const int64_t factor = t.param;
-        light_map<int64_t, int64_t, 4, 4>(GC<int64_t>(t.buf1) + t.row_offset + row0, GM<int64_t>(t.out_data) + row0, n, [&](int r, int64_t v) {
+        light_map<int64_t, int64_t, 4, 4>(GC<int64_t>(t.buf1) + t.row_offset + row0, GM<int64_t>(t.out_data) + row0, n, valid4, [&](bool ok, int64_t v) {
           int64_t o = 0;
-          if (valid(r) && __builtin_mul_overflow(v, factor, &o)) {  // TryMultiplyOperator => ConversionException
+          if (ok && __builtin_mul_overflow(v, factor, &o)) {  // TryMultiplyOperator => ConversionException
             o = 0;
             err = MI_ST_MUL_OVERFLOW;
           }
@@ -466,8 +573,8 @@ __global__ __launch_bounds__(kLightThreads) void transcode_misc_light(const mi_c
         // multiply-high, the generic 64-bit division (~100 instructions, dozens of registers) stays out of the unrolled code
         const int64_t d = t.param;
         if (d == 1000) {
-          light_map<int64_t, int64_t, 4, 4>(GC<int64_t>(t.buf1) + t.row_offset + row0, GM<int64_t>(t.out_data) + row0, n,
-                                            [&](int, int64_t v) { return v / 1000; });  // all rows, like upstream
+          light_map<int64_t, int64_t, 4, 4>(GC<int64_t>(t.buf1) + t.row_offset + row0, GM<int64_t>(t.out_data) + row0, n, [](int) { return 0xFu; },
+                                            [&](bool, int64_t v) { return v / 1000; });  // all rows, like upstream
         } else {
           gptr<const int64_t> src = GC<int64_t>(t.buf1) + t.row_offset + row0;
           gptr<int64_t> out = GM<int64_t>(t.out_data) + row0;
@@ -482,8 +589,8 @@ __global__ __launch_bounds__(kLightThreads) void transcode_misc_light(const mi_c
       case MI_K_BOOL: light_bool(t, row0, n); break;
       case MI_K_MUL_I32: {
         const int64_t factor = t.param;  // int32 * 1e6 cannot overflow int64
-        light_map<int32_t, int64_t, 4, 4>(GC<int32_t>(t.buf1) + t.row_offset + row0, GM<int64_t>(t.out_data) + row0, n,
-                                          [&](int r, int32_t v) { return valid(r) ? static_cast<int64_t>(v) * factor : int64_t(0); });
+        light_map<int32_t, int64_t, 4, 4>(GC<int32_t>(t.buf1) + t.row_offset + row0, GM<int64_t>(t.out_data) + row0, n, valid4,
+                                          [&](bool ok, int32_t v) { return ok ? static_cast<int64_t>(v) * factor : int64_t(0); });
         break;
       }
       case MI_K_DICT: {
@@ -491,8 +598,8 @@ __global__ __launch_bounds__(kLightThreads) void transcode_misc_light(const mi_c
         const int iw = static_cast<int>(t.param & 0xFF);
         const bool is_signed = ((t.param >> 8) & 1) != 0;
         const uint32_t dict_len = static_cast<uint32_t>(t.param2);
-        auto to_sel = [&](int r, uint64_t v) {
-          if (!valid(r)) return dict_len;
+        auto to_sel = [&](bool ok, uint64_t v) {
+          if (!ok) return dict_len;
           if (v > 0xFFFFFFFFull) {  // "DuckDB only supports indices that fit on an uint32"
             err = MI_ST_INDEX_RANGE;
             return dict_len;
@@ -506,20 +613,25 @@ __global__ __launch_bounds__(kLightThreads) void transcode_misc_light(const mi_c
         gptr<uint32_t> out = GM<uint32_t>(t.out_data) + row0;
         gptr<const uint8_t> idx = GC<uint8_t>(t.buf1) + (t.row_offset + row0) * iw;
         if (iw == 4) {
-          if (is_signed) light_map<int32_t, uint32_t, 4, 8>((gptr<const int32_t>)idx, out, n, [&](int r, int32_t v) { return to_sel(r, static_cast<uint64_t>(static_cast<int64_t>(v))); });
-          else light_map<uint32_t, uint32_t, 4, 8>((gptr<const uint32_t>)idx, out, n, [&](int r, uint32_t v) { return to_sel(r, v); });
+          if (is_signed) light_map<int32_t, uint32_t, 4, 8>((gptr<const int32_t>)idx, out, n, valid4, [&](bool ok, int32_t v) { return to_sel(ok, static_cast<uint64_t>(static_cast<int64_t>(v))); });
+          else light_map<uint32_t, uint32_t, 4, 8>((gptr<const uint32_t>)idx, out, n, valid4, [&](bool ok, uint32_t v) { return to_sel(ok, v); });
         } else if (iw == 2) {
-          if (is_signed) light_map<int16_t, uint32_t, 4, 8>((gptr<const int16_t>)idx, out, n, [&](int r, int16_t v) { return to_sel(r, static_cast<uint64_t>(static_cast<int64_t>(v))); });
-          else light_map<uint16_t, uint32_t, 4, 8>((gptr<const uint16_t>)idx, out, n, [&](int r, uint16_t v) { return to_sel(r, v); });
+          if (is_signed) light_map<int16_t, uint32_t, 4, 8>((gptr<const int16_t>)idx, out, n, valid4, [&](bool ok, int16_t v) { return to_sel(ok, static_cast<uint64_t>(static_cast<int64_t>(v))); });
+          else light_map<uint16_t, uint32_t, 4, 8>((gptr<const uint16_t>)idx, out, n, valid4, [&](bool ok, uint16_t v) { return to_sel(ok, v); });
         } else if (iw == 1) {
-          if (is_signed) light_map<int8_t, uint32_t, 4, 8>((gptr<const int8_t>)idx, out, n, [&](int r, int8_t v) { return to_sel(r, static_cast<uint64_t>(static_cast<int64_t>(v))); });
-          else light_map<uint8_t, uint32_t, 4, 8>(idx, out, n, [&](int r, uint8_t v) { return to_sel(r, v); });
+          if (is_signed) light_map<int8_t, uint32_t, 4, 8>((gptr<const int8_t>)idx, out, n, valid4, [&](bool ok, int8_t v) { return to_sel(ok, static_cast<uint64_t>(static_cast<int64_t>(v))); });
+          else light_map<uint8_t, uint32_t, 4, 8>(idx, out, n, valid4, [&](bool ok, uint8_t v) { return to_sel(ok, v); });
         } else {
-          light_map<uint64_t, uint32_t, 4, 4>((gptr<const uint64_t>)idx, out, n, [&](int r, uint64_t v) { return to_sel(r, v); });  // a negative int64 is > UINT32_MAX too
+          light_map<uint64_t, uint32_t, 4, 4>((gptr<const uint64_t>)idx, out, n, valid4, [&](bool ok, uint64_t v) { return to_sel(ok, v); });  // a negative int64 is > UINT32_MAX too
         }
         break;
       }
       default: break;
+    }
+    if (!nested && t.out_validity != nullptr && 32 * lane < ((n + 63) >> 6) * 64) {
+      const int rem = n - 32 * lane;   // canonical pad bits
+      const uint32_t d = rem >= 32 ? vd : rem <= 0 ? ~0u : (vd | (~0u << rem));
+      GM<uint32_t>(t.out_validity)[(row0 >> 5) + lane] = d;
     }
     raise(status, err);
   }
@@ -615,8 +727,14 @@ hipError_t LaunchTranscode(int cls, const mi_col_task* d_tasks, const uint32_t* 
   hipLaunchKernelGGL(KERNEL, grid, BLOCK, 0, stream, d_tasks, d_tile_begin, d_tile_task, n_tasks, total_tiles, d_status)
   switch (cls) {
     case kClassCopy: MI_LAUNCH(transcode_copy, block); break;
-    case kClassDec128: MI_LAUNCH(transcode_dec128, block); break;
-    case kClassString: MI_LAUNCH(transcode_string, block); break;
+    case kClassDec128:   // misc_groups: bit 0 = tiles without NULLs, bit 1 = tiles that need a mask
+      if (misc_groups & 1u) MI_LAUNCH(transcode_dec128<false>, block);
+      if (misc_groups & 2u) MI_LAUNCH(transcode_dec128<true>, block);
+      break;
+    case kClassString:
+      if (misc_groups & 1u) MI_LAUNCH(transcode_string<false>, block);
+      if (misc_groups & 2u) MI_LAUNCH(transcode_string<true>, block);
+      break;
     case kClassMisc:
       if (misc_groups & 1u) MI_LAUNCH(transcode_misc_light<false>, dim3(kLightThreads));
       if (misc_groups & 8u) MI_LAUNCH(transcode_misc_light<true>, dim3(kLightThreads));

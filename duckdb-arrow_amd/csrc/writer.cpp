@@ -1548,6 +1548,18 @@ int mi_ipc_serialize_schema(mi_writer* w, const uint8_t** blob, int64_t* size) {
   });
 }
 
+int mi_writer_append_message(mi_writer* w, const uint8_t* blob, int64_t size) {
+  return WrapC([&] {
+    if (!w || !w->writer || (!blob && size) || size < 0) throw InvalidInputException("mi_writer_append_message: bad argument");
+    if (size == 0) {   // an empty collection still counts as a flushed row group (ArrowStreamWriter::Flush)
+      w->writer->CountEmptyFlush();
+      return;
+    }
+    const int64_t at = w->writer->ReserveRowGroup(static_cast<size_t>(size));
+    w->writer->WriteAt(at, blob, static_cast<size_t>(size));
+  });
+}
+
 int mi_ipc_serialize_chunks(mi_writer* w, const mi_data_chunk* chunks, int32_t n_chunks, const uint8_t** blob, int64_t* size) {
   return WrapC([&] {
     if (!w || !w->serializer || !blob || !size || (!chunks && n_chunks)) throw InvalidInputException("mi_ipc_serialize_chunks: bad argument");

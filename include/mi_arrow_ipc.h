@@ -454,8 +454,9 @@ typedef struct mi_scan_options {
                                  * then is not DMA'd to the GPU at all; HBM copy of the body when device_resident) and
                                  * its validity is NULL = all valid -- the reference's zero-copy DirectConversion +
                                  * unset ValidityMask.  The body stays alive until the chunk after the batch's last.
-                                 * 0 = default: ON for device_resident scans (what the reference does; the GPU consumer
-                                 * reads the Arrow buffer in HBM), OFF for host consumers; -1 = never. */
+                                 * 0 = default = ON, what the reference does: a GPU consumer reads the Arrow buffer in HBM,
+                                 * a host consumer the pinned host body (lineitem: 7 of 16 columns cross PCIe in neither
+                                 * direction); -1 = never (every vector is materialised by a kernel). */
   int32_t unset_all_valid;      /* 1: a column without NULLs in a record batch gets no validity words: mi_vector.validity is
                                  * NULL (= all valid), like the reference's unset ValidityMask; 0: 32 all-ones words per chunk */
   int32_t filter_compact;       /* with a pushed-down filter: 1 = late materialisation, chunks hold ONLY the selected rows
@@ -601,6 +602,8 @@ typedef struct mi_scan_stats {
                                      * fall in step, 65 = the serial walk) ... */
   int64_t lz4_parse_rounds_max;     /* ... and the worst block */
   int64_t zstd_batches_on_device;   /* ZSTD bodies decompressed in HBM (K8: entropy stage per block, then the LZ4 copy stages) */
+  int64_t d2h_bytes;                /* vector (and mirrored string payload) bytes copied HBM -> pinned host memory */
+  int64_t aliased_bytes;            /* vector bytes that were never copied: DirectConversion columns aliasing the body */
 } mi_scan_stats;
 int mi_scan_get_stats(mi_scan* s, mi_scan_stats* out);
 
@@ -671,6 +674,10 @@ void mi_writer_local_destroy(mi_writer_local* l);
  * where the one-thread sink would cut them and are staged / encoded / written by several sink threads
  * (MI_WRITER_THREADS, default cores / 3, at most 6); they reach the file in input order.  *rows = copied. */
 int mi_writer_sink_scan(mi_writer* w, mi_scan* scan, int64_t* rows);
+/* ArrowWriteFlushBatch (write_arrow_stream.cpp:240-245): appends one record-batch message that was serialised elsewhere --
+ * the header||body blob of mi_ipc_serialize_chunks, which ArrowWritePrepareBatch (:227-238) runs concurrently, one
+ * serializer per call -- at the next free position of the file and counts it as a row group.  size 0 = an empty batch. */
+int mi_writer_append_message(mi_writer* w, const uint8_t* blob, int64_t size);
 /* ArrowWriteCombine + ArrowWriteFinalize (write_arrow_stream.cpp:161-174): flush the tail, write EOS
  * {FF FF FF FF 00 00 00 00} (arrow_stream_writer.cpp:78-82), close. */
 int mi_writer_finalize(mi_writer* w);

@@ -158,7 +158,16 @@ def pyarrow_value(t, v):
 
 def pyarrow_columns(table):
     """Every column of a pyarrow table as canonical values (canon_python form)."""
-    return [canon_python([pyarrow_value(f.type, v) for v in table.column(i).to_pylist()]) for i, f in enumerate(table.schema)]
+    import pyarrow as pa
+    out = []
+    for i, f in enumerate(table.schema):
+        col, t = table.column(i), f.type
+        if pa.types.is_timestamp(t):   # stored int64 in DuckDB's unit: microseconds (nanoseconds stay TIMESTAMP_NS)
+            if t.unit in ("s", "ms"):
+                col = col.cast(pa.timestamp("us", tz=t.tz))
+            col, t = col.cast(pa.int64()), pa.int64()
+        out.append(canon_python([pyarrow_value(t, v) for v in col.to_pylist()]))
+    return out
 
 
 # ------------------------------------------------------------------------------------------ raw (-1) compressed buffers

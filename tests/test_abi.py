@@ -34,6 +34,38 @@ def test_binding_covers_every_declared_symbol():
         assert getattr(L, name) is not None
 
 
+def test_duckdb_glue_calls_only_declared_and_exported_symbols():
+    """glue/duckdb/*.{cpp,hpp} -- the extension's TableFunction / CopyFunction surface written against DuckDB's API, built only
+    with -DDUCKDB_DIR -- may call nothing but what include/mi_arrow_ipc.h declares and the library exports; the sources name
+    the reference file each of them replaces, and the build refuses to configure without a DuckDB tree (no stand-in headers)."""
+    glue = os.path.join(ROOT, "glue", "duckdb")
+    sources = sorted(f for f in os.listdir(glue) if f.endswith((".cpp", ".hpp")))
+    assert {"mi_scan_arrow_ipc.cpp", "mi_read_arrow.cpp", "mi_write_arrow_stream.cpp", "mi_to_arrow_ipc.cpp",
+            "mi_nanoarrow_extension.cpp", "mi_glue_common.hpp", "mi_file_scan.hpp"} <= set(sources)
+    out = subprocess.run(["nm", "-D", "--defined-only", _ffi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\bT (mi_[a-z0-9_]+)", out))
+    declared = declared_symbols()
+    types = set(re.findall(r"\b(mi_[a-z0-9_]+)\b", " ".join(re.findall(r"typedef struct (\w+)|\} (\w+);", open(os.path.join(ROOT, "include", "mi_arrow_ipc.h")).read()).__str__().split())))
+    called = set()
+    for f in sources:
+        text = open(os.path.join(glue, f)).read()
+        assert "src/" in text, "%s does not cite the reference file it replaces" % f
+        text = re.sub(r"//[^\n]*", "", text)
+        called |= set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", text))
+    called -= types
+    assert called and called <= declared, sorted(called - declared)
+    assert called <= exported, sorted(called - exported)
+    # the five entry points of the reference, under its names
+    ext = open(os.path.join(glue, "mi_nanoarrow_extension.cpp")).read() + open(os.path.join(glue, "mi_read_arrow.cpp")).read() + \
+        open(os.path.join(glue, "mi_scan_arrow_ipc.cpp")).read() + open(os.path.join(glue, "mi_write_arrow_stream.cpp")).read() + \
+        open(os.path.join(glue, "mi_to_arrow_ipc.cpp")).read()
+    for name in ('"nanoarrow_version"', '"read_arrow"', '"scan_arrow_ipc"', '"to_arrow_ipc"', 'CopyFunction function("arrows")', 'function.name = "arrow"'):
+        assert name in ext, name
+    cm = open(os.path.join(glue, "CMakeLists.txt")).read()
+    assert "DUCKDB_DIR" in cm and "FATAL_ERROR" in cm
+    assert not os.path.exists(os.path.join(glue, "duckdb")), "no stand-in DuckDB headers"
+
+
 def test_struct_sizes_match_header():
     """ctypes mirrors vs the C compiler's view of include/mi_arrow_ipc.h."""
     src = r'''

@@ -109,3 +109,66 @@ def test_sf10_fused_q6_equals_torch_on_decoded_vectors(sf10, tmp_path_factory):
     total, sel, scanned = rel.sum_product("l_extendedprice", "l_discount",
                                           [("l_shipdate", 8766, 9131), ("l_discount", 5, 8), ("l_quantity", -2**63, 2400)])
     assert (total, sel, scanned) == (want, selected, info["n_rows"])
+
+
+def test_config5_commits_shape_bit_exact_and_equal_to_pyarrow():
+    """BASELINE configs[4] ("config 5" of SURVEY 8d) at its shape: arrow-commits columns (40-byte commit, ts[us, UTC], int32,
+    bool, 9-513 byte message) with 10 % NULLs in every nullable column and two dictionary-encoded columns (int32 indices),
+    1 228 800 rows in 10 record batches, resident in HBM.  Every batch bit-exact against the oracle (dictionaries included);
+    validity words and fixed-width values of every batch, and all values of the first and the last batch, equal pyarrow's
+    reading of the same stream.  Beyond the reference, which cannot read dictionary-encoded IPC at all
+    (src/ipc/stream_reader/base_stream_reader.cpp:86-96): parity for K5 is pinned by pyarrow, not by the reference."""
+    import os
+    import sys
+    import pyarrow as pa
+    import pyarrow.ipc as ipc
+    from duckdb_arrow_amd.hbm import HbmStream
+    from oracle import pyoracle as po
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from commits_bench import commits_stream
+    from helpers import canon_stream, pyarrow_columns
+    from test_gpu_decode_parity import assert_streams_equal
+
+    n_rows = 1228800
+    buf = commits_stream(n_rows)
+    ctx = da.Context(0)
+    hs = HbmStream(ctx, buf, accept_dictionaries=True)
+    hs.launch()
+    assert hs.status() == 0
+    got = hs.fetch()
+    fields, want = po.decode_stream(buf)
+    assert len(got) == 10 and sum(b["nrows"] for b in got) == n_rows
+    assert_streams_equal(got, want)
+    for gb, wb in zip(got, want):
+        for gc, wc in zip(gb["columns"], wb["columns"]):
+            if "dictionary" in wc:
+                assert np.array_equal(gc["dictionary"]["data"], wc["dictionary"]["data"]), gc["name"]
+                assert np.array_equal(gc["dictionary"]["validity"], wc["dictionary"]["validity"]), gc["name"]
+    # pyarrow, every batch: validity bits and the fixed-width values of the valid rows
+    batches = list(ipc.open_stream(pa.py_buffer(buf)))
+    names = batches[0].schema.names
+    for gb, pb in zip(got, batches):
+        n = pb.num_rows
+        for ci, name in enumerate(names):
+            col = pb.column(ci)
+            ok = np.unpackbits(gb["columns"][ci]["validity"].view(np.uint8), bitorder="little")[:n].astype(bool)
+            assert np.array_equal(ok, np.asarray(col.is_valid())), name
+            if name == "time":
+                assert np.array_equal(gb["columns"][ci]["data"].view(np.int64)[ok], np.asarray(col.cast(pa.int64()).drop_null()))
+            elif name == "files":
+                assert np.array_equal(gb["columns"][ci]["data"].view(np.int32)[ok], np.asarray(col.drop_null()))
+            elif name == "merge":
+                assert np.array_equal(gb["columns"][ci]["data"].view(np.uint8)[ok].astype(bool), np.asarray(col.drop_null()))
+            elif name in ("author", "component"):
+                assert np.array_equal(gb["columns"][ci]["data"].view(np.uint32)[ok], np.asarray(col.indices.drop_null()).astype(np.uint32))
+            else:   # strings: the lengths of every row (the bytes: first and last batch below)
+                lens = gb["columns"][ci]["data"].reshape(-1, 16)[:, :4].copy().view(np.uint32).reshape(-1)
+                off = np.frombuffer(col.buffers()[1], np.int32, n + 1)
+                assert np.array_equal(lens[ok], np.diff(off).astype(np.uint32)[ok]), name
+    # pyarrow, first and last batch: every value
+    for bi in (0, len(got) - 1):
+        vals = canon_stream(fields, [got[bi]], buf)
+        table = pa.Table.from_batches([batches[bi]])
+        for name, exp in zip(names, pyarrow_columns(table)):
+            assert vals[name] == exp, (bi, name)
+    hs.close()

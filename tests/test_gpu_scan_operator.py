@@ -366,7 +366,13 @@ def test_zero_copy_direct_columns(con, golden_dir, expected):
     """zero_copy_direct: plain fixed-width columns without NULLs alias the record-batch body (the reference's
     DirectConversion) and carry no validity mask; everything else still goes through the kernels.  Same values."""
     path = g(golden_dir, "lineitem_sf0_01_head.arrows")
-    want = con.read_arrow(path).fetch_columns()
+    off = con.read_arrow(path, zero_copy_direct=False)      # every vector materialised by a kernel
+    want = off.fetch_columns()
+    assert off.stats()["aliased_bytes"] == 0 and off.stats()["d2h_bytes"] > 0
+    auto = con.read_arrow(path)                              # the default: on, for host consumers too
+    assert auto.fetch_columns() == want
+    st = auto.stats()
+    assert st["aliased_bytes"] > 0 and st["d2h_bytes"] < off.stats()["d2h_bytes"] and st["h2d_bytes"] < off.stats()["h2d_bytes"]
     rel = con.read_arrow(path, zero_copy_direct=True)
     aliased = set()
     got = [[] for _ in rel.columns]
@@ -381,7 +387,7 @@ def test_zero_copy_direct_columns(con, golden_dir, expected):
     assert not ({"l_quantity", "l_comment", "l_returnflag"} & aliased)
     # NULL-bearing and nested files: nothing breaks, columns with NULLs are transcoded as before
     for rel_path in ("edge_types.arrows", "edge_nested.arrows", "ref_data/test.arrows"):
-        a = con.read_arrow(g(golden_dir, rel_path)).fetch_columns()
+        a = con.read_arrow(g(golden_dir, rel_path), zero_copy_direct=False).fetch_columns()
         b = con.read_arrow(g(golden_dir, rel_path), zero_copy_direct=True).fetch_columns()
         assert [canon_python(c) for c in a] == [canon_python(c) for c in b], rel_path
     # with a pushed-down filter on a direct column the filter column itself is still materialised on the GPU
