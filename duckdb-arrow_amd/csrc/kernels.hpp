@@ -77,15 +77,18 @@ struct Lz4Args {
   const Lz4BlockDev* blocks;
   const Lz4BufferDev* buffers;
   uint32_t n_blocks, n_buffers;
-  uint32_t max_block_comp, _pad;  // largest compressed block
+  uint32_t max_block_comp, _pad;  // largest compressed block; _pad: set by the launcher (which parse kernel owns which blocks)
+  uint32_t min_block_comp;        // smallest compressed (not stored) block
+  uint32_t max_buffer_blocks;     // most blocks any one buffer has
   void* seq;                      // 16 bytes per sequence, in the slices of lz4_parse's 256 lanes per block
   uint32_t* seq_off;              // 4 bytes per sequence
   uint32_t* lane_out;             // per block and lane: output position (inside the block) its slice begins at ...
   uint32_t* lane_nseq;            // ... and its number of sequences
-  uint32_t* link;                 // 4 bytes per decompressed byte (rounded up to 16 bytes), preset to 0xFF
+  uint32_t* link;                 // 4 bytes per decompressed byte (rounded up to 16 bytes); no preset needed
   uint32_t* block_out_size;       // per block
   uint32_t* block_nseq;
   uint64_t* block_out_base;
+  uint32_t* chunk_base;           // per block (+ 1): first chunk (<= 8 KiB of one block's output) of the block, k8_chunk_map
   uint32_t* buffer_ok;            // per buffer
   uint8_t* mark;                  // one byte per decompressed byte (rounded up to 16), zeroed: 1 = an open word of another tile points here
   uint32_t* skel;                 // the skeleton list: up to one entry per decompressed byte

@@ -56,7 +56,7 @@ ArrowScan::ArrowScan(Context* ctx_p, std::vector<std::string> paths, const mi_sc
     sources.push_back(std::move(s));
   }
   slots.resize(static_cast<size_t>(PipelineDepth(opts)));
-  staging.resize(slots.size() + kReadAhead + 2);   // slots + queue + the body being read + its decompressed copy
+  staging.resize(slots.size() + 2 * kMaxProducers + 2);   // slots + queues + the bodies being read + a decompressed copy
 }
 
 ArrowScan::ArrowScan(Context* ctx_p, std::vector<ArrowIPCBuffer> buffers_p, const mi_scan_options& o)
@@ -64,7 +64,7 @@ ArrowScan::ArrowScan(Context* ctx_p, std::vector<ArrowIPCBuffer> buffers_p, cons
   Source s;
   sources.push_back(std::move(s));
   slots.resize(static_cast<size_t>(PipelineDepth(opts)));
-  staging.resize(slots.size() + kReadAhead + 2);   // slots + queue + the body being read + its decompressed copy
+  staging.resize(slots.size() + 2 * kMaxProducers + 2);   // slots + queues + the bodies being read + a decompressed copy
 }
 
 ArrowScan::~ArrowScan() {
@@ -103,6 +103,7 @@ ArrowScan::~ArrowScan() {
     if (p) (void)hipFree(p);
   dicts.clear();
   fetched.clear();
+  extra_readers.clear();
   for (auto& st : staging)
     if (st.p) (void)hipHostFree(st.p);
 }
@@ -356,7 +357,7 @@ void ArrowScan::EnsurePipelineDepth(int depth) {
   std::vector<Slot> bigger(static_cast<size_t>(depth));
   for (size_t i = 0; i < slots.size(); i++) bigger[i] = std::move(slots[i]);
   slots = std::move(bigger);
-  staging.resize(slots.size() + kReadAhead + 2);   // slots + queue + the body being read + its decompressed copy
+  staging.resize(slots.size() + 2 * kMaxProducers + 2);   // slots + queues + the bodies being read + a decompressed copy
   if (initialized)
     for (auto& s : slots) InitSlot(s);
 }
@@ -919,11 +920,12 @@ void ArrowScan::EnqueueLz4(Slot& s) {
   const size_t o_zblocks = take(is_zstd ? nb * sizeof(zstd::BlockInfo) : 0);
   const size_t tables_bytes = at;
   uint64_t total_seq = 0, max_len = 0;
+  uint32_t max_blocks = 0;
   for (auto& blk : d.blocks) total_seq += is_zstd ? blk.seq_cap : device::Lz4SeqCapacity(blk.comp_size);
   // ZSTD: the decoded literals of every block lie behind the compressed body, in the same allocation
   const size_t lit_base = RoundUp(static_cast<size_t>(d.comp_size) + 64, 256);
   const size_t comp_need = is_zstd ? lit_base + d.literal_scratch + 64 : static_cast<size_t>(d.comp_size) + 64;
-  const size_t o_bsize = take(nb * 4), o_bnseq = take(nb * 4), o_bbase = take(nb * 8), o_bufok = take(nf * 4), o_round = take(40 * 4),
+  const size_t o_bsize = take(nb * 4), o_bnseq = take(nb * 4), o_bbase = take(nb * 8), o_chunk = take((nb + 1) * 4), o_bufok = take(nf * 4), o_round = take(40 * 4),
                o_status = take(4), o_mark = take(out_size + 16);
   const size_t counters_end = at;
   const size_t o_seq = take(static_cast<size_t>(total_seq) * 16), o_seqoff = take(static_cast<size_t>(total_seq) * 4);
@@ -978,7 +980,10 @@ void ArrowScan::EnqueueLz4(Slot& s) {
     hf[i].n_blocks = f.raw ? 0 : f.n_blocks;
     hf[i].block_max = f.block_max;
     hf[i]._pad = 0;
-    if (!f.raw) max_len = std::max<uint64_t>(max_len, static_cast<uint64_t>(f.out_len));
+    if (!f.raw) {
+      max_len = std::max<uint64_t>(max_len, static_cast<uint64_t>(f.out_len));
+      max_blocks = std::max<uint32_t>(max_blocks, f.n_blocks);
+    }
   }
   // H2D on the copy stream: the compressed bytes of the needed buffers (neighbours closer than 64 KiB travel as one copy)
   std::vector<std::pair<int64_t, int64_t>> ranges;
@@ -1007,12 +1012,9 @@ void ArrowScan::EnqueueLz4(Slot& s) {
   MI_HIP_CHECK(hipEventRecord(s.h2d_done, ctx->h2d_stream));
   hipStream_t q = s.lz4_stream;
   MI_HIP_CHECK(hipStreamWaitEvent(q, s.h2d_done, 0));
-  static const int dbg_skip = std::getenv("MI_K8_DIAG_SKIP") ? std::atoi(std::getenv("MI_K8_DIAG_SKIP")) : 0;   // DIAG-TEMP
-  if (!(dbg_skip & 2)) {   // DIAG-TEMP
-  MI_HIP_CHECK(hipMemsetAsync(s.d_in, 0, out_size, q));                                        // padding between buffers
-  MI_HIP_CHECK(hipMemsetAsync(s.d_lz4 + tables_bytes, 0, counters_end - tables_bytes, q));      // counters, status
-  MI_HIP_CHECK(hipMemsetAsync(s.d_lz4 + o_link, 0xFF, out_size * 4 + 16, q));                   // every link word "untouched"
-  }   // DIAG-TEMP
+  // ONE memset per record batch: counters, status, marks.  The link words need none (every word a stage reads was written
+  // by the stage before it), nor does the body: the bytes between its buffers are padding nobody reads.
+  MI_HIP_CHECK(hipMemsetAsync(s.d_lz4 + tables_bytes, 0, counters_end - tables_bytes, q));
   for (auto& f : d.buffers)
     if (f.raw && f.out_len > 0)
       MI_HIP_CHECK(hipMemcpyAsync(s.d_in + f.out_off, s.d_comp + f.comp_off, static_cast<size_t>(f.out_len), hipMemcpyDeviceToDevice, q));
@@ -1022,12 +1024,17 @@ void ArrowScan::EnqueueLz4(Slot& s) {
   a.out = s.d_in;
   a.out_size = out_size;
   a.max_buffer_len = max_len;
+  a.max_buffer_blocks = max_blocks;
   a.blocks = reinterpret_cast<const device::Lz4BlockDev*>(s.d_lz4 + o_blocks);
   a.buffers = reinterpret_cast<const device::Lz4BufferDev*>(s.d_lz4 + o_buffers);
   a.n_blocks = static_cast<uint32_t>(nb);
   a.n_buffers = static_cast<uint32_t>(nf);
+  a.min_block_comp = 0xFFFFFFFFu;
   for (auto& blk : d.blocks)
-    if (!blk.stored && !is_zstd) a.max_block_comp = std::max(a.max_block_comp, blk.comp_size);
+    if (!blk.stored && !is_zstd) {
+      a.max_block_comp = std::max(a.max_block_comp, blk.comp_size);
+      a.min_block_comp = std::min(a.min_block_comp, blk.comp_size);
+    }
   a.seq = s.d_lz4 + o_seq;
   a.seq_off = reinterpret_cast<uint32_t*>(s.d_lz4 + o_seqoff);
   a.lane_out = reinterpret_cast<uint32_t*>(s.d_lz4 + o_lane_out);
@@ -1036,6 +1043,7 @@ void ArrowScan::EnqueueLz4(Slot& s) {
   a.block_out_size = reinterpret_cast<uint32_t*>(s.d_lz4 + o_bsize);
   a.block_nseq = reinterpret_cast<uint32_t*>(s.d_lz4 + o_bnseq);
   a.block_out_base = reinterpret_cast<uint64_t*>(s.d_lz4 + o_bbase);
+  a.chunk_base = reinterpret_cast<uint32_t*>(s.d_lz4 + o_chunk);
   a.buffer_ok = reinterpret_cast<uint32_t*>(s.d_lz4 + o_bufok);
   a.round_left = reinterpret_cast<uint32_t*>(s.d_lz4 + o_round);
   a.mark = s.d_lz4 + o_mark;
@@ -1214,7 +1222,12 @@ void ArrowScan::PrepareSource(size_t si) {
   src.filter_to_file_column.assign(filter_only_columns.size(), -1);
   for (size_t c = 0; c < filter_only_columns.size(); c++) src.filter_to_file_column[c] = map_column(filter_only_columns[c]);
   if (!wanted.empty()) src.reader->SetColumnProjection(wanted);
-  src.prepared = true;
+  {
+    std::lock_guard<std::mutex> lk(q_mu);   // the other producers wait for this before they open their own reader of the file
+    src.wanted = wanted;
+    src.prepared = true;
+  }
+  q_cv.notify_all();
 }
 
 // A pinned staging buffer for one record-batch body; the returned handle gives it back when the batch is released.
@@ -1254,12 +1267,13 @@ std::shared_ptr<void> ArrowScan::LeaseStaging(size_t bytes, uint8_t** ptr) {
   });
 }
 
-void ArrowScan::ProducerLoop() {
+void ArrowScan::ProducerLoop(int p) {
+  const size_t cap = n_producers > 1 ? 2 : static_cast<size_t>(kReadAhead);
   auto push = [&](Fetched&& f) {
     std::unique_lock<std::mutex> lk(q_mu);
-    q_cv.wait(lk, [&] { return producer_stop || fetched.size() < static_cast<size_t>(kReadAhead); });
+    q_cv.wait(lk, [&] { return producer_stop || fetched[static_cast<size_t>(p)].size() < cap; });
     if (producer_stop) return false;
-    fetched.push_back(std::move(f));
+    fetched[static_cast<size_t>(p)].push_back(std::move(f));
     lk.unlock();
     q_cv.notify_all();
     return true;
@@ -1267,28 +1281,52 @@ void ArrowScan::ProducerLoop() {
   try {
     ctx->Bind();
     size_t si = 0;
-    int64_t ordinal = 0;
+    int64_t ordinal = 0, share = 0;   // record batches of the file list; of those, this scan's (rank / world)
     while (si < sources.size()) {
       {
         std::lock_guard<std::mutex> lk(q_mu);
         if (producer_stop) return;
       }
-      PrepareSource(si);
-      Source& src = sources[si];
-      src.reader->SetBodyAllocator([this](size_t bytes, MessageType type, uint8_t** ptr) -> std::shared_ptr<void> {
+      IPCStreamReader* reader = nullptr;
+      if (p == 0) {
+        PrepareSource(si);
+        reader = sources[si].reader.get();
+      } else {
+        // a reader of its own over the same file, with the projection producer 0 settled on
+        auto& mine = extra_readers[static_cast<size_t>(p - 1)];
+        if (mine.size() <= si) mine.resize(sources.size());
+        if (!mine[si]) {
+          std::vector<std::string> wanted;
+          {
+            std::unique_lock<std::mutex> lk(q_mu);
+            q_cv.wait(lk, [&] { return producer_stop || producer_error || sources[si].prepared; });
+            if (producer_stop) return;
+            if (producer_error) std::rethrow_exception(producer_error);   // producer 0 could not prepare the file: same error here
+            wanted = sources[si].wanted;
+          }
+          mine[si] = std::make_unique<IPCFileStreamReader>(sources[si].path);
+          mine[si]->SetDeferLz4(opts.host_decompress < 0 || (opts.host_decompress == 0 && opts.device_resident != 0));
+          mine[si]->SetDeferZstd(opts.host_decompress < 0);
+          mine[si]->GetBaseSchema();
+          if (!wanted.empty()) mine[si]->SetColumnProjection(wanted);
+        }
+        reader = mine[si].get();
+      }
+      reader->SetBodyAllocator([this](size_t bytes, MessageType type, uint8_t** ptr) -> std::shared_ptr<void> {
         if (type == MessageType::DICTIONARY_BATCH) {  // lives as long as the dictionary version that points into it
           ctx->Bind();
-          void* p = nullptr;
-          MI_HIP_CHECK(hipHostMalloc(&p, bytes + 64, hipHostMallocDefault));
-          *ptr = static_cast<uint8_t*>(p);
-          return std::shared_ptr<void>(p, [](void* q) { (void)hipHostFree(q); });
+          void* q = nullptr;
+          MI_HIP_CHECK(hipHostMalloc(&q, bytes + 64, hipHostMallocDefault));
+          *ptr = static_cast<uint8_t*>(q);
+          return std::shared_ptr<void>(q, [](void* x) { (void)hipHostFree(x); });
         }
         return LeaseStaging(bytes, ptr);
       });
       Fetched f;
-      const bool mine = opts.world <= 1 || (ordinal % opts.world) == opts.rank;
-      const bool got = src.reader->GetNextBatch(&f.batch, opts.accept_dictionaries != 0, /*skip_body*/ !mine);
-      src.reader->ReleaseCurrentBody();  // the lease belongs to the batch alone
+      const bool in_share = opts.world <= 1 || (ordinal % opts.world) == opts.rank;
+      const bool mine = in_share && (share % n_producers) == p;
+      const bool got = reader->GetNextBatch(&f.batch, opts.accept_dictionaries != 0, /*skip_body*/ !mine);
+      reader->ReleaseCurrentBody();  // the lease belongs to the batch alone
       if (!got) {
         si++;
         continue;
@@ -1296,6 +1334,7 @@ void ArrowScan::ProducerLoop() {
       f.source = static_cast<int32_t>(si);
       if (!f.batch.is_dictionary) {
         f.ordinal = ordinal++;
+        if (in_share) share++;
         if (!mine) continue;
       }
       if (!push(std::move(f))) return;
@@ -1306,6 +1345,11 @@ void ArrowScan::ProducerLoop() {
   } catch (...) {
     Fetched err;
     err.error = std::current_exception();
+    {
+      std::lock_guard<std::mutex> lk(q_mu);   // producers waiting for this one (a file it was to prepare) fail with it
+      if (!producer_error) producer_error = err.error;
+    }
+    q_cv.notify_all();
     push(std::move(err));
   }
 }
@@ -1313,7 +1357,17 @@ void ArrowScan::ProducerLoop() {
 void ArrowScan::StartProducer() {
   if (producer_started) return;
   producer_started = true;
-  producer = std::thread([this] { ProducerLoop(); });
+  // several producers only where record batches are independent of what came before them in the stream (no dictionary
+  // batches, which every later batch of the file depends on) and where there is a pread to overlap (files, not caller buffers)
+  n_producers = 1;
+  if (!is_buffers && !opts.accept_dictionaries) {
+    const char* v = std::getenv("MI_SCAN_PRODUCERS");
+    n_producers = std::max(1, std::min(kMaxProducers, v ? std::atoi(v) : 3));
+  }
+  fetched.assign(static_cast<size_t>(n_producers), {});
+  extra_readers.resize(static_cast<size_t>(n_producers - 1));
+  next_fetch = 0;
+  for (int p = 0; p < n_producers; p++) producers.emplace_back([this, p] { ProducerLoop(p); });
 }
 
 void ArrowScan::StopProducer() {
@@ -1323,7 +1377,8 @@ void ArrowScan::StopProducer() {
     producer_stop = true;
   }
   q_cv.notify_all();
-  if (producer.joinable()) producer.join();
+  for (auto& t : producers)
+    if (t.joinable()) t.join();
 }
 
 bool ArrowScan::SubmitNextBatch(bool may_block) {
@@ -1333,13 +1388,16 @@ bool ArrowScan::SubmitNextBatch(bool may_block) {
     if (!slot) return false;
     Fetched f;
     {
+      // in order: batch j of this scan's share comes from producer j mod P (a dictionary batch -- single producer only --
+      // does not count)
       std::unique_lock<std::mutex> lk(q_mu);
-      if (fetched.empty()) {
+      auto& q = fetched[static_cast<size_t>(next_fetch % n_producers)];
+      if (q.empty()) {
         if (!may_block) return false;
-        q_cv.wait(lk, [&] { return !fetched.empty(); });
+        q_cv.wait(lk, [&] { return !q.empty(); });
       }
-      f = std::move(fetched.front());
-      fetched.pop_front();
+      f = std::move(q.front());
+      q.pop_front();
     }
     q_cv.notify_all();
     if (f.error) {
@@ -1356,6 +1414,7 @@ bool ArrowScan::SubmitNextBatch(bool may_block) {
       DecodeDictionary(src, f.batch);
       continue;
     }
+    next_fetch++;
     Slot& s = *slot;
     s.batch = std::move(f.batch);
     s.source = f.source;

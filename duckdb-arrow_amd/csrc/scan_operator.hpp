@@ -155,6 +155,7 @@ class ArrowScan : public ScanBase {
     std::vector<int32_t> filter_to_file_column;  // per filter-only column (not in the projection)
     std::map<std::string, std::string> hive;   // key -> value parsed from the path
     bool opened = false, prepared = false;
+    std::vector<std::string> wanted;           // the reader projection PrepareSource settled on (the extra producers' readers take it too)
   };
   //! One immutable version of a decoded dictionary (dict_len + 1 entries, the last one NULL).  Record batches keep the
   //! version they were enqueued with, so a later replacement / delta never changes what an in-flight batch sees.
@@ -236,14 +237,23 @@ class ArrowScan : public ScanBase {
   };
   void StartProducer();
   void StopProducer();
-  void ProducerLoop();
+  void ProducerLoop(int p);
   void PrepareSource(size_t si);      // per-file column mapping + reader projection
   std::shared_ptr<void> LeaseStaging(size_t bytes, uint8_t** ptr);
-  static constexpr int kReadAhead = 3;              // fetched batches waiting for a slot
-  std::thread producer;
+  static constexpr int kReadAhead = 3;              // fetched batches waiting for a slot (per producer: 2 when there are several)
+  static constexpr int kMaxProducers = 4;
+  //! Several read-ahead threads for file scans without dictionaries: producer p reads the record batches j of this scan's
+  //! share with j mod P == p (every producer walks every header, bodies that are not its own are stepped over unread -- the
+  //! rank / world rule once more, inside the process), so the pread of one body overlaps the header walk, staging lease and
+  //! pread of the next ones.  The consumer takes them back in order: batch j from queue j mod P.
+  int n_producers = 1;
+  std::vector<std::thread> producers;
   std::mutex q_mu;
   std::condition_variable q_cv;
-  std::deque<Fetched> fetched;
+  std::vector<std::deque<Fetched>> fetched;         // one queue per producer
+  int64_t next_fetch = 0;                           // j of the batch the consumer takes next
+  std::exception_ptr producer_error;                // the first failure of any producer
+  std::vector<std::vector<std::unique_ptr<IPCStreamReader>>> extra_readers;   // [producer - 1][source]
   std::vector<Staging> staging;                     // in flight on the GPU + waiting + the one being read
   bool producer_started = false, producer_stop = false;
   void InitSlot(Slot& s);

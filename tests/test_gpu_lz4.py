@@ -276,9 +276,12 @@ def test_lz4_in_a_multi_device_scan(con, golden_dir, tmp_path):
     assert s1 == s2
 
 
-def test_lz4_blocks_walked_from_global_memory(tmp_path):
-    """Compressed blocks too large for the workgroup's LDS (near-incompressible 64 KiB blocks, 4 MiB block frames) are walked
-    from global memory: the same kernel, the other instantiation -- forced here (MI_LZ4_PARSE_GLOBAL) in a fresh process."""
+@pytest.mark.parametrize("variant", ["default", "MI_LZ4_PARSE_SPECULATIVE", "MI_LZ4_PARSE_GLOBAL"])
+def test_lz4_parse_kernel_variants(tmp_path, variant):
+    """The token walk has three kernels: lz4_parse_dp (exit tables, blocks of <= 50 KiB compressed bytes: the default), the
+    speculative walk from an LDS copy (larger blocks; forced for every block by MI_LZ4_PARSE_SPECULATIVE) and the same from
+    global memory (blocks too large for LDS, 4 MiB block frames; forced by MI_LZ4_PARSE_GLOBAL).  Column `h` (5 random bytes
+    of every 8) compresses to > 50 KiB per 64 KiB block, so the default run uses two of them in one launch set."""
     import subprocess, sys, textwrap
     code = textwrap.dedent("""
         import os, sys
@@ -289,7 +292,8 @@ def test_lz4_blocks_walked_from_global_memory(tmp_path):
         rng = np.random.default_rng(5)
         n = 150000
         t = pa.table({"k": pa.array(np.arange(n, dtype=np.int64) * 5), "s": pa.array(["text %%d %%s" %% (i %% 701, "z" * (i %% 23)) for i in range(n)]),
-                      "q": pa.array(rng.integers(0, 50, n).astype(np.int32))})
+                      "q": pa.array(rng.integers(0, 50, n).astype(np.int32)),
+                      "h": pa.array(rng.integers(0, 1 << 40, n, dtype=np.int64))})
         p = %r
         with ipc.new_stream(p, t.schema, options=ipc.IpcWriteOptions(compression="lz4")) as w:
             w.write_table(t, max_chunksize=60000)
@@ -298,9 +302,12 @@ def test_lz4_blocks_walked_from_global_memory(tmp_path):
         rel = con.read_arrow(p, host_decompress="gpu")
         got = rel.fetch_columns()
         assert got == want and rel.stats()["lz4_batches_on_device"] == 3
+        from helpers import pyarrow_columns, canon_python
+        assert [canon_python(c) for c in got] == pyarrow_columns(t)
         print("ok")
     """) % (ROOT, ROOT, str(tmp_path / "g.arrows"))
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, MI_LZ4_PARSE_GLOBAL="1"), timeout=300)
+    env = dict(os.environ) if variant == "default" else dict(os.environ, **{variant: "1"})
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
