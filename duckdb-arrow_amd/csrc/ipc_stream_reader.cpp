@@ -1434,67 +1434,69 @@ const std::vector<BatchIndexEntry>& IPCFileStreamReader::BuildIndex() {
 // ------------------------------------------------------------------------------------------------ buffer reader
 IPCBufferStreamReader::IPCBufferStreamReader(std::vector<ArrowIPCBuffer> buffers_p) : buffers(std::move(buffers_p)) {}
 
+// The caller's buffers are read in place (ipc_buffer_stream_reader.cpp:36-41: a pointer bump): `view` is the window over the
+// buffer being consumed, `view_index` its place in the list; a buffer is opened when the first byte of it is asked for.
+bool IPCBufferStreamReader::SeekUnreadByte() {
+  while (!view.opened || view.pos >= view.size) {
+    const idx_t next = view.opened ? view_index + 1 : view_index;
+    if (next >= buffers.size()) return false;
+    view_index = next;
+    view.opened = true;
+    view.ptr = reinterpret_cast<const uint8_t*>(static_cast<uintptr_t>(buffers[next].ptr));
+    view.size = static_cast<int64_t>(buffers[next].size);
+    view.pos = 0;
+    if (!view.ptr && view.size > 0) throw IOException("Arrow IPC buffer " + std::to_string(next) + " is a NULL pointer");
+  }
+  return true;
+}
+
 const uint8_t* IPCBufferStreamReader::ReadData(idx_t size) {
   // the reference only asserts (ipc_buffer_stream_reader.cpp:37); a short buffer is reported instead of read past
-  if (!SpanInside(cur_buffer.pos, static_cast<int64_t>(size), cur_buffer.size)) {
+  if (!SpanInside(view.pos, static_cast<int64_t>(size), view.size)) {
     throw IOException("Unexpected end of Arrow IPC buffer: need " + std::to_string(size) + " bytes at position " +
-                      std::to_string(cur_buffer.pos) + " of " + std::to_string(cur_buffer.size));
+                      std::to_string(view.pos) + " of " + std::to_string(view.size));
   }
-  const uint8_t* p = cur_buffer.ptr + cur_buffer.pos;
-  cur_buffer.pos += static_cast<int64_t>(size);
+  const uint8_t* p = view.ptr + view.pos;
+  view.pos += static_cast<int64_t>(size);
   return p;
 }
 
 MessageType IPCBufferStreamReader::ReadNextMessage() {
-  if ((!initialized && cur_idx == buffers.size()) || finished) {
-    finished = true;
-    return MessageType::UNINITIALIZED;
+  while (!finished && SeekUnreadByte()) {
+    prefix_at = ReadData(sizeof(message_prefix));
+    std::memcpy(&message_prefix, prefix_at, sizeof(message_prefix));
+    // An IPC *file* handed over as a buffer begins with the magic the file reader steps over
+    // (ipc_file_stream_reader.cpp:116-119); the reference's buffer reader has no such case, accepting it is a superset
+    const bool file_magic = view_index == 0 && view.pos == 8 && std::memcmp("ARROW1\0\0", prefix_at, 8) == 0;
+    if (file_magic) continue;
+    if (message_prefix.continuation_token != kContinuationToken)
+      throw IOException("Expected continuation token (0xFFFFFFFF) but got " + std::to_string(message_prefix.continuation_token));
+    return FinishMessage();
   }
-  if (!initialized || cur_buffer.pos >= cur_buffer.size) {
-    if (initialized) cur_idx++;
-    if (cur_idx >= buffers.size()) {
-      finished = true;
-      return MessageType::UNINITIALIZED;
-    }
-    cur_buffer.ptr = reinterpret_cast<const uint8_t*>(static_cast<uintptr_t>(buffers[cur_idx].ptr));
-    cur_buffer.size = static_cast<int64_t>(buffers[cur_idx].size);
-    cur_buffer.pos = 0;
-    initialized = true;
-  }
-  std::memcpy(&message_prefix, ReadData(sizeof(message_prefix)), sizeof(message_prefix));
-  // An IPC *file* handed over as a buffer: skip the magic like the file reader does (ipc_file_stream_reader.cpp:116-119).
-  // The reference's buffer reader has no such case; accepting it is a superset.
-  if (cur_buffer.pos == 8 && cur_idx == 0 && std::memcmp("ARROW1\0\0", &message_prefix, 8) == 0) {
-    return ReadNextMessage();
-  }
-  if (message_prefix.continuation_token != kContinuationToken) {
-    throw IOException(std::string("Expected continuation token (0xFFFFFFFF) but got " +
-                                  std::to_string(message_prefix.continuation_token)));
-  }
-  return FinishMessage();
+  finished = true;   // every buffer is consumed (or the end-of-stream marker was seen before)
+  return MessageType::UNINITIALIZED;
 }
 
 bool IPCBufferStreamReader::DecodeHeader(idx_t message_header_size) {
-  // Our Header must contain the message prefix
-  const uint8_t* header = ReadData(static_cast<idx_t>(message_prefix.metadata_size)) - sizeof(message_prefix);
-  if (!ParseHeader(header, message_header_size)) {
-    finished = true;
-    return true;
-  }
-  return false;
+  // the decoder wants prefix + metadata as one span: the metadata follows the prefix in the caller's buffer, so the span
+  // starts where the prefix was read
+  (void)ReadData(static_cast<idx_t>(message_prefix.metadata_size));
+  const bool end_of_stream = !ParseHeader(prefix_at, message_header_size);
+  if (end_of_stream) finished = true;
+  return end_of_stream;
 }
 
 void IPCBufferStreamReader::DecodeBody() {
   cur_owner.reset();
   if (message.body_length > 0) {
     // bodies are 8-byte aligned relative to the start of the stream
-    int64_t aligned = (cur_buffer.pos + 7) & ~static_cast<int64_t>(7);
-    if (aligned != cur_buffer.pos) ReadData(static_cast<idx_t>(aligned - cur_buffer.pos));
-    cur_body_offset = cur_buffer.pos;
+    int64_t aligned = (view.pos + 7) & ~static_cast<int64_t>(7);
+    if (aligned != view.pos) ReadData(static_cast<idx_t>(aligned - view.pos));
+    cur_body_offset = view.pos;
     cur_ptr = ReadData(static_cast<idx_t>(message.body_length));
     cur_size = message.body_length;
   } else {
-    cur_body_offset = cur_buffer.pos;
+    cur_body_offset = view.pos;
     cur_ptr = nullptr;
     cur_size = 0;
   }
@@ -1502,8 +1504,8 @@ void IPCBufferStreamReader::DecodeBody() {
 
 double IPCBufferStreamReader::GetProgress() {
   if (buffers.empty()) return 100;
-  double done = static_cast<double>(cur_idx);
-  if (cur_buffer.size > 0 && cur_idx < buffers.size()) done += static_cast<double>(cur_buffer.pos) / static_cast<double>(cur_buffer.size);
+  double done = static_cast<double>(view_index);
+  if (view.size > 0 && view_index < buffers.size()) done += static_cast<double>(view.pos) / static_cast<double>(view.size);
   return std::min(100.0, 100.0 * done / static_cast<double>(buffers.size()));
 }
 
@@ -1516,8 +1518,8 @@ const std::vector<BatchIndexEntry>& IPCBufferStreamReader::BuildIndex() {
     const uint8_t* base = reinterpret_cast<const uint8_t*>(static_cast<uintptr_t>(buffers[b].ptr));
     int64_t size = static_cast<int64_t>(buffers[b].size);
     int64_t pos = 0;
-    if (b < cur_idx) { global_base += size; continue; }
-    if (b == cur_idx && initialized) pos = cur_buffer.pos;
+    if (view.opened && b < view_index) { global_base += size; continue; }
+    if (b == view_index && view.opened) pos = view.pos;
     if (pos == 0 && b == 0 && size >= 8 && std::memcmp("ARROW1\0\0", base, 8) == 0) pos = 8;
     while (pos + 8 <= size) {
       ArrowIpcMessagePrefix p;

@@ -256,15 +256,18 @@ class IPCBufferStreamReader : public IPCStreamReader {
   void DecodeBody() override;
 
  private:
-  struct Cursor {
+  //! positions `view` on the next byte of the buffer list nobody has read yet; false when there is none
+  bool SeekUnreadByte();
+  struct View {
     const uint8_t* ptr = nullptr;
+    bool opened = false;            // false until the first buffer is opened
     int64_t size = 0;
     int64_t pos = 0;
   };
   std::vector<ArrowIPCBuffer> buffers;
-  Cursor cur_buffer;
-  idx_t cur_idx = 0;
-  bool initialized = false;
+  View view;
+  idx_t view_index = 0;             // which buffer `view` is a window of
+  const uint8_t* prefix_at = nullptr;  // where the current message's prefix lies in the caller's memory
 };
 
 }  // namespace miarrow

@@ -456,7 +456,7 @@ __device__ __forceinline__ void light_map(gptr<const IN> src, gptr<OUT> out, int
 #pragma unroll
     for (int p = 0; p < GROUP; p++) {
       const int base = ((g + p) * kLightThreads + lane) * V;
-      ok[p] = base < n ? mask(base) : 0u;
+      ok[p] = mask(base);   // by every lane, also past the tile's end: the bits come from another lane's register (ds_bpermute)
       if (base + V <= n) {
         vin[p] = __builtin_nontemporal_load((gptr<const in_vec_a>)(src + base));
       } else {

@@ -109,10 +109,13 @@ ArrowScan::~ArrowScan() {
 }
 
 ArrowScan::DictState::~DictState() {
+  decode_plan.reset();
   if (d_data) (void)hipFree(d_data);
   if (d_validity) (void)hipFree(d_validity);
   if (h_data) (void)hipHostFree(h_data);
-  if (h_validity) (void)hipHostFree(h_validity);
+  if (h_words) (void)hipHostFree(h_words);   // h_validity is the same memory
+  if (h_status) (void)hipHostFree(h_status);
+  if (uploaded) (void)hipEventDestroy(uploaded);
 }
 
 void ArrowScan::OpenSource(size_t i) {
@@ -433,37 +436,49 @@ void ArrowScan::DecodeDictionary(Source& src, const DecodedBatch& b) {
   if (b.owner) d->host_bodies.push_back(b.owner);
   const size_t data_bytes = RoundUp(static_cast<size_t>(n + 1) * static_cast<size_t>(w));
   const size_t valid_bytes = RoundUp(static_cast<size_t>((n + 1 + 63) / 64) * 8);
+  // Nothing below waits for the device: the body goes up on the copy stream, the values are decoded on the compute stream
+  // behind it (the record batches that use the dictionary follow on the same stream), the decode's status word comes back
+  // with the first such batch (DictState::h_status, checked in AcquireBatch).  The validity words are built on the host
+  // from the Arrow bitmap (the value types admitted above are flat: a value is NULL exactly when its bit says so).
   MI_HIP_CHECK(hipMalloc(&d->d_data, data_bytes));
   MI_HIP_CHECK(hipMalloc(&d->d_validity, valid_bytes));
-  MI_HIP_CHECK(hipMemset(d->d_data, 0, data_bytes));
-  MI_HIP_CHECK(hipStreamSynchronize(nullptr));   // the null stream is not ordered with the (non-blocking) streams the plans run on
+  MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&d->h_words), valid_bytes, hipHostMallocDefault));
+  MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&d->h_status), 64, hipHostMallocDefault));
+  d->h_status[0] = 0;
+  MI_HIP_CHECK(hipMemsetAsync(d->d_data, 0, data_bytes, ctx->stream));
   uint8_t* heap = nullptr;
   if (b.body_size > 0) {
     void* p = nullptr;
     MI_HIP_CHECK(hipMalloc(&p, RoundUp(static_cast<size_t>(b.body_size) + 16)));
     d->d_heaps.push_back(std::shared_ptr<void>(p, [](void* q) { (void)hipFree(q); }));
     heap = static_cast<uint8_t*>(p);
-    MI_HIP_CHECK(hipMemcpy(heap, b.body, static_cast<size_t>(b.body_size), hipMemcpyHostToDevice));
+    // the body is pinned (the read-ahead's allocator for DICTIONARY_BATCH messages) and lives in host_bodies
+    MI_HIP_CHECK(hipMemcpyAsync(heap, b.body, static_cast<size_t>(b.body_size), hipMemcpyHostToDevice, ctx->h2d_stream));
+    if (!d->uploaded) MI_HIP_CHECK(hipEventCreateWithFlags(&d->uploaded, hipEventDisableTiming));
+    MI_HIP_CHECK(hipEventRecord(d->uploaded, ctx->h2d_stream));
+    MI_HIP_CHECK(hipStreamWaitEvent(ctx->stream, d->uploaded, 0));
   }
   if (n_old > 0)
-    MI_HIP_CHECK(hipMemcpy(d->d_data, old->d_data, static_cast<size_t>(n_old) * static_cast<size_t>(w), hipMemcpyDeviceToDevice));
-  std::vector<uint64_t> words(valid_bytes / 8, ~0ull);
+    MI_HIP_CHECK(hipMemcpyAsync(d->d_data, old->d_data, static_cast<size_t>(n_old) * static_cast<size_t>(w), hipMemcpyDeviceToDevice, ctx->stream));
+  uint64_t* words = d->h_words;
+  for (size_t i = 0; i < valid_bytes / 8; i++) words[i] = ~0ull;
   auto set_bit = [&](int64_t i, bool v) {
     if (v) words[static_cast<size_t>(i >> 6)] |= 1ull << (i & 63);
     else words[static_cast<size_t>(i >> 6)] &= ~(1ull << (i & 63));
   };
-  if (n_old > 0) {
-    std::vector<uint64_t> ow(static_cast<size_t>((n_old + 63) / 64));
-    MI_HIP_CHECK(hipMemcpy(ow.data(), old->d_validity, ow.size() * 8, hipMemcpyDeviceToHost));
-    for (int64_t i = 0; i < n_old; i++) set_bit(i, (ow[static_cast<size_t>(i >> 6)] >> (i & 63)) & 1);
+  for (int64_t i = 0; i < n_old; i++) set_bit(i, old->host_valid[static_cast<size_t>(i)] != 0);
+  {
+    const mi_buffer_span* sp = &b.buffers[0];
+    const bool has_bitmap = sp[0].length > 0 && b.null_count[0] != 0;
+    if (has_bitmap && sp[0].length < (n_new + 7) / 8) throw InternalException("Arrow IPC validation failed: dictionary validity bitmap is too short");
+    for (int64_t i = 0; i < n_new; i++) set_bit(n_old + i, !has_bitmap || ((b.body[sp[0].offset + (i >> 3)] >> (i & 7)) & 1));
   }
   if (n_new > 0) {
-    // decode the new values into a tile-aligned scratch vector, then append
+    // decode the new values into a tile-aligned scratch vector, then append (the scratch lives as long as the version:
+    // freeing it here would wait for the device)
     void* scratch_data = nullptr;
-    void* scratch_valid = nullptr;
     MI_HIP_CHECK(hipMalloc(&scratch_data, RoundUp(static_cast<size_t>(n_new) * static_cast<size_t>(w) + 16)));
-    MI_HIP_CHECK(hipMalloc(&scratch_valid, RoundUp(static_cast<size_t>((n_new + 63) / 64) * 8 + 8)));
-    std::shared_ptr<void> g1(scratch_data, [](void* q) { (void)hipFree(q); }), g2(scratch_valid, [](void* q) { (void)hipFree(q); });
+    d->d_heaps.push_back(std::shared_ptr<void>(scratch_data, [](void* q) { (void)hipFree(q); }));
     mi_col_task t;
     std::memset(&t, 0, sizeof(t));
     const mi_buffer_span* sp = &b.buffers[0];
@@ -472,31 +487,28 @@ void ArrowScan::DecodeDictionary(Source& src, const DecodedBatch& b) {
     t.buf2 = nb > 2 ? heap + sp[2].offset : nullptr;
     t.buf2_len = nb > 2 ? sp[2].length : 0;
     t.out_data = scratch_data;
-    t.out_validity = scratch_valid;
+    t.out_validity = nullptr;   // built on the host, above
     const int64_t data_off = nb > 2 ? sp[2].offset : sp[1].offset;
     t.ptr_base = opts.device_resident ? reinterpret_cast<uint64_t>(heap + data_off) : reinterpret_cast<uint64_t>(b.body + data_off);
     t.nrows = n_new;
     t.null_count = b.null_count[0];
     t.kind = kind;
     t.param = param;
-    Plan plan(ctx, &t, 1);
-    plan.Launch(ctx->stream);
-    ThrowForStatus(plan.Status());
-    MI_HIP_CHECK(hipMemcpy(static_cast<uint8_t*>(d->d_data) + static_cast<size_t>(n_old) * static_cast<size_t>(w), scratch_data,
-                           static_cast<size_t>(n_new) * static_cast<size_t>(w), hipMemcpyDeviceToDevice));
-    std::vector<uint64_t> nw(static_cast<size_t>((n_new + 63) / 64));
-    MI_HIP_CHECK(hipMemcpy(nw.data(), scratch_valid, nw.size() * 8, hipMemcpyDeviceToHost));
-    for (int64_t i = 0; i < n_new; i++) set_bit(n_old + i, (nw[static_cast<size_t>(i >> 6)] >> (i & 63)) & 1);
+    d->decode_plan = std::make_unique<Plan>(ctx, &t, 1);
+    d->decode_plan->Launch(ctx->stream);
+    MI_HIP_CHECK(hipMemcpyAsync(static_cast<uint8_t*>(d->d_data) + static_cast<size_t>(n_old) * static_cast<size_t>(w), scratch_data,
+                                static_cast<size_t>(n_new) * static_cast<size_t>(w), hipMemcpyDeviceToDevice, ctx->stream));
+    MI_HIP_CHECK(hipMemcpyAsync(d->h_status, d->decode_plan->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   }
-  // string-valued dictionaries keep their values on the host too (validated by the decode above): pushed-down string
-  // predicates are matched against the dictionary once and against the rows by index
+  // string-valued dictionaries keep their values on the host too: pushed-down string predicates are matched against the
+  // dictionary once and against the rows by index (the offsets are validated here; the device validates them again)
   d->host_valid.resize(static_cast<size_t>(n));
   for (int64_t i = 0; i < n; i++) d->host_valid[static_cast<size_t>(i)] = (words[static_cast<size_t>(i >> 6)] >> (i & 63)) & 1;
   if (kind == MI_K_STR32 || kind == MI_K_STR64 || kind == MI_K_FIXED_BINARY) {
     if (delta) d->host_strings = old->host_strings;
     const mi_buffer_span* sp = &b.buffers[0];
     for (int64_t i = 0; i < n_new; i++) {
-      const bool ok = sp[0].length == 0 || ((b.body[sp[0].offset + (i >> 3)] >> (i & 7)) & 1);
+      const bool ok = d->host_valid[static_cast<size_t>(n_old + i)] != 0;
       std::string v;
       if (ok) {
         if (kind == MI_K_FIXED_BINARY) {
@@ -520,12 +532,13 @@ void ArrowScan::DecodeDictionary(Source& src, const DecodedBatch& b) {
     }
   }
   set_bit(n, false);  // the extra NULL entry at index dict_len (ColumnArrowToDuckDBDictionary)
-  MI_HIP_CHECK(hipMemcpy(d->d_validity, words.data(), valid_bytes, hipMemcpyHostToDevice));
+  MI_HIP_CHECK(hipMemcpyAsync(d->d_validity, words, valid_bytes, hipMemcpyHostToDevice, ctx->stream));
   if (!opts.device_resident) {
+    // host consumers read the values from pinned memory: the copy rides the compute stream too, and every batch that uses
+    // the dictionary is handed out only after its own results have come back behind it
     MI_HIP_CHECK(hipHostMalloc(&d->h_data, data_bytes, hipHostMallocDefault));
-    MI_HIP_CHECK(hipHostMalloc(&d->h_validity, valid_bytes, hipHostMallocDefault));
-    MI_HIP_CHECK(hipMemcpy(d->h_data, d->d_data, data_bytes, hipMemcpyDeviceToHost));
-    std::memcpy(d->h_validity, words.data(), valid_bytes);
+    MI_HIP_CHECK(hipMemcpyAsync(d->h_data, d->d_data, data_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    d->h_validity = words;   // the same pinned words
   }
   dicts[b.dict_id] = d;
 }
@@ -788,10 +801,17 @@ void ArrowScan::EnqueueBatch(Slot& s) {
               codes[static_cast<size_t>(e)] = !dict->host_valid[static_cast<size_t>(e)] ? 2
                                               : (leaf.is_string && std::binary_search(leaf.str_values.begin(), leaf.str_values.end(), dict->host_strings[static_cast<size_t>(e)])) ? 1 : 0;
             codes[static_cast<size_t>(dict->dict_len)] = 2;   // the NULL entry rows without a value point at
+            // device copy + its pinned source, uploaded on the compute stream in front of the filter kernel that reads it
             void* p = nullptr;
+            void* hp = nullptr;
             MI_HIP_CHECK(hipMalloc(&p, RoundUp(codes.size() + 16)));
-            std::shared_ptr<void> keep(p, [](void* q) { (void)hipFree(q); });
-            MI_HIP_CHECK(hipMemcpy(p, codes.data(), codes.size(), hipMemcpyHostToDevice));
+            MI_HIP_CHECK(hipHostMalloc(&hp, RoundUp(codes.size() + 16), hipHostMallocDefault));
+            std::shared_ptr<void> keep(p, [hp](void* q) {
+              (void)hipFree(q);
+              (void)hipHostFree(hp);
+            });
+            std::memcpy(hp, codes.data(), codes.size());
+            MI_HIP_CHECK(hipMemcpyAsync(p, hp, codes.size(), hipMemcpyHostToDevice, ctx->stream));
             it = dict->match_maps.emplace(li, std::move(keep)).first;
           }
           L.op = device::kLeafDictMap;
@@ -1458,7 +1478,10 @@ bool ArrowScan::AcquireBatch(BatchRef* out) {
       stats.lz4_parse_rounds += s.h_status[6];
       stats.lz4_parse_rounds_max = std::max<int64_t>(stats.lz4_parse_rounds_max, s.h_status[5]);
     }
-    ThrowForStatus(s.h_status[0] | s.h_status[1] | s.h_status[2]);
+    uint32_t dict_status = 0;   // the decode of the dictionary versions this batch uses ran in front of it on the same stream
+    for (auto& nd : s.node_dict)
+      if (nd && nd->h_status) dict_status |= nd->h_status[0];
+    ThrowForStatus(s.h_status[0] | s.h_status[1] | s.h_status[2] | dict_status);
   } catch (...) {
     s.busy = false;
     s.batch.owner.reset();

@@ -163,7 +163,11 @@ class ArrowScan : public ScanBase {
     void* d_data = nullptr;        // decoded values on the device
     void* d_validity = nullptr;
     void* h_data = nullptr;        // pinned host copy (host consumers)
-    void* h_validity = nullptr;
+    void* h_validity = nullptr;    // == h_words for host consumers
+    uint64_t* h_words = nullptr;   // pinned: the validity words as built on the host (uploaded from here)
+    uint32_t* h_status = nullptr;  // pinned: status word of the decode of the values, checked with the first batch that uses them
+    hipEvent_t uploaded = nullptr; // the dictionary body is in HBM
+    std::unique_ptr<Plan> decode_plan;   // kept until the version dies: its status word is read asynchronously
     std::vector<std::shared_ptr<void>> d_heaps;      // device copies of the dictionary bodies (long string payload)
     std::vector<std::shared_ptr<void>> host_bodies;  // host bodies: long dictionary strings point into them
     int64_t dict_len = 0;

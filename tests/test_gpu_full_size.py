@@ -114,7 +114,7 @@ def test_sf10_fused_q6_equals_torch_on_decoded_vectors(sf10, tmp_path_factory):
 def test_config5_commits_shape_bit_exact_and_equal_to_pyarrow():
     """BASELINE configs[4] ("config 5" of SURVEY 8d) at its shape: arrow-commits columns (40-byte commit, ts[us, UTC], int32,
     bool, 9-513 byte message) with 10 % NULLs in every nullable column and two dictionary-encoded columns (int32 indices),
-    1 228 800 rows in 10 record batches, resident in HBM.  Every batch bit-exact against the oracle (dictionaries included);
+    1 230 704 rows in 11 record batches (the last one 1 904 rows: a ragged final tile), resident in HBM.  Every batch bit-exact against the oracle (dictionaries included);
     validity words and fixed-width values of every batch, and all values of the first and the last batch, equal pyarrow's
     reading of the same stream.  Beyond the reference, which cannot read dictionary-encoded IPC at all
     (src/ipc/stream_reader/base_stream_reader.cpp:86-96): parity for K5 is pinned by pyarrow, not by the reference."""
@@ -129,7 +129,7 @@ def test_config5_commits_shape_bit_exact_and_equal_to_pyarrow():
     from helpers import canon_stream, pyarrow_columns
     from test_gpu_decode_parity import assert_streams_equal
 
-    n_rows = 1228800
+    n_rows = 1228800 + 1904
     buf = commits_stream(n_rows)
     ctx = da.Context(0)
     hs = HbmStream(ctx, buf, accept_dictionaries=True)
@@ -137,7 +137,7 @@ def test_config5_commits_shape_bit_exact_and_equal_to_pyarrow():
     assert hs.status() == 0
     got = hs.fetch()
     fields, want = po.decode_stream(buf)
-    assert len(got) == 10 and sum(b["nrows"] for b in got) == n_rows
+    assert len(got) == 11 and got[-1]["nrows"] == 1904 and sum(b["nrows"] for b in got) == n_rows
     assert_streams_equal(got, want)
     for gb, wb in zip(got, want):
         for gc, wc in zip(gb["columns"], wb["columns"]):
