@@ -436,11 +436,12 @@ class Relation:
     def filter(self, expr):
         """Pushed-down predicate tree (mi_scan_set_filter).  `expr` is nested tuples:
             ("and", e1, e2, ...) | ("or", e1, e2, ...) | (column, op, value) with op in = <> != < <= > >= |
-            (column, "in", [values]) | (column, "is null") | (column, "is not null")
-        Constants are the stored integers, or str / bytes for VARCHAR / BLOB columns (= <> in only).  NULL semantics are
+            (column, "in", [values]) | (column, "is null") | (column, "is not null") | (column, "starts_with", prefix)
+        Constants are the stored integers, or str / bytes for VARCHAR / BLOB columns (byte-wise order).  NULL semantics are
         SQL's: a comparison with NULL is not true."""
         ops = {"=": _ffi.F_EQ, "==": _ffi.F_EQ, "<>": _ffi.F_NE, "!=": _ffi.F_NE, "<": _ffi.F_LT, "<=": _ffi.F_LE,
-               ">": _ffi.F_GT, ">=": _ffi.F_GE, "is null": _ffi.F_IS_NULL, "is not null": _ffi.F_IS_NOT_NULL, "in": _ffi.F_IN}
+               ">": _ffi.F_GT, ">=": _ffi.F_GE, "is null": _ffi.F_IS_NULL, "is not null": _ffi.F_IS_NOT_NULL, "in": _ffi.F_IN,
+               "starts_with": _ffi.F_STARTS_WITH}
         nodes, keep = [None], []
 
         def emit(at, e):

@@ -88,7 +88,7 @@ class FilterNode(C.Structure):
                 ("str_values", C.POINTER(C.c_char_p)), ("str_lens", C.POINTER(C.c_int32))]
 
 
-F_EQ, F_NE, F_LT, F_LE, F_GT, F_GE, F_IS_NULL, F_IS_NOT_NULL, F_IN, F_AND, F_OR = 1, 2, 3, 4, 5, 6, 7, 8, 9, 16, 17
+F_EQ, F_NE, F_LT, F_LE, F_GT, F_GE, F_IS_NULL, F_IS_NOT_NULL, F_IN, F_STARTS_WITH, F_AND, F_OR = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 16, 17
 
 
 class HbmOptions(C.Structure):

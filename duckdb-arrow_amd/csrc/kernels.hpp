@@ -121,6 +121,8 @@ constexpr int kLeafStrIn = 5;       // string_t column: the row equals one of n_
                                     // dword1..3 are the string_t image (inline bytes, or prefix + 0 + 0 for > 12 bytes)
 constexpr int kLeafDictMap = 6;     // dictionary-encoded string column: data = the uint32 selection vector, in_values = one byte per
                                     // dictionary entry (n_in of them; 0 no, 1 yes, 2 NULL entry), lo = 0 match, 1 no match, 2 IS NULL, 3 IS NOT NULL
+constexpr int kLeafStrRange = 7;    // string_t column: lower bound <(=) row <(=) upper bound, byte-wise.  in_values: two constants in kLeafStrIn's
+                                    // layout (lower, upper); n_in = bit 0 has lower, bit 1 lower inclusive, bit 2 has upper, bit 3 upper inclusive
 constexpr int kLeafUnsigned = 1;    // flags: the column holds unsigned integers
 constexpr int kLeafNegate = 2;      //        NOT (range / in-list); NULL still fails
 constexpr int kLeafEndsClause = 4;

@@ -119,6 +119,63 @@ __device__ __forceinline__ void leaf_strin(const FilterLeafDev& L, int64_t first
   }
 }
 
+// kLeafStrRange: lower <(=) row <(=) upper in byte-wise order (memcmp over the common length, then the shorter string first:
+// DuckDB's string_t comparison).  The first four bytes decide most rows: a string_t keeps them in dword 1, zero padded, so the
+// byte-swapped dwords compare like the strings do unless they are equal; then the bytes from 4 on are walked -- inline
+// strings from the row's own registers, longer ones from the heap -- and at last the lengths.
+__device__ __forceinline__ int strrow_compare(const u32x4& s, gptr<const uint8_t> heap, uint64_t ptr_base, uint32_t clen, uint32_t cw1,
+                                              gptr<const uint8_t> cbytes) {
+  const uint32_t pr = __builtin_bswap32(s.y), pc = __builtin_bswap32(cw1);
+  if (pr != pc) return pr < pc ? -1 : 1;
+  const uint32_t rlen = s.x, m = rlen < clen ? rlen : clen;
+  if (m > 4) {
+    gptr<const uint8_t> a = nullptr;
+    if (rlen > 12) {
+      const uint64_t p = static_cast<uint64_t>(s.z) | (static_cast<uint64_t>(s.w) << 32);
+      a = heap + (p - ptr_base);
+    }
+    for (uint32_t i = 4; i < m; i++) {
+      const uint32_t rb = rlen > 12 ? a[i] : ((i < 8 ? s.z : s.w) >> (8 * (i & 3))) & 0xFFu;
+      const uint32_t cb = cbytes[i];
+      if (rb != cb) return rb < cb ? -1 : 1;
+    }
+  }
+  return rlen < clen ? -1 : rlen > clen ? 1 : 0;
+}
+
+__device__ __forceinline__ void leaf_strrange(const FilterLeafDev& L, int64_t first_window, int64_t nrows, int r, uint32_t (&m)[kFilterWindows]) {
+  gptr<const u32x4> rows = GC<u32x4>(L.data);
+  gptr<const uint8_t> heap = GC<uint8_t>(reinterpret_cast<const void*>(static_cast<uintptr_t>(L.lo)));
+  const uint64_t ptr_base = static_cast<uint64_t>(L.hi);
+  const bool has_lo = (L.n_in & 1) != 0, lo_incl = (L.n_in & 2) != 0, has_hi = (L.n_in & 4) != 0, hi_incl = (L.n_in & 8) != 0;
+  const uint64_t l0 = static_cast<uint64_t>(L.in_values[0]), h0 = static_cast<uint64_t>(L.in_values[3]);
+  gptr<const uint8_t> lbytes = GC<uint8_t>(reinterpret_cast<const void*>(static_cast<uintptr_t>(L.in_values[2])));
+  gptr<const uint8_t> hbytes = GC<uint8_t>(reinterpret_cast<const void*>(static_cast<uintptr_t>(L.in_values[5])));
+#pragma clang loop unroll(disable)
+  for (int w = 0; w < kFilterWindows; w++) {
+    const int64_t row0 = (first_window + w) * kTileRows;
+    const int64_t left = nrows - row0;
+    const int n = left < kTileRows ? static_cast<int>(left < 0 ? 0 : left) : kTileRows;
+    uint32_t mm = 0;
+#pragma clang loop unroll(disable)
+    for (int k = 0; k < 8; k++) {
+      if (r + k >= n) break;
+      const u32x4 s = __builtin_nontemporal_load(rows + row0 + r + k);
+      bool ok = true;
+      if (has_lo) {
+        const int c = strrow_compare(s, heap, ptr_base, static_cast<uint32_t>(l0), static_cast<uint32_t>(l0 >> 32), lbytes);
+        ok = c > 0 || (c == 0 && lo_incl);
+      }
+      if (ok && has_hi) {
+        const int c = strrow_compare(s, heap, ptr_base, static_cast<uint32_t>(h0), static_cast<uint32_t>(h0 >> 32), hbytes);
+        ok = c < 0 || (c == 0 && hi_incl);
+      }
+      mm |= ok ? (1u << k) : 0u;
+    }
+    m[w] = mm;
+  }
+}
+
 // kLeafDictMap: a string predicate on a dictionary-encoded column was evaluated once per dictionary (on the host: one byte per
 // entry: 0 no, 1 yes, 2 the entry is NULL); a row passes by looking its index up -- 4 bytes per row instead of a string_t and
 // its heap bytes.  Rows without a value point at the extra NULL entry (index dict_len), so the row validity is not needed, and
@@ -187,6 +244,7 @@ __global__ __launch_bounds__(kBlockThreads) void filter_program(const FilterProg
       for (int w = 0; w < kFilterWindows; w++) m[w] = L.op == kLeafIsNull ? (~vb[w] & 0xFFu) : vb[w];
     } else {
       if (L.op == kLeafStrIn) leaf_strin(L, first_window, nrows, r, m);
+      else if (L.op == kLeafStrRange) leaf_strrange(L, first_window, nrows, r, m);
       else if (L.op == kLeafDictMap) leaf_dictmap(L, first_window, nrows, r, m);
       else switch (L.width) {
         case 1: leaf_compare<int8_t>(L, first_window, nrows, r, m); break;

@@ -39,8 +39,40 @@ FilterLeaf LeafOf(const mi_filter_node& n) {
         if (n.n_values > 256) throw NotImplementedException("IN-list with more than 256 values is not pushed down");
         for (int32_t k = 0; k < n.n_values; k++) add(n.str_values[k], n.str_lens[k]);
         break;
+      case MI_F_LT: case MI_F_LE: case MI_F_GT: case MI_F_GE: case MI_F_STARTS_WITH: {
+        // ordering and prefix tests: one range leaf [lower, upper] with open / closed ends (byte-wise order)
+        if (!n.str_value || n.str_len < 0) throw InvalidInputException("string filter constant without bytes");
+        const std::string c(n.str_value, static_cast<size_t>(n.str_len));
+        l.op = device::kLeafStrRange;
+        l.str_values.assign(2, std::string());
+        l.lo_open = l.hi_open = true;
+        if (n.op == MI_F_LT || n.op == MI_F_LE) {
+          l.str_values[1] = c;
+          l.hi_open = false;
+          l.hi_incl = n.op == MI_F_LE;
+        } else if (n.op == MI_F_GT || n.op == MI_F_GE) {
+          l.str_values[0] = c;
+          l.lo_open = false;
+          l.lo_incl = n.op == MI_F_GE;
+        } else {
+          // begins with c  <=>  c <= row < successor(c), the successor being c with its last byte that is not 0xFF
+          // incremented and everything behind it dropped (all 0xFF or empty: no upper bound)
+          l.str_values[0] = c;
+          l.lo_open = false;
+          l.lo_incl = true;
+          std::string up = c;
+          while (!up.empty() && static_cast<unsigned char>(up.back()) == 0xFF) up.pop_back();
+          if (!up.empty()) {
+            up.back() = static_cast<char>(static_cast<unsigned char>(up.back()) + 1);
+            l.str_values[1] = up;
+            l.hi_open = false;
+            l.hi_incl = false;
+          }
+        }
+        return l;
+      }
       default:
-        throw NotImplementedException("only =, <> and IN are pushed down on VARCHAR / BLOB columns (column '" + l.column + "')");
+        throw NotImplementedException("this comparison is not pushed down on VARCHAR / BLOB columns (column '" + l.column + "')");
     }
     std::sort(l.str_values.begin(), l.str_values.end());
     l.str_values.erase(std::unique(l.str_values.begin(), l.str_values.end()), l.str_values.end());

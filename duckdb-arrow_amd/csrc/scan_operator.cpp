@@ -294,7 +294,7 @@ void ArrowScan::Init(const std::vector<std::string>& projected) {
         if (leaf.op == device::kLeafIn) {
           MI_HIP_CHECK(hipMalloc(&p, leaf.in_values.size() * 8));
           MI_HIP_CHECK(hipMemcpy(p, leaf.in_values.data(), leaf.in_values.size() * 8, hipMemcpyHostToDevice));
-        } else if (leaf.op == device::kLeafStrIn && !leaf.str_values.empty()) {
+        } else if ((leaf.op == device::kLeafStrIn || leaf.op == device::kLeafStrRange) && !leaf.str_values.empty()) {
           // 3 words per constant (its string_t image + the device address of its bytes), the bytes behind the table
           const size_t nc = leaf.str_values.size();
           size_t bytes = 0;
@@ -767,6 +767,8 @@ void ArrowScan::EnqueueBatch(Slot& s) {
         L.hi = leaf.hi;
         L.in_values = static_cast<const int64_t*>(d_in_lists[li]);
         L.n_in = static_cast<int32_t>(leaf.is_string ? leaf.str_values.size() : leaf.in_values.size());
+        if (leaf.op == device::kLeafStrRange)
+          L.n_in = (leaf.lo_open ? 0 : 1) | (leaf.lo_incl ? 2 : 0) | (leaf.hi_open ? 0 : 4) | (leaf.hi_incl ? 8 : 0);
         L.width = 1;
         if (root < 0) {
           // the column is absent from this file (union_by_name): every row is NULL -- IS NULL keeps every row, everything
@@ -797,9 +799,25 @@ void ArrowScan::EnqueueBatch(Slot& s) {
           auto it = dict->match_maps.find(li);
           if (it == dict->match_maps.end()) {
             std::vector<uint8_t> codes(static_cast<size_t>(dict->dict_len) + 1, 0);
+            auto passes = [&](const std::string& v) {   // std::string compares byte-wise (unsigned), a proper prefix first
+              if (leaf.op != device::kLeafStrRange) return std::binary_search(leaf.str_values.begin(), leaf.str_values.end(), v);
+              auto cmp = [](const std::string& a, const std::string& b) {
+                const int c = std::memcmp(a.data(), b.data(), std::min(a.size(), b.size()));
+                return c != 0 ? c : (a.size() < b.size() ? -1 : a.size() > b.size() ? 1 : 0);
+              };
+              if (!leaf.lo_open) {
+                const int c = cmp(v, leaf.str_values[0]);
+                if (c < 0 || (c == 0 && !leaf.lo_incl)) return false;
+              }
+              if (!leaf.hi_open) {
+                const int c = cmp(v, leaf.str_values[1]);
+                if (c > 0 || (c == 0 && !leaf.hi_incl)) return false;
+              }
+              return true;
+            };
             for (int64_t e = 0; e < dict->dict_len; e++)
               codes[static_cast<size_t>(e)] = !dict->host_valid[static_cast<size_t>(e)] ? 2
-                                              : (leaf.is_string && std::binary_search(leaf.str_values.begin(), leaf.str_values.end(), dict->host_strings[static_cast<size_t>(e)])) ? 1 : 0;
+                                              : (leaf.is_string && passes(dict->host_strings[static_cast<size_t>(e)])) ? 1 : 0;
             codes[static_cast<size_t>(dict->dict_len)] = 2;   // the NULL entry rows without a value point at
             // device copy + its pinned source, uploaded on the compute stream in front of the filter kernel that reads it
             void* p = nullptr;

@@ -51,6 +51,8 @@ struct FilterLeaf {
   std::vector<int64_t> in_values;
   bool is_string = false;         // kLeafStrIn: the column is VARCHAR / BLOB, the row passes when it equals one of ...
   std::vector<std::string> str_values;   // ... these byte strings (negate: none of them)
+  //! kLeafStrRange: str_values = {lower, upper}; lo_open / hi_open = no such bound, the two below = the bound itself passes
+  bool lo_incl = false, hi_incl = false;
   int32_t out_col = -1;           // resolved at Init: index into the scan's filter columns
 };
 //! Conjunctive normal form: every clause is an OR of leaves, the filter is the AND of its clauses.

@@ -418,9 +418,11 @@ class MiFilterTranslator {
 
   bool SetConstant(mi_filter_node& n, const Value& v) {
     if (v.type().id() == LogicalTypeId::VARCHAR || v.type().id() == LogicalTypeId::BLOB) {
-      if (v.IsNull() || (n.op != MI_F_EQ && n.op != MI_F_NE)) {
-        return false;  // ordering on strings stays above the scan unless the library accepts it
+      if (v.IsNull()) {
+        return false;
       }
+      // = <> < <= > >= : byte-wise, like string_t's own comparison (a column with a non-default collation never gets here: its
+      // comparisons arrive wrapped in collation functions, which are not column references)
       out.strings.push_back(make_uniq<string>(StringValue::Get(v)));
       n.str_value = out.strings.back()->data();
       n.str_len = NumericCast<int32_t>(out.strings.back()->size());

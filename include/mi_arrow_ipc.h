@@ -538,14 +538,16 @@ typedef struct mi_data_chunk {
  * hands a scan: col <op> constant with = <> < <= > >=, IS NULL, IS NOT NULL, IN (list), combined
  * by AND / OR trees over any number of columns.  Comparison columns are fixed-width integer-like after the scan
  * (integers, BOOLEAN, DATE, TIME / TIMESTAMP, DECIMAL(<=18)) and constants are the stored integers (DECIMAL(15,2) 0.05
- * is 5), or VARCHAR / BLOB columns with = <> IN against byte strings; IS [NOT] NULL takes any column.  SQL semantics: a comparison with NULL is not true, so the row is dropped
+ * is 5), or VARCHAR / BLOB columns with = <> < <= > >= IN and MI_F_STARTS_WITH against byte strings (byte-wise order,
+ * a proper prefix sorts first: DuckDB's default collation); IS [NOT] NULL takes any column.  SQL semantics: a comparison with NULL is not true, so the row is dropped
  * unless another branch of an OR keeps it.  A filter column need not be projected.  The tree is normalised to at most
  * 24 leaves in conjunctive normal form; larger ones are refused with MI_ENOTSUP (DuckDB then keeps the filter above the
  * scan).  Chunks carry a selection vector (or only the selected rows: mi_scan_options.filter_compact).  Call between
  * bind and init. */
 enum mi_filter_op {
   MI_F_EQ = 1, MI_F_NE = 2, MI_F_LT = 3, MI_F_LE = 4, MI_F_GT = 5, MI_F_GE = 6, MI_F_IS_NULL = 7, MI_F_IS_NOT_NULL = 8,
-  MI_F_IN = 9, MI_F_AND = 16, MI_F_OR = 17
+  MI_F_IN = 9, MI_F_STARTS_WITH = 10 /* VARCHAR / BLOB: the row begins with str_value (LIKE 'abc%', prefix()) */,
+  MI_F_AND = 16, MI_F_OR = 17
 };
 typedef struct mi_filter_node {
   int32_t op;             /* enum mi_filter_op */
@@ -555,9 +557,9 @@ typedef struct mi_filter_node {
   const char* column;     /* leaves */
   int64_t value;          /* comparison constant */
   const int64_t* values;  /* MI_F_IN */
-  /* VARCHAR / BLOB columns (utf8, large_utf8, binary, fixed_size_binary, dictionary-encoded or not): MI_F_EQ / MI_F_NE take str_value (str_len bytes, no
-   * terminator needed), MI_F_IN takes str_values / str_lens; byte-wise equality like DuckDB's.  Leave NULL for the
-   * integer forms above.  Ordering comparisons on strings are not pushed down (MI_ENOTSUP). */
+  /* VARCHAR / BLOB columns (utf8, large_utf8, binary, fixed_size_binary, dictionary-encoded or not): MI_F_EQ / MI_F_NE /
+   * MI_F_LT / MI_F_LE / MI_F_GT / MI_F_GE / MI_F_STARTS_WITH take str_value (str_len bytes, no terminator needed), MI_F_IN
+   * takes str_values / str_lens; byte-wise comparison like DuckDB's.  Leave NULL for the integer forms above. */
   const char* str_value;
   int32_t str_len;
   int32_t _pad;

@@ -457,7 +457,7 @@ def filter_cnf(clauses, columns, n):
     """The rows [0, n) that pass AND-of-ORs `clauses` = [[(column, op, value), ...], ...] over `columns` =
     {name: (data ndarray of the stored integers, validity uint64 words or None)} -> ascending row indices (orc_filter_cnf).
     A column may also be a python list of bytes / str / None (VARCHAR, BLOB): then the whole predicate is evaluated here,
-    row by row, with SQL's rules (a comparison with NULL is not true; = <> IN compare bytes)."""
+    row by row, with SQL's rules (a comparison with NULL is not true; bytes compare byte-wise, a proper prefix first)."""
     if any(isinstance(columns[leaf[0]], list) or isinstance(columns[leaf[0]][0], list) for clause in clauses for leaf in clause):
         def value(col, i):
             c = columns[col]
@@ -484,6 +484,8 @@ def filter_cnf(clauses, columns, n):
             if op == "in":
                 return v in [norm(c) for c in leaf[2]]
             c = norm(leaf[2])
+            if op == "starts_with":
+                return v.startswith(c)
             return {"=": v == c, "==": v == c, "<>": v != c, "!=": v != c, "<": v < c, "<=": v <= c, ">": v > c, ">=": v >= c}[op]
         return np.array([i for i in range(n) if all(any(leaf_true(l, i) for l in clause) for clause in clauses)], np.uint32)
     leaves, keep = [], []

@@ -1,4 +1,4 @@
-"""K6 on VARCHAR / BLOB columns: =, <>, IN against byte strings, alone and inside AND / OR trees with integer leaves, with
+"""K6 on VARCHAR / BLOB columns: =, <>, <, <=, >, >=, IN and starts_with (LIKE 'abc%') against byte strings, alone and inside AND / OR trees with integer leaves, with
 selection vectors and with late materialisation.  The reference pushes no filters (filter_pushdown = false,
 src/scanner/read_arrow.cpp:47-48), DuckDB's filter above the scan keeps the same rows: the check is python's own evaluation
 of the predicate over pyarrow's values, and the oracle's scalar CNF evaluator (SQL rules: a comparison with NULL is not
@@ -55,7 +55,9 @@ def _eval(expr, cols, i):
     if op == "in":
         return v in [norm(c) for c in expr[2]]
     c = norm(expr[2])
-    return {"=": v == c, "<>": v != c, "<": v < c, ">=": v >= c}[op]
+    if op == "starts_with":
+        return v.startswith(c)
+    return {"=": v == c, "<>": v != c, "<": v < c, "<=": v <= c, ">": v > c, ">=": v >= c}[op]   # bytes: byte-wise, a proper prefix first
 
 
 EXPRS = [
@@ -67,6 +69,15 @@ EXPRS = [
     ("and", ("mode", "in", ["MAIL", "SHIP"]), ("q", "<", 24), ("instr", "=", "DELIVER IN PERSON")),          # TPC-H Q12 / Q19 shapes
     ("or", ("flag", "=", "R"), ("and", ("mode", "=", "AIR"), ("q", ">=", 40)), ("instr", "is null")),
     ("and", ("or", ("mode", "=", "FOB"), ("mode", "is null")), ("long", "<>", LONG[1])),
+    # ordering and prefixes (DuckDB's default collation: byte-wise, a proper prefix sorts first)
+    ("mode", "<", "REG AIR"), ("mode", ">=", "SHIP"), ("mode", ">", "RAIL"), ("mode", "<=", "AIR"), ("mode", "<", "REG"),
+    ("instr", "<=", "DELIVER IN PERSON"), ("instr", ">", "DELIVER IN PERSO"), ("instr", "<", "DELIVER IN PERSON AND MORE"),
+    ("long", ">", LONG[2]), ("long", "<", "a string that is much longer than the inline twelve bytes 3"), ("long", ">=", ""), ("long", "<=", ""),
+    ("long", "starts_with", "a string that is much longer than the inline twelve bytes"), ("long", "starts_with", LONG[4][:-1] + "4"),
+    ("mode", "starts_with", "R"), ("mode", "starts_with", ""), ("instr", "starts_with", "TAKE"), ("instr", "starts_with", "TAKE BACK RETURN!"),
+    ("blob", ">=", b"\x01"), ("blob", "<", b"\x01\x00\x00"), ("blob", "starts_with", b"\x02\x02"), ("flag", "<", "N"),
+    ("and", ("mode", ">", "AIR"), ("mode", "<", "SHIP"), ("q", "<", 25)),
+    ("or", ("instr", "starts_with", "COLLECT"), ("and", ("long", ">", LONG[3]), ("flag", ">=", "N"))),
 ]
 
 
@@ -129,6 +140,8 @@ DICT_EXPRS = [
     ("author", "in", []), ("comp", "=", "C++"), ("comp", "<>", "Python"), ("author", "is null"), ("author", "is not null"),
     ("and", ("author", "in", ["alice", "bob"]), ("comp", "<>", "C++"), ("q", "<", 30)),
     ("or", ("author", "=", "dave"), ("and", ("comp", "=", "Rust"), ("mode", "=", "MAIL"))),
+    ("author", "<", "carol the third of her name"), ("author", ">=", "bob"), ("author", "starts_with", "carol the"),
+    ("and", ("comp", ">", "C++"), ("comp", "<=", "Python"), ("author", "starts_with", "")),
 ]
 
 
