@@ -905,7 +905,17 @@ hipError_t LaunchLz4Decompress(const Lz4Args& a, int num_cus, hipStream_t stream
   MI_DROP_STALE_ERROR();
   if (a.n_blocks == 0) return hipSuccess;
   if (a.zblocks) {
-    hipLaunchKernelGGL(zstd_entropy, dim3(a.n_blocks), dim3(kZstdThreads), 0, stream, a);
+    // the block staged in LDS (dynamic, sized by the launch's largest compressed block, at most kZstdStageMax): see zstd_entropy
+    constexpr uint32_t kZstdStageMax = 100u << 10;
+    static const bool no_stage = std::getenv("MI_ZSTD_WINDOWED") != nullptr;   // tests / A-B: the windowed readers for every block
+    uint32_t stage = no_stage ? 0u : ((a.max_block_comp + 16u + 15u) & ~15u);
+    if (stage > kZstdStageMax) stage = kZstdStageMax;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(zstd_entropy), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kZstdStageMax));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(zstd_entropy, dim3(a.n_blocks), dim3(kZstdThreads), stage, stream, a, stage);
     hipLaunchKernelGGL(zstd_layout, dim3(a.n_buffers), dim3(64), 0, stream, a);
   } else {
     // compressed blocks below 64 KiB (64 KiB is the default block size of every writer) are walked from an LDS copy

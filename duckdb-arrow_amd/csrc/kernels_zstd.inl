@@ -23,7 +23,13 @@ constexpr int kZstdSeqWindowWords = 256;         // the sequences' bitstream: 1 
 template <typename T>
 using ldsptr = T __attribute__((address_space(3)))*;
 
-__global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a) {
+// Blocks of up to `stage_bytes` compressed bytes (the launch's dynamic LDS; every block of a columnar stream in practice) are
+// copied into LDS first, by all threads, and decoded from there with the POSITIONAL decoders of zstd_format.hpp: the serial
+// lanes then never touch HBM for input, and a field of the bitstream is an indexed LDS read instead of a turn of a shifting
+// bit buffer with its counters and refill tests.  Per sequence: 1 us -> see DESIGN.md 4.2.  Larger blocks keep the windowed
+// readers.
+__global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a, uint32_t stage_bytes) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_stage[];   // the block, from the 4-byte boundary at or before its first byte
   __shared__ uint16_t s_huf[1u << zstd::kHufMaxBits];
   __shared__ zstd::FseCell s_ll[512], s_of[256], s_ml[512], s_wcells[64];   // 8 bytes a cell
   __shared__ uint8_t s_weights[256];
@@ -73,6 +79,14 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a) {
     return;
   }
   if (tid == 0) s_fail = 0;
+  // --- the block into LDS ---------------------------------------------------------------------------------------------
+  const uint32_t mis0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(c) & 3u);
+  const bool staged = stage_bytes != 0 && z.comp_size + mis0 + 8u <= stage_bytes;   // uniform
+  if (staged) {
+    gptr<const uint32_t> src = (gptr<const uint32_t>)(c - mis0);
+    const uint32_t nw = (mis0 + z.comp_size + 3u) / 4u + 2u;   // the readers look one word past the last byte (the body has >= 64 bytes of slack)
+    for (uint32_t i = tid; i < nw; i += kZstdThreads) s_stage[i] = src[i];
+  }
   __syncthreads();
   // --- tables ---------------------------------------------------------------------------------------------------------
   if (wave == 0) {
@@ -114,11 +128,17 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a) {
       uint32_t first, nbytes, out0, nsym;
       bool ok = zstd::LiteralStream(z, c, s_desc, lane, &first, &nbytes, &out0, &nsym);
       ok = ok && first + nbytes <= z.comp_size;
-      // the stream is read through a window in LDS that the lane refills itself: between refills the loop touches HBM only to
-      // store (a load would wait for the last store -- one counter for both -- at every refill of the bit buffer)
-      zstd::BackBits<gptr<const uint8_t>, zstd::WindowWords<gptr<const uint8_t>, ldsptr<uint32_t>, kZstdWindowWords>> br;
-      br.src.win = (ldsptr<uint32_t>)s_win[lane];
-      ok = ok && zstd::DecodeHuffmanStream(br, c + first, nbytes, nsym, huf, s_huf_bits, arena + z.lit_pos + out0);
+      if (staged) {
+        const uint32_t at = mis0 + first;   // byte offset of the stream in the staged block
+        ok = ok && zstd::DecodeHuffmanStreamPos((ldsptr<const uint32_t>)s_stage + (at >> 2), at & 3u, nbytes, nsym, huf, s_huf_bits,
+                                                arena + z.lit_pos + out0);
+      } else {
+        // the stream is read through a window in LDS that the lane refills itself: between refills the loop touches HBM only
+        // to store (a load would wait for the last store -- one counter for both -- at every refill of the bit buffer)
+        zstd::BackBits<gptr<const uint8_t>, zstd::WindowWords<gptr<const uint8_t>, ldsptr<uint32_t>, kZstdWindowWords>> br;
+        br.src.win = (ldsptr<uint32_t>)s_win[lane];
+        ok = ok && zstd::DecodeHuffmanStream(br, c + first, nbytes, nsym, huf, s_huf_bits, arena + z.lit_pos + out0);
+      }
       if (!ok) lz4_fail(a.status);   // the block's size is still reported by wave 1; the batch is rejected through the status word
     }
     return;
@@ -170,10 +190,16 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a) {
       put(ll, ml, code);
       return ok;
     };
-    // like the literal streams: read through a window in LDS, so that the loop's only traffic to HBM is its stores
-    zstd::BackBits<gptr<const uint8_t>, zstd::WindowWords<gptr<const uint8_t>, ldsptr<uint32_t>, kZstdSeqWindowWords>> br;
-    br.src.win = (ldsptr<uint32_t>)s_seqwin;
-    ok = zstd::DecodeSequences(br, c + bits_at, bits_len, z.nseq, t_ll, s_al[0], t_of, s_al[1], t_ml, s_al[2], emit);
+    if (staged) {
+      const uint32_t at = mis0 + bits_at;
+      ok = zstd::DecodeSequencesPos((ldsptr<const uint32_t>)s_stage + (at >> 2), at & 3u, bits_len, z.nseq, t_ll, s_al[0], t_of, s_al[1], t_ml,
+                                    s_al[2], emit);
+    } else {
+      // like the literal streams: read through a window in LDS, so that the loop's only traffic to HBM is its stores
+      zstd::BackBits<gptr<const uint8_t>, zstd::WindowWords<gptr<const uint8_t>, ldsptr<uint32_t>, kZstdSeqWindowWords>> br;
+      br.src.win = (ldsptr<uint32_t>)s_seqwin;
+      ok = zstd::DecodeSequences(br, c + bits_at, bits_len, z.nseq, t_ll, s_al[0], t_of, s_al[1], t_ml, s_al[2], emit);
+    }
   }
   if (ok && lit_used < z.lit_regen) {
     ok = z.lit_regen - lit_used <= zstd::kBlockMax - out_pos;

@@ -1069,7 +1069,7 @@ void ArrowScan::EnqueueLz4(Slot& s) {
   a.n_buffers = static_cast<uint32_t>(nf);
   a.min_block_comp = 0xFFFFFFFFu;
   for (auto& blk : d.blocks)
-    if (!blk.stored && !is_zstd) {
+    if (!blk.stored) {   // LZ4: which token walk fits; ZSTD: how much LDS the staged block takes
       a.max_block_comp = std::max(a.max_block_comp, blk.comp_size);
       a.min_block_comp = std::min(a.min_block_comp, blk.comp_size);
     }

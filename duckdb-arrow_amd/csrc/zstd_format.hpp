@@ -507,6 +507,127 @@ MI_ZHD bool DecodeSequences(READER& br, BP bits, uint32_t nbytes, uint32_t nseq,
   return br.Left() == 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same two decoders over a stream that is wholly addressable by 32-bit word (the block staged in LDS on the device, a
+// plain array on the CPU): POSITIONAL reads instead of a shifting bit buffer.
+//
+// BackBits above pays for every field it reads: peek, shift the 64-bit buffer, two counters, a refill test -- some fifteen
+// dependent instructions, six fields per sequence, on ONE lane, where every instruction costs a full issue slot.  With the
+// stream addressable the head is just a bit position.  A sequence's six field widths are all known as soon as its three
+// table cells are (the cell holds the width of the code's extra bits and of the next state's bits), so the six positions are a
+// prefix sum, the twelve words they lie in are independent loads, and a field is one v_alignbit and a mask: the dependent
+// chain per sequence is two table / stream round trips and a handful of instructions.  The Huffman streams take four
+// symbols from one 64-bit fetch (at most 11 bits each), one table look-up per symbol.
+//
+// WP: indexable, WP[i] = aligned word i of the stream counted from the 4-byte boundary at or before its first byte; words
+// up to one past the stream's last byte are read.  `mis` = byte offset of the stream's first byte in word 0.
+MI_ZHD uint32_t AlignBit(uint32_t hi, uint32_t lo, uint32_t sh) {   // (hi:lo) >> sh, low 32 bits; sh < 32
+  return static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32) | lo) >> sh);
+}
+template <typename WP>
+MI_ZHD uint32_t PosField(WP w, int32_t at, uint32_t n) {   // bits [at, at + n) of the stream, n <= 32, at >= 0
+  const uint32_t i = static_cast<uint32_t>(at) >> 5, sh = static_cast<uint32_t>(at) & 31u;
+  const uint32_t v = AlignBit(w[i + 1], w[i], sh);
+  return n >= 32 ? v : (v & ((1u << n) - 1u));
+}
+// head position (in bits from the aligned base) of a backward stream of nbytes bytes that starts `mis` bytes into word 0;
+// -1: the stream is empty or its last byte is zero (no end mark)
+template <typename WP>
+MI_ZHD int32_t PosOpen(WP w, uint32_t mis, uint32_t nbytes) {
+  if (nbytes == 0) return -1;
+  const uint32_t last_at = mis + nbytes - 1;
+  const uint32_t last = (w[last_at >> 2] >> (8 * (last_at & 3u))) & 0xFFu;
+  if (last == 0) return -1;
+  return static_cast<int32_t>(8 * last_at + HighBit(last));
+}
+
+template <typename WP, typename TP, typename EMIT>
+MI_ZHD bool DecodeSequencesPos(WP w, uint32_t mis, uint32_t nbytes, uint32_t nseq, TP tll, uint32_t al_ll, TP tof, uint32_t al_of, TP tml,
+                               uint32_t al_ml, EMIT emit) {
+  int32_t q = PosOpen(w, mis, nbytes);
+  const int32_t floor = static_cast<int32_t>(8 * mis);   // bits below belong to whatever lies in front of the stream
+  if (q < 0 || q - static_cast<int32_t>(al_ll + al_of + al_ml) < floor) return false;
+  q -= static_cast<int32_t>(al_ll);
+  uint32_t sll = PosField(w, q, al_ll);
+  q -= static_cast<int32_t>(al_of);
+  uint32_t sof = PosField(w, q, al_of);
+  q -= static_cast<int32_t>(al_ml);
+  uint32_t sml = PosField(w, q, al_ml);
+  for (uint32_t i = 0; i < nseq; i++) {
+    const FseCell cl = tll[sll], co = tof[sof], cm = tml[sml];
+    const bool more = i + 1 < nseq;
+    const uint32_t e_of = CellExtra(co), e_ml = CellExtra(cm), e_ll = CellExtra(cl);
+    const uint32_t b_ll = more ? CellBits(cl) : 0u, b_ml = more ? CellBits(cm) : 0u, b_of = more ? CellBits(co) : 0u;
+    // the order of the fields below the head: offset extra, match-length extra, literal-length extra, then the bits of the
+    // next literal-length, match-length and offset states
+    const int32_t p1 = q - static_cast<int32_t>(e_of), p2 = p1 - static_cast<int32_t>(e_ml), p3 = p2 - static_cast<int32_t>(e_ll),
+                  p4 = p3 - static_cast<int32_t>(b_ll), p5 = p4 - static_cast<int32_t>(b_ml), p6 = p5 - static_cast<int32_t>(b_of);
+    if (p6 < floor) return false;   // the stream ran out
+    const uint32_t ov = CellBase(co) + PosField(w, p1, e_of);
+    const uint32_t ml = CellBase(cm) + PosField(w, p2, e_ml);
+    const uint32_t ll = CellBase(cl) + PosField(w, p3, e_ll);
+    if (more) {
+      sll = CellNext(cl) + PosField(w, p4, b_ll);
+      sml = CellNext(cm) + PosField(w, p5, b_ml);
+      sof = CellNext(co) + PosField(w, p6, b_of);
+    }
+    q = p6;
+    if (ov > 3 && ov - 3 >= kRepMarker) return false;   // offset code 31: see DecodeSequences
+    if (!emit(i, ll, ml, ov > 3 ? ov - 3 : (kRepMarker | (ov - 1 + (ll == 0 ? 1u : 0u))))) return false;
+  }
+  return q == floor;
+}
+
+template <typename WP, typename HP, typename OP>
+MI_ZHD bool DecodeHuffmanStreamPos(WP w, uint32_t mis, uint32_t nbytes, uint32_t nsym, HP table, uint32_t max_bits, OP out) {
+  int32_t q = PosOpen(w, mis, nbytes);
+  const int32_t floor = static_cast<int32_t>(8 * mis);
+  if (q < 0) return false;
+  const uint32_t addr = static_cast<uint32_t>(Mem<OP>::Address(out));
+  uint32_t i = 0;
+  // symbols in front of the first aligned output word, one at a time (a look-up may peek below the stream's first bit: the
+  // format reads zeros there -- the words in front of the stream hold other bytes of the block, so they are masked)
+  auto peek = [&](int32_t head) -> uint32_t {
+    const int32_t at = head - static_cast<int32_t>(max_bits);
+    if (at >= floor) return PosField(w, at, max_bits);
+    const int32_t have = head - floor;   // < max_bits bits are left
+    return have <= 0 ? 0u : (PosField(w, floor, static_cast<uint32_t>(have)) << (max_bits - static_cast<uint32_t>(have)));
+  };
+  for (; i < nsym && ((addr + i) & 3u) != 0; i++) {
+    const uint32_t c = table[peek(q)];
+    q -= static_cast<int32_t>(c >> 8);
+    out[i] = static_cast<uint8_t>(c);
+  }
+  // four symbols per round from ONE 64-bit fetch: 4 x max_bits <= 44 bits lie in the two words below the head's word and
+  // that word itself -- three words, fetched together
+  while (i + 4 <= nsym && q - floor >= 64) {
+    const uint32_t hi_idx = static_cast<uint32_t>(q - 1) >> 5;          // word of the first unread bit
+    const uint32_t sh = 31u - (static_cast<uint32_t>(q - 1) & 31u);      // unread bits above it in that word: none after the shift
+    const uint32_t w2 = w[hi_idx], w1 = w[hi_idx - 1], w0 = w[hi_idx - 2];
+    // the 64 bits below the head, left-aligned (bit 63 = the next bit to read)
+    uint64_t buf = ((static_cast<uint64_t>(w2) << 32) | w1) << sh;
+    buf |= sh ? (static_cast<uint64_t>(w0) >> (32u - sh)) : 0ull;
+    uint32_t acc = 0, used = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+      const uint32_t c = table[static_cast<uint32_t>(buf >> (64u - max_bits))];
+      const uint32_t nb = c >> 8;
+      buf <<= nb;
+      used += nb;
+      acc |= (c & 0xFFu) << (8 * k);
+    }
+    q -= static_cast<int32_t>(used);
+    Mem<OP>::Store32(out + i, acc);
+    i += 4;
+  }
+  for (; i < nsym; i++) {   // the tail, and the last bits of the stream
+    const uint32_t c = table[peek(q)];
+    q -= static_cast<int32_t>(c >> 8);
+    out[i] = static_cast<uint8_t>(c);
+  }
+  return q == floor;
+}
+
 // Repeat offsets.  A sequence either brings a fresh offset or names one of the frame's three most recent ones, and that
 // history runs through all blocks of a frame -- but a block is decoded without its predecessors.  So the history is kept
 // SYMBOLICALLY: a state word is either a known offset (bit 31 clear; 0 = invalid) or "slot i of the history at the start of

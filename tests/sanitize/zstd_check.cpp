@@ -83,6 +83,16 @@ static bool DecodeFrame(const std::vector<uint8_t>& frame, size_t expect_size, s
         zstd::BackBits<const uint8_t*, zstd::WindowWords<const uint8_t*, uint32_t*, 8>> br;
         br.src.win = window;
         if (!zstd::DecodeHuffmanStream(br, c + first, nbytes, nsym, huf, max_bits, lits.data() + z.lit_pos + out0)) { *why = "literal stream " + std::to_string(s) + " of block " + std::to_string(bi); return false; }
+        // ... and the positional decoder of the staged path (the block addressable by aligned words): same literals
+        {
+          const uint32_t mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(c + first) & 3u);
+          std::vector<uint32_t> words((mis + nbytes + 3) / 4 + 2, 0xA5A5A5A5u);   // whatever lies around the stream must not matter
+          std::memcpy(reinterpret_cast<uint8_t*>(words.data()) + mis, c + first, nbytes);
+          std::vector<uint8_t> again(nsym + 8, 0);
+          uint8_t* dst = again.data() + ((4 - (reinterpret_cast<uintptr_t>(again.data()) & 3u)) & 3u) + ((reinterpret_cast<uintptr_t>(lits.data() + z.lit_pos + out0)) & 3u);
+          if (!zstd::DecodeHuffmanStreamPos(words.data(), mis, nbytes, nsym, huf, max_bits, dst)) { *why = "positional literal stream " + std::to_string(s) + " of block " + std::to_string(bi); return false; }
+          if (std::memcmp(dst, lits.data() + z.lit_pos + out0, nsym) != 0) { *why = "positional literal stream differs in block " + std::to_string(bi); return false; }
+        }
       }
     }
     uint32_t out_pos = 0, lit_used = 0;
@@ -133,6 +143,21 @@ static bool DecodeFrame(const std::vector<uint8_t>& frame, size_t expect_size, s
                                               return rep_ok;
                                             });
       if (!ok) { *why = "sequences of block " + std::to_string(bi); return false; }
+      // the positional decoder of the staged path: the same (literal length, match length, offset code) triples
+      {
+        const uint8_t* first = c + so + bo;
+        const uint32_t nbytes = z.comp_size - so - bo;
+        const uint32_t mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(first) & 3u);
+        std::vector<uint32_t> words((mis + nbytes + 3) / 4 + 2, 0x5A5A5A5Au);
+        std::memcpy(reinterpret_cast<uint8_t*>(words.data()) + mis, first, nbytes);
+        std::vector<uint32_t> a, b;
+        zstd::BackBits<const uint8_t*> plain;
+        const bool ok1 = zstd::DecodeSequences(plain, first, nbytes, z.nseq, tll, al[0], tof, al[1], tml, al[2],
+                                               [&](uint32_t, uint32_t ll, uint32_t ml, uint32_t code) { a.insert(a.end(), {ll, ml, code}); return true; });
+        const bool ok2 = zstd::DecodeSequencesPos(words.data(), mis, nbytes, z.nseq, tll, al[0], tof, al[1], tml, al[2],
+                                                  [&](uint32_t, uint32_t ll, uint32_t ml, uint32_t code) { b.insert(b.end(), {ll, ml, code}); return true; });
+        if (!ok1 || !ok2 || a != b) { *why = "positional sequence decoder differs in block " + std::to_string(bi); return false; }
+      }
     }
     if (lit_used < z.lit_regen) {
       if (z.lit_regen - lit_used > zstd::kBlockMax - out_pos) { *why = "block too long"; return false; }
@@ -213,7 +238,12 @@ static bool OffsetCode31IsRejected() {
   bool emitted = false;
   const bool ok = zstd::DecodeSequences(sbr, section + bo, static_cast<uint32_t>(sizeof(section)) - bo, 1, tll, al[0], tof, al[1], tml, al[2],
                                         [&](uint32_t, uint32_t, uint32_t, uint32_t) { emitted = true; return true; });
-  return !ok && !emitted;
+  bool emitted2 = false;
+  uint32_t words[4] = {0, 0, 0, 0};
+  std::memcpy(words, section + bo, sizeof(section) - bo);
+  const bool ok2 = zstd::DecodeSequencesPos(words, 0u, static_cast<uint32_t>(sizeof(section)) - bo, 1, tll, al[0], tof, al[1], tml, al[2],
+                                            [&](uint32_t, uint32_t, uint32_t, uint32_t) { emitted2 = true; return true; });
+  return !ok && !emitted && !ok2 && !emitted2;
 }
 
 int main(int argc, char** argv) {
