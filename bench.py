@@ -427,6 +427,7 @@ def main():
                     t1 = time.perf_counter()
                     got = rel.count(detail=True)
                     dt = time.perf_counter() - t1
+                    scan_stats = rel.stats()
                     rel.close()
                     dt = max_over_ranks(dt)
                     cnt = torch.tensor([got["rows"], got["selected"]], dtype=torch.int64, device="cuda" if (world > 1 and args.backend == "nccl") else "cpu")
@@ -435,8 +436,11 @@ def main():
                     best = dt if best is None else min(best, dt)
                     rows_all, sel_all = int(cnt[0].item()), int(cnt[1].item())
                 assert rows_all == info["n_rows"], (rows_all, info["n_rows"])
+                mine = max(1, got["rows"])   # PCIe bytes per row of THIS rank's share (mi_scan_get_stats)
                 legs[leg] = {"seconds": best, "rows_per_s": rows_all / best, "rows": rows_all, "selected": sel_all,
-                             "file_GBps": sum(os.path.getsize(p) for p in paths) / best / 1e9}
+                             "file_GBps": sum(os.path.getsize(p) for p in paths) / best / 1e9,
+                             "h2d_bytes_per_row": scan_stats["h2d_bytes"] / mine, "d2h_bytes_per_row": scan_stats["d2h_bytes"] / mine,
+                             "aliased_bytes_per_row": scan_stats["aliased_bytes"] / mine}
             if world == 1 and not args.no_cpu_baseline:
                 # the CPU beside the multi-file legs (min(files, cores) threads, one file per thread -- the reference
                 # scans one file per thread, src/file_scanner/arrow_file_scan.cpp:35-42): the oracle port over the same 8 files
@@ -460,30 +464,15 @@ def main():
                     legs[leg] = {"seconds": best, "rows_per_s": info["n_rows"] / best, "GBps_out": float(buf.size) / best / 1e9}
                 if os.path.exists(opath):
                     os.remove(opath)
-                # the same table as ONE LZ4_FRAME-compressed stream (what pyarrow / Feather V2 write), device-resident
-                # count: bodies decompressed by the reader's host threads vs in HBM by the K8 kernels (compressed bytes over PCIe)
+                # the same table as ONE compressed stream -- LZ4_FRAME (what pyarrow / Feather V2 write by default) and
+                # ZSTD (the codec the reference registers a decompressor for and its benchmark writes, benchmark/lineitem.py:135)
+                # -- device-resident count: bodies decompressed by the reader's host threads vs in HBM by the K8 kernels (the
+                # compressed bytes cross PCIe).  Default environment first; then the same scan in a process whose HIP runtime has
+                # 20 hardware queues (GPU_MAX_HW_QUEUES is read once, at start-up): every slot's K8 kernels on a stream of their own.
                 try:
+                    import subprocess
                     import pyarrow as pa
                     import pyarrow.ipc as ipc
-                    lpath = os.path.join(d, "lineitem_lz4.arrows")
-                    reader = ipc.open_stream(pa.py_buffer(buf))
-                    with ipc.new_stream(lpath, reader.schema, options=ipc.IpcWriteOptions(compression="lz4")) as w:
-                        for b in reader:
-                            w.write_batch(b)
-                    lz4 = {"file_bytes": os.path.getsize(lpath)}
-                    for tag, kw in (("host_threads", {"host_decompress": True}), ("in_hbm", {})):
-                        best = None
-                        for _ in range(2):
-                            rel = con.read_arrow(lpath, device_resident=True, pipeline_depth=8, **kw)
-                            t1 = time.perf_counter()
-                            got = rel.count(detail=True)
-                            dt = time.perf_counter() - t1
-                            st = rel.stats()
-                            rel.close()
-                            assert got["rows"] == info["n_rows"]
-                            best = dt if best is None else min(best, dt)
-                        lz4[tag] = {"seconds": best, "rows_per_s": info["n_rows"] / best, "h2d_bytes": st["h2d_bytes"],
-                                    "lz4_batches_on_device": st["lz4_batches_on_device"]}
                     best = None
                     for _ in range(2):
                         rel = con.read_arrow(paths, device_resident=True, pipeline_depth=8)
@@ -492,40 +481,39 @@ def main():
                         dt = time.perf_counter() - t1
                         rel.close()
                         best = dt if best is None else min(best, dt)
-                    lz4["uncompressed_files"] = {"seconds": best, "rows_per_s": info["n_rows"] / best}
-                    legs["lz4_device_resident_scan"] = lz4
-                    os.remove(lpath)
-                    # the same scan in a process whose HIP runtime has 20 hardware queues (GPU_MAX_HW_QUEUES is read once, at
-                    # start-up): every slot's K8 kernels then run on a stream of their own (scan_operator.cpp EnqueueLz4)
-                    import subprocess
-                    env = dict(os.environ, GPU_MAX_HW_QUEUES="20")
-                    run = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "lz4_bench.py"),
-                                          "--codec", "lz4", "--sf", str(args.sf), "--dir", args.shm_dir, "--depth", "8",
-                                          "--legs", "plain,lz4_in_hbm"], env=env, capture_output=True, text=True, timeout=600)
-                    if run.returncode == 0:
-                        z = json.loads(run.stdout.strip().split("\n")[-1])
-                        lz4["with_20_hw_queues"] = {"GPU_MAX_HW_QUEUES": 20, "pipeline_depth": 8,
-                                                    "in_hbm": {k: z["lz4_in_hbm"][k] for k in ("seconds", "rows_per_s")},
-                                                    "uncompressed_file": {k: z["plain"][k] for k in ("seconds", "rows_per_s")}}
-                    else:
-                        lz4["with_20_hw_queues"] = {"error": run.stderr[-300:]}
-                    # the same for ZSTD (the codec of the reference's benchmark, benchmark/lineitem.py:135).  Its GPU path is one
-                    # serial entropy chain per 128 KiB block: it needs many record batches side by side, so the leg runs in a
-                    # process of its own with 16 slots and GPU_MAX_HW_QUEUES=20 (the HIP runtime reads that once, at start-up;
-                    # with its default of 4 queues the same scan takes 2.6 s at SF10 -- DESIGN 4.2)
-                    run = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "lz4_bench.py"),
-                                          "--codec", "zstd", "--sf", str(args.sf), "--dir", args.shm_dir, "--depth", "16",
-                                          "--legs", "lz4_host_threads,lz4_in_hbm"], env=env, capture_output=True, text=True, timeout=600)
-                    if run.returncode == 0:
-                        z = json.loads(run.stdout.strip().split("\n")[-1])
-                        legs["zstd_device_resident_scan"] = {
-                            "file_bytes": z["lz4_bytes"], "GPU_MAX_HW_QUEUES": 20, "pipeline_depth": 16,
-                            "host_threads": {k: z["lz4_host_threads"][k] for k in ("seconds", "rows_per_s")},
-                            "in_hbm": dict({k: z["lz4_in_hbm"][k] for k in ("seconds", "rows_per_s")},
-                                           h2d_bytes=z["lz4_in_hbm"]["stats"]["h2d_bytes"],
-                                           zstd_batches_on_device=z["lz4_in_hbm"]["stats"]["zstd_batches_on_device"])}
-                    else:
-                        legs["zstd_device_resident_scan"] = {"error": run.stderr[-300:]}
+                    plain = {"seconds": best, "rows_per_s": info["n_rows"] / best}
+                    for codec, depth in (("lz4", 8), ("zstd", 16)):
+                        cpath = os.path.join(d, "lineitem_%s.arrows" % codec)
+                        reader = ipc.open_stream(pa.py_buffer(buf))
+                        with ipc.new_stream(cpath, reader.schema, options=ipc.IpcWriteOptions(compression=codec)) as w:
+                            for b in reader:
+                                w.write_batch(b)
+                        leg = {"file_bytes": os.path.getsize(cpath), "pipeline_depth": depth, "uncompressed_files": plain}
+                        for tag, kw in (("host_threads", {"host_decompress": True}), ("in_hbm", {"host_decompress": "gpu"}),
+                                        ("auto", {})):
+                            best = None
+                            for _ in range(2):
+                                rel = con.read_arrow(cpath, device_resident=True, pipeline_depth=depth, **kw)
+                                t1 = time.perf_counter()
+                                got = rel.count(detail=True)
+                                dt = time.perf_counter() - t1
+                                st = rel.stats()
+                                rel.close()
+                                assert got["rows"] == info["n_rows"]
+                                best = dt if best is None else min(best, dt)
+                            leg[tag] = {"seconds": best, "rows_per_s": info["n_rows"] / best, "h2d_bytes": st["h2d_bytes"],
+                                        "batches_decompressed_in_hbm": st["lz4_batches_on_device"] + st["zstd_batches_on_device"]}
+                        os.remove(cpath)
+                        env = dict(os.environ, GPU_MAX_HW_QUEUES="20")
+                        run = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lz4_bench.py"), "--codec", codec, "--sf", str(args.sf),
+                                              "--dir", args.shm_dir, "--depth", str(depth), "--legs", "lz4_in_hbm"], env=env, capture_output=True,
+                                             text=True, timeout=600)
+                        if run.returncode == 0:
+                            z = json.loads(run.stdout.strip().split("\n")[-1])
+                            leg["with_20_hw_queues"] = {"GPU_MAX_HW_QUEUES": 20, "in_hbm": {k: z["lz4_in_hbm"][k] for k in ("seconds", "rows_per_s")}}
+                        else:
+                            leg["with_20_hw_queues"] = {"error": run.stderr[-300:]}
+                        legs["%s_device_resident_scan" % codec] = leg
                 except ImportError:
                     pass   # no pyarrow on this box: the leg needs it to write the compressed stream
             con.close()

@@ -28,7 +28,7 @@ using ldsptr = T __attribute__((address_space(3)))*;
 // lanes then never touch HBM for input, and a field of the bitstream is an indexed LDS read instead of a turn of a shifting
 // bit buffer with its counters and refill tests.  Per sequence: 1 us -> see DESIGN.md 4.2.  Larger blocks keep the windowed
 // readers.
-__global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a, uint32_t stage_bytes) {
+__global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a, uint32_t stage_bytes, uint32_t own_above, uint32_t own_upto) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_stage[];   // the block, from the 4-byte boundary at or before its first byte
   __shared__ uint16_t s_huf[1u << zstd::kHufMaxBits];
   __shared__ zstd::FseCell s_ll[512], s_of[256], s_ml[512], s_wcells[64];   // 8 bytes a cell
@@ -55,6 +55,9 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a, uint32_t
   gptr<uint32_t> lane_out = GM<uint32_t>(a.lane_out) + static_cast<size_t>(bi) * kParseLanes;
   gptr<uint32_t> lane_nseq = GM<uint32_t>(a.lane_nseq) + static_cast<size_t>(bi) * kParseLanes;
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+  // a launch set may run this kernel twice with different LDS sizes (small blocks, many per CU; large blocks): each instance
+  // takes the blocks whose compressed size lies in (own_above, own_upto]
+  if (z.comp_size <= own_above || z.comp_size > own_upto) return;   // uniform
   if (z.type == 0) {   // raw: lz4_expand copies it (Lz4BlockDev::stored)
     if (tid == 0) {
       a.block_out_size[bi] = z.comp_size;
@@ -143,10 +146,154 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a, uint32_t
     }
     return;
   }
+  if (staged) {
+    // ---- wave 1, staged block: lane 0 runs the FSE state machine alone, 64 sequences at a time, and leaves {literal length,
+    // match length, offset code} in LDS; everything else about those 64 sequences is done by the whole wave: positions by a
+    // wave scan, the repeat-offset history by a segmented scan of the sequences' functions (zstd_format.hpp RepFunction; a
+    // segment = one of the block's 256 descriptor slices), descriptors and offsets as coalesced stores.  On one lane that
+    // bookkeeping was four fifths of the 1 us a sequence cost.
+    __shared__ uint32_t s_trip[64][3];
+    gptr<u32x4> rep_fn = GM<u32x4>(a.rep_state) + static_cast<size_t>(bi) * kParseLanes;
+    const uint32_t I0 = zstd::RepSlot(0), I1 = zstd::RepSlot(1), I2 = zstd::RepSlot(2);
+    zstd::SeqPosDecoder<ldsptr<const uint32_t>, ldsptr<zstd::FseCell>> dec;
+    bool ok0 = !failed;
+    if (lane == 0 && ok0 && z.nseq) {
+      const uint32_t at = mis0 + bits_at;
+      ok0 = dec.Open((ldsptr<const uint32_t>)s_stage + (at >> 2), at & 3u, bits_len, t_ll, s_al[0], t_of, s_al[1], t_ml, s_al[2]);
+    }
+    bool ok = __shfl(ok0 ? 1 : 0, 0, 64) != 0;
+    uint32_t out_base = 0, lit_base = 0, n_desc = 0;          // uniform: totals of the groups before this one
+    uint32_t cx = I0, cy = I1, cz = I2;                        // the function of the slice that straddles the group's start, up to there
+    uint32_t slice_base = 0;                                   // ... and the output position that slice began at
+    auto after = [](uint32_t gx, uint32_t gy, uint32_t gz, uint32_t x, uint32_t y, uint32_t zz, uint32_t* rx, uint32_t* ry, uint32_t* rz) {
+      *rx = zstd::RepResolve(gx, x, y, zz);
+      *ry = zstd::RepResolve(gy, x, y, zz);
+      *rz = zstd::RepResolve(gz, x, y, zz);
+    };
+    auto group = [&](uint32_t cnt) {   // the descriptors n_desc .. n_desc + cnt - 1, their triples in s_trip
+      const bool active = lane < cnt;
+      const uint32_t ll = active ? s_trip[lane][0] : 0u, ml = active ? s_trip[lane][1] : 0u, code = active ? s_trip[lane][2] : 0u;
+      const uint32_t incl_ll = wave_inclusive_scan_u32(ll), incl_out = wave_inclusive_scan_u32(ll + ml);
+      const uint32_t lit_i = lit_base + incl_ll - ll, out_i = out_base + incl_out - (ll + ml);
+      bool bad = active && (lit_i > z.lit_regen || ll > z.lit_regen - lit_i || out_i > zstd::kBlockMax || ll + ml > zstd::kBlockMax - out_i);
+      const uint32_t n = n_desc + lane, k = n / per, j = n - k * per;
+      const bool head = active && j == 0;
+      const uint64_t heads = __ballot(head ? 1 : 0);
+      const uint64_t below = heads & ((lane == 63u) ? ~0ull : ((2ull << lane) - 1ull));   // slice starts at or before this lane
+      const bool carried = below == 0;                          // the lane's slice began in an earlier group
+      const int hl = carried ? 0 : 63 - __builtin_clzll(below);
+      const uint32_t head_out = __shfl(out_i, hl, 64);
+      const uint32_t base_i = carried ? slice_base : head_out;
+      // the history: inclusive segmented scan of the sequences' functions, then the straddling slice's part on top
+      uint32_t px, py, pz, used;
+      zstd::RepFunction(code, active && ml != 0, &px, &py, &pz, &used);
+      uint32_t h = head ? 1u : 0u;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t nx = __shfl_up(px, d, 64), ny = __shfl_up(py, d, 64), nz = __shfl_up(pz, d, 64), nh = __shfl_up(h, d, 64);
+        if (lane >= static_cast<uint32_t>(d) && !h) {
+          after(px, py, pz, nx, ny, nz, &px, &py, &pz);
+          h |= nh;
+        }
+      }
+      if (carried) after(px, py, pz, cx, cy, cz, &px, &py, &pz);
+      // the state BEFORE the lane's sequence, in terms of its slice's start
+      uint32_t ex = __shfl_up(px, 1, 64), ey = __shfl_up(py, 1, 64), ez = __shfl_up(pz, 1, 64);
+      if (lane == 0) { ex = cx; ey = cy; ez = cz; }
+      if (head) { ex = I0; ey = I1; ez = I2; }
+      uint32_t off = 0;
+      if (active && ml != 0) {
+        off = zstd::RepResolve(used, ex, ey, ez);
+        if (off == 0) bad = true;
+      }
+      if (active) {
+        u32x4 d4;
+        d4.x = out_i - base_i;
+        d4.y = z.lit_pos + lit_i;
+        d4.z = ll;
+        d4.w = ml;
+        seq[k * per + j] = d4;
+        seq_off[k * per + j] = off;
+        if (head) lane_out[k] = out_i;
+        if (j + 1 == per) {   // the slice is full: its function is final
+          lane_nseq[k] = per;
+          u32x4 f;
+          f.x = px; f.y = py; f.z = pz; f.w = 0;
+          rep_fn[k] = f;
+        }
+      }
+      // what the next group starts from
+      const int last = static_cast<int>(cnt) - 1;
+      const bool last_full = __shfl((active && j + 1 == per) ? 1 : 0, last, 64) != 0;
+      const uint32_t lx = __shfl(px, last, 64), ly = __shfl(py, last, 64), lz = __shfl(pz, last, 64), lb = __shfl(base_i, last, 64);
+      cx = last_full ? I0 : lx;
+      cy = last_full ? I1 : ly;
+      cz = last_full ? I2 : lz;
+      slice_base = lb;
+      out_base += __shfl(incl_out, 63, 64);
+      lit_base += __shfl(incl_ll, 63, 64);
+      n_desc += cnt;
+      if (__any(bad ? 1 : 0)) ok = false;
+    };
+    for (uint32_t g0 = 0; g0 < z.nseq && ok; g0 += 64) {
+      const uint32_t cnt = z.nseq - g0 < 64u ? z.nseq - g0 : 64u;
+      if (lane == 0) {
+        for (uint32_t i = 0; i < cnt && ok0; i++) {
+          uint32_t ll, ml, code;
+          ok0 = dec.Step(g0 + i + 1 < z.nseq, &ll, &ml, &code);
+          s_trip[i][0] = ll;
+          s_trip[i][1] = ml;
+          s_trip[i][2] = code;
+        }
+        if (ok0 && g0 + cnt == z.nseq) ok0 = dec.AtEnd();
+      }
+      __builtin_amdgcn_wave_barrier();
+      ok = __shfl(ok0 ? 1 : 0, 0, 64) != 0;
+      if (!ok) break;
+      group(cnt);
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (ok && lit_base < z.lit_regen) {   // the literals behind the last sequence: a descriptor without a match
+      if (lane == 0) {
+        s_trip[0][0] = z.lit_regen - lit_base;
+        s_trip[0][1] = 0;
+        s_trip[0][2] = 0;
+      }
+      __builtin_amdgcn_wave_barrier();
+      group(1);
+    }
+    if (!ok) {
+      if (lane == 0) lz4_fail(a.status);
+      out_base = 0;
+      n_desc = 0;
+    }
+    uint32_t k_open = n_desc / per;
+    if (n_desc % per) {   // the last slice is partly filled
+      if (lane == 0) {
+        lane_nseq[k_open] = n_desc % per;
+        u32x4 f;
+        f.x = cx; f.y = cy; f.z = cz; f.w = 0;
+        rep_fn[k_open] = f;
+      }
+      k_open++;
+    }
+    for (uint32_t k = k_open + lane; k < kParseLanes; k += 64) {   // empty slices begin where the block ends and leave the history as it is
+      lane_out[k] = out_base;
+      lane_nseq[k] = 0;
+      u32x4 f;
+      f.x = I0; f.y = I1; f.z = I2; f.w = 0;
+      rep_fn[k] = f;
+    }
+    if (lane == 0) {
+      a.block_out_size[bi] = out_base;
+      a.block_nseq[bi] = n_desc;
+    }
+    return;
+  }
   if (lane != 0) {
     return;
   }
-  // wave 1, lane 0: the sequences
+  // wave 1, lane 0: the sequences (blocks too large to stage: the windowed reader, everything on this lane)
   uint32_t out_pos = 0, lit_used = 0, k = 0, j = 0, lane_base = 0, n_desc = 0;
   uint32_t S[3] = {zstd::RepSlot(0), zstd::RepSlot(1), zstd::RepSlot(2)};   // the history, as a function of the slice's start
   gptr<u32x4> rep_fn = GM<u32x4>(a.rep_state) + static_cast<size_t>(bi) * kParseLanes;
@@ -190,16 +337,10 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a, uint32_t
       put(ll, ml, code);
       return ok;
     };
-    if (staged) {
-      const uint32_t at = mis0 + bits_at;
-      ok = zstd::DecodeSequencesPos((ldsptr<const uint32_t>)s_stage + (at >> 2), at & 3u, bits_len, z.nseq, t_ll, s_al[0], t_of, s_al[1], t_ml,
-                                    s_al[2], emit);
-    } else {
-      // like the literal streams: read through a window in LDS, so that the loop's only traffic to HBM is its stores
-      zstd::BackBits<gptr<const uint8_t>, zstd::WindowWords<gptr<const uint8_t>, ldsptr<uint32_t>, kZstdSeqWindowWords>> br;
-      br.src.win = (ldsptr<uint32_t>)s_seqwin;
-      ok = zstd::DecodeSequences(br, c + bits_at, bits_len, z.nseq, t_ll, s_al[0], t_of, s_al[1], t_ml, s_al[2], emit);
-    }
+    // like the literal streams: read through a window in LDS, so that the loop's only traffic to HBM is its stores
+    zstd::BackBits<gptr<const uint8_t>, zstd::WindowWords<gptr<const uint8_t>, ldsptr<uint32_t>, kZstdSeqWindowWords>> br;
+    br.src.win = (ldsptr<uint32_t>)s_seqwin;
+    ok = zstd::DecodeSequences(br, c + bits_at, bits_len, z.nseq, t_ll, s_al[0], t_of, s_al[1], t_ml, s_al[2], emit);
   }
   if (ok && lit_used < z.lit_regen) {
     ok = z.lit_regen - lit_used <= zstd::kBlockMax - out_pos;

@@ -541,21 +541,33 @@ MI_ZHD int32_t PosOpen(WP w, uint32_t mis, uint32_t nbytes) {
   return static_cast<int32_t>(8 * last_at + HighBit(last));
 }
 
-template <typename WP, typename TP, typename EMIT>
-MI_ZHD bool DecodeSequencesPos(WP w, uint32_t mis, uint32_t nbytes, uint32_t nseq, TP tll, uint32_t al_ll, TP tof, uint32_t al_of, TP tml,
-                               uint32_t al_ml, EMIT emit) {
-  int32_t q = PosOpen(w, mis, nbytes);
-  const int32_t floor = static_cast<int32_t>(8 * mis);   // bits below belong to whatever lies in front of the stream
-  if (q < 0 || q - static_cast<int32_t>(al_ll + al_of + al_ml) < floor) return false;
-  q -= static_cast<int32_t>(al_ll);
-  uint32_t sll = PosField(w, q, al_ll);
-  q -= static_cast<int32_t>(al_of);
-  uint32_t sof = PosField(w, q, al_of);
-  q -= static_cast<int32_t>(al_ml);
-  uint32_t sml = PosField(w, q, al_ml);
-  for (uint32_t i = 0; i < nseq; i++) {
+// The sequence decoder as a resumable state: Open, then Step once per sequence (the device decodes 64 at a time on one lane
+// and lets the whole wave do everything else about them).
+template <typename WP, typename TP>
+struct SeqPosDecoder {
+  WP w;
+  TP tll, tof, tml;
+  int32_t q, floor;
+  uint32_t sll, sof, sml;
+  MI_ZHD bool Open(WP words, uint32_t mis, uint32_t nbytes, TP ll, uint32_t al_ll, TP of, uint32_t al_of, TP ml, uint32_t al_ml) {
+    w = words;
+    tll = ll;
+    tof = of;
+    tml = ml;
+    q = PosOpen(w, mis, nbytes);
+    floor = static_cast<int32_t>(8 * mis);   // bits below belong to whatever lies in front of the stream
+    if (q < 0 || q - static_cast<int32_t>(al_ll + al_of + al_ml) < floor) return false;
+    q -= static_cast<int32_t>(al_ll);
+    sll = PosField(w, q, al_ll);
+    q -= static_cast<int32_t>(al_of);
+    sof = PosField(w, q, al_of);
+    q -= static_cast<int32_t>(al_ml);
+    sml = PosField(w, q, al_ml);
+    return true;
+  }
+  // one sequence: literal length, match length, offset code as DecodeSequences emits it.  `more`: another sequence follows.
+  MI_ZHD bool Step(bool more, uint32_t* ll_out, uint32_t* ml_out, uint32_t* code_out) {
     const FseCell cl = tll[sll], co = tof[sof], cm = tml[sml];
-    const bool more = i + 1 < nseq;
     const uint32_t e_of = CellExtra(co), e_ml = CellExtra(cm), e_ll = CellExtra(cl);
     const uint32_t b_ll = more ? CellBits(cl) : 0u, b_ml = more ? CellBits(cm) : 0u, b_of = more ? CellBits(co) : 0u;
     // the order of the fields below the head: offset extra, match-length extra, literal-length extra, then the bits of the
@@ -564,8 +576,9 @@ MI_ZHD bool DecodeSequencesPos(WP w, uint32_t mis, uint32_t nbytes, uint32_t nse
                   p4 = p3 - static_cast<int32_t>(b_ll), p5 = p4 - static_cast<int32_t>(b_ml), p6 = p5 - static_cast<int32_t>(b_of);
     if (p6 < floor) return false;   // the stream ran out
     const uint32_t ov = CellBase(co) + PosField(w, p1, e_of);
-    const uint32_t ml = CellBase(cm) + PosField(w, p2, e_ml);
+    *ml_out = CellBase(cm) + PosField(w, p2, e_ml);
     const uint32_t ll = CellBase(cl) + PosField(w, p3, e_ll);
+    *ll_out = ll;
     if (more) {
       sll = CellNext(cl) + PosField(w, p4, b_ll);
       sml = CellNext(cm) + PosField(w, p5, b_ml);
@@ -573,9 +586,23 @@ MI_ZHD bool DecodeSequencesPos(WP w, uint32_t mis, uint32_t nbytes, uint32_t nse
     }
     q = p6;
     if (ov > 3 && ov - 3 >= kRepMarker) return false;   // offset code 31: see DecodeSequences
-    if (!emit(i, ll, ml, ov > 3 ? ov - 3 : (kRepMarker | (ov - 1 + (ll == 0 ? 1u : 0u))))) return false;
+    *code_out = ov > 3 ? ov - 3 : (kRepMarker | (ov - 1 + (ll == 0 ? 1u : 0u)));
+    return true;
   }
-  return q == floor;
+  MI_ZHD bool AtEnd() const { return q == floor; }
+};
+
+template <typename WP, typename TP, typename EMIT>
+MI_ZHD bool DecodeSequencesPos(WP w, uint32_t mis, uint32_t nbytes, uint32_t nseq, TP tll, uint32_t al_ll, TP tof, uint32_t al_of, TP tml,
+                               uint32_t al_ml, EMIT emit) {
+  SeqPosDecoder<WP, TP> dec;
+  if (!dec.Open(w, mis, nbytes, tll, al_ll, tof, al_of, tml, al_ml)) return false;
+  for (uint32_t i = 0; i < nseq; i++) {
+    uint32_t ll, ml, code;
+    if (!dec.Step(i + 1 < nseq, &ll, &ml, &code)) return false;
+    if (!emit(i, ll, ml, code)) return false;
+  }
+  return dec.AtEnd();
 }
 
 template <typename WP, typename HP, typename OP>
@@ -644,6 +671,18 @@ MI_ZHD uint32_t RepResolve(uint32_t w, uint32_t f0, uint32_t f1, uint32_t f2) {
   const uint32_t u = i == 0 ? f0 : i == 1 ? f1 : f2;
   if (!(u >> 31)) return u > dec ? u - dec : 0u;
   return u + dec;
+}
+// The same step as a FUNCTION on the history: F = the state after the sequence when the state before it is (slot 0, slot 1,
+// slot 2) -- RepStep on the identity -- so that the states of many sequences come from a parallel scan: later after earlier is
+// (RepResolve(later.x, earlier), RepResolve(later.y, earlier), RepResolve(later.z, earlier)).  *used = the offset the sequence
+// uses, in terms of the state before it.
+MI_ZHD uint32_t RepStep(uint32_t code, uint32_t* S);
+MI_ZHD void RepFunction(uint32_t code, bool has_match, uint32_t* fx, uint32_t* fy, uint32_t* fz, uint32_t* used) {
+  uint32_t S[3] = {RepSlot(0), RepSlot(1), RepSlot(2)};
+  *used = has_match ? RepStep(code, S) : 0u;
+  *fx = S[0];
+  *fy = S[1];
+  *fz = S[2];
 }
 // one sequence: `code` as DecodeSequences emits it; S[3] is updated, the offset the sequence uses is returned (0 = invalid)
 MI_ZHD uint32_t RepStep(uint32_t code, uint32_t* S) {

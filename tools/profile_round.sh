@@ -6,7 +6,7 @@
 # BASELINE config 4), commits (tools/commits_bench.py, config 5), filter (tools/filter_bench.py, K6 + gather), lz4
 # (tools/lz4_bench.py, K8 through the scan operator), zstd (the same with --codec zstd: 16 slots, GPU_MAX_HW_QUEUES=20).
 set -eo pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 shift || true
 workloads=${@:-decode encode commits filter lz4}
 cd "${GRAFT_REPO_ROOT:-.}"
@@ -18,7 +18,8 @@ for w in $workloads; do
     commits) full="tools/commits_bench.py"; short="tools/commits_bench.py" ;;
     filter)  full="tools/filter_bench.py"; short="tools/filter_bench.py" ;;
     lz4)     full="tools/lz4_bench.py --sf 10"; short="tools/lz4_bench.py --sf 2" ;;
-    zstd)    export GPU_MAX_HW_QUEUES=20   # read once by the HIP runtime; exported, not passed through env(1): rocprofv3 needs the program itself behind --
+    zstd)    full="tools/lz4_bench.py --codec zstd --depth 16 --sf 10"; short="tools/lz4_bench.py --codec zstd --depth 16 --sf 2 --legs lz4_in_hbm" ;;   # the HIP runtime's default queues
+    zstd20)  export GPU_MAX_HW_QUEUES=20   # read once by the HIP runtime; exported, not passed through env(1): rocprofv3 needs the program itself behind --
              full="tools/lz4_bench.py --codec zstd --depth 16 --sf 10"; short="tools/lz4_bench.py --codec zstd --depth 16 --sf 2 --legs lz4_in_hbm" ;;
     *) echo "unknown workload $w"; exit 2 ;;
   esac

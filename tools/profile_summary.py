@@ -26,7 +26,7 @@ KERNELS = ("transcode_copy", "transcode_dec128", "transcode_string", "transcode_
 
 
 def short(name):
-    m = re.search(r"(transcode_\w+|encode_\w+|filter_\w+|agg_sum_product|gather_\w+|lz4_\w+|zstd_\w+)", name)
+    m = re.search(r"(transcode_\w+|encode_\w+|filter_\w+|agg_sum_product|gather_\w+|lz4_\w+|zstd_\w+|k8_\w+)", name)
     return m.group(1) if m else None
 
 
