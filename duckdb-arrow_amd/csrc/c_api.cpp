@@ -3,6 +3,7 @@
 // boundary (src/include/ipc/array_stream.hpp:29-48).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -204,6 +205,17 @@ int mi_reader_index(mi_reader* r, const mi_batch_index_entry** entries, int32_t*
 }
 
 // ------------------------------------------------------------------------------------------------ device
+// The HIP runtime multiplexes every stream of a process onto GPU_MAX_HW_QUEUES hardware queues (4 unless the variable says
+// otherwise) and reads the variable ONCE, when it initialises at the process's first HIP call.  The compressed-body scans (K8)
+// are sets of latency-bound kernels that want the record batches of many pipeline slots side by side, each slot on a stream of
+// its own: on 4 queues their kernels queue up behind one another (ZSTD, SF10: 2.6 s against 0.9 s on 20 queues).  So when the
+// library is loaded and nobody has chosen a value, it asks for 20 -- effective when the library is loaded before the process
+// touches HIP (a DuckDB process loading the extension; bench.py and the tools import the package first), a no-op otherwise;
+// an explicit GPU_MAX_HW_QUEUES in the environment always wins.
+namespace {
+__attribute__((constructor)) void MiRuntimeDefaults() { (void)setenv("GPU_MAX_HW_QUEUES", "20", /*overwrite*/ 0); }
+}  // namespace
+
 int mi_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

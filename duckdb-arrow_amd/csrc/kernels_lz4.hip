@@ -905,29 +905,8 @@ hipError_t LaunchLz4Decompress(const Lz4Args& a, int num_cus, hipStream_t stream
   MI_DROP_STALE_ERROR();
   if (a.n_blocks == 0) return hipSuccess;
   if (a.zblocks) {
-    // the block staged in LDS (dynamic): see zstd_entropy.  Small blocks (the rule for columnar data: a 128 KiB block of lineitem
-    // compresses to ~30 KiB) get a launch with little LDS, so that several of them share a CU -- the kernel is a set of serial
-    // chains, what it needs is many blocks side by side; the others a second launch that stages up to kZstdStageMax bytes
-    // and reads anything larger through the windowed readers.
-    constexpr uint32_t kZstdStageSmall = 36u << 10, kZstdStageMax = 100u << 10;
-    static const bool no_stage = std::getenv("MI_ZSTD_WINDOWED") != nullptr;   // tests / A-B: the windowed readers for every block
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(zstd_entropy), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kZstdStageMax));
-      attr_set = true;
-    }
-    if (no_stage) {
-      hipLaunchKernelGGL(zstd_entropy, dim3(a.n_blocks), dim3(kZstdThreads), 0, stream, a, 0u, 0u, 0xFFFFFFFFu);
-    } else {
-      const uint32_t small_limit = kZstdStageSmall - 16u;   // compressed bytes a small-launch block may have
-      const uint32_t small_lds = (std::min(a.max_block_comp, small_limit) + 16u + 15u) & ~15u;
-      const bool big = a.max_block_comp > small_limit;   // (stored blocks are not in max_block_comp: they only report their size, in either launch)
-      hipLaunchKernelGGL(zstd_entropy, dim3(a.n_blocks), dim3(kZstdThreads), small_lds, stream, a, small_lds, 0u, big ? small_limit : 0xFFFFFFFFu);
-      if (big) {
-        const uint32_t big_lds = std::min((a.max_block_comp + 16u + 15u) & ~15u, kZstdStageMax);
-        hipLaunchKernelGGL(zstd_entropy, dim3(a.n_blocks), dim3(kZstdThreads), big_lds, stream, a, big_lds, small_limit, 0xFFFFFFFFu);
-      }
-    }
+    static const bool windowed = std::getenv("MI_ZSTD_WINDOWED") != nullptr;   // tests / A-B: the first formulation's readers
+    hipLaunchKernelGGL(zstd_entropy, dim3(a.n_blocks), dim3(kZstdThreads), 0, stream, a, windowed ? 0u : 1u);
     hipLaunchKernelGGL(zstd_layout, dim3(a.n_buffers), dim3(64), 0, stream, a);
   } else {
     // compressed blocks below 64 KiB (64 KiB is the default block size of every writer) are walked from an LDS copy

@@ -23,13 +23,13 @@ constexpr int kZstdSeqWindowWords = 256;         // the sequences' bitstream: 1 
 template <typename T>
 using ldsptr = T __attribute__((address_space(3)))*;
 
-// Blocks of up to `stage_bytes` compressed bytes (the launch's dynamic LDS; every block of a columnar stream in practice) are
-// copied into LDS first, by all threads, and decoded from there with the POSITIONAL decoders of zstd_format.hpp: the serial
-// lanes then never touch HBM for input, and a field of the bitstream is an indexed LDS read instead of a turn of a shifting
-// bit buffer with its counters and refill tests.  Per sequence: 1 us -> see DESIGN.md 4.2.  Larger blocks keep the windowed
-// readers.
-__global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a, uint32_t stage_bytes, uint32_t own_above, uint32_t own_upto) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t s_stage[];   // the block, from the 4-byte boundary at or before its first byte
+// pos != 0 (the default): the streams are decoded with the POSITIONAL decoders of zstd_format.hpp -- a field of the bitstream
+// is an indexed read from a 0.5 - 1 KiB window of the stream in LDS that the decoding lane slides itself, not a turn of a
+// shifting bit buffer with its counters and refill tests -- and wave 1 shares the work on the sequences (see there).  pos == 0:
+// the BackBits readers of the first formulation, everything about a sequence on one lane (MI_ZSTD_WINDOWED: tests, A/B).
+// (Staging the whole block in LDS instead of windows was measured and dropped: 36 - 100 KiB per workgroup leave room for two
+// blocks per CU instead of eight, and the kernel is a set of serial chains -- what it needs is many blocks side by side.)
+__global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a, uint32_t pos) {
   __shared__ uint16_t s_huf[1u << zstd::kHufMaxBits];
   __shared__ zstd::FseCell s_ll[512], s_of[256], s_ml[512], s_wcells[64];   // 8 bytes a cell
   __shared__ uint8_t s_weights[256];
@@ -55,9 +55,6 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a, uint32_t
   gptr<uint32_t> lane_out = GM<uint32_t>(a.lane_out) + static_cast<size_t>(bi) * kParseLanes;
   gptr<uint32_t> lane_nseq = GM<uint32_t>(a.lane_nseq) + static_cast<size_t>(bi) * kParseLanes;
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-  // a launch set may run this kernel twice with different LDS sizes (small blocks, many per CU; large blocks): each instance
-  // takes the blocks whose compressed size lies in (own_above, own_upto]
-  if (z.comp_size <= own_above || z.comp_size > own_upto) return;   // uniform
   if (z.type == 0) {   // raw: lz4_expand copies it (Lz4BlockDev::stored)
     if (tid == 0) {
       a.block_out_size[bi] = z.comp_size;
@@ -82,14 +79,7 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a, uint32_t
     return;
   }
   if (tid == 0) s_fail = 0;
-  // --- the block into LDS ---------------------------------------------------------------------------------------------
-  const uint32_t mis0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(c) & 3u);
-  const bool staged = stage_bytes != 0 && z.comp_size + mis0 + 8u <= stage_bytes;   // uniform
-  if (staged) {
-    gptr<const uint32_t> src = (gptr<const uint32_t>)(c - mis0);
-    const uint32_t nw = (mis0 + z.comp_size + 3u) / 4u + 2u;   // the readers look one word past the last byte (the body has >= 64 bytes of slack)
-    for (uint32_t i = tid; i < nw; i += kZstdThreads) s_stage[i] = src[i];
-  }
+  const bool staged = pos != 0;   // uniform (the name is history: the positional path)
   __syncthreads();
   // --- tables ---------------------------------------------------------------------------------------------------------
   if (wave == 0) {
@@ -132,9 +122,10 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a, uint32_t
       bool ok = zstd::LiteralStream(z, c, s_desc, lane, &first, &nbytes, &out0, &nsym);
       ok = ok && first + nbytes <= z.comp_size;
       if (staged) {
-        const uint32_t at = mis0 + first;   // byte offset of the stream in the staged block
-        ok = ok && zstd::DecodeHuffmanStreamPos((ldsptr<const uint32_t>)s_stage + (at >> 2), at & 3u, nbytes, nsym, huf, s_huf_bits,
-                                                arena + z.lit_pos + out0);
+        const uint32_t mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(c + first) & 3u);
+        zstd::SlidingWords<gptr<const uint8_t>, ldsptr<uint32_t>, kZstdWindowWords> sw;
+        sw.Init(c + first - mis, (ldsptr<uint32_t>)s_win[lane]);
+        ok = ok && zstd::DecodeHuffmanStreamPos(sw, mis, nbytes, nsym, huf, s_huf_bits, arena + z.lit_pos + out0);
       } else {
         // the stream is read through a window in LDS that the lane refills itself: between refills the loop touches HBM only
         // to store (a load would wait for the last store -- one counter for both -- at every refill of the bit buffer)
@@ -147,7 +138,7 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a, uint32_t
     return;
   }
   if (staged) {
-    // ---- wave 1, staged block: lane 0 runs the FSE state machine alone, 64 sequences at a time, and leaves {literal length,
+    // ---- wave 1, positional path: lane 0 runs the FSE state machine alone, 64 sequences at a time, and leaves {literal length,
     // match length, offset code} in LDS; everything else about those 64 sequences is done by the whole wave: positions by a
     // wave scan, the repeat-offset history by a segmented scan of the sequences' functions (zstd_format.hpp RepFunction; a
     // segment = one of the block's 256 descriptor slices), descriptors and offsets as coalesced stores.  On one lane that
@@ -155,11 +146,14 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a, uint32_t
     __shared__ uint32_t s_trip[64][3];
     gptr<u32x4> rep_fn = GM<u32x4>(a.rep_state) + static_cast<size_t>(bi) * kParseLanes;
     const uint32_t I0 = zstd::RepSlot(0), I1 = zstd::RepSlot(1), I2 = zstd::RepSlot(2);
-    zstd::SeqPosDecoder<ldsptr<const uint32_t>, ldsptr<zstd::FseCell>> dec;
+    using SeqWords = zstd::SlidingWords<gptr<const uint8_t>, ldsptr<uint32_t>, kZstdSeqWindowWords>;
+    zstd::SeqPosDecoder<SeqWords, ldsptr<zstd::FseCell>> dec;
     bool ok0 = !failed;
     if (lane == 0 && ok0 && z.nseq) {
-      const uint32_t at = mis0 + bits_at;
-      ok0 = dec.Open((ldsptr<const uint32_t>)s_stage + (at >> 2), at & 3u, bits_len, t_ll, s_al[0], t_of, s_al[1], t_ml, s_al[2]);
+      const uint32_t mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(c + bits_at) & 3u);
+      SeqWords sw;
+      sw.Init(c + bits_at - mis, (ldsptr<uint32_t>)s_seqwin);
+      ok0 = dec.Open(sw, mis, bits_len, t_ll, s_al[0], t_of, s_al[1], t_ml, s_al[2]);
     }
     bool ok = __shfl(ok0 ? 1 : 0, 0, 64) != 0;
     uint32_t out_base = 0, lit_base = 0, n_desc = 0;          // uniform: totals of the groups before this one

@@ -521,11 +521,37 @@ MI_ZHD bool DecodeSequences(READER& br, BP bits, uint32_t nbytes, uint32_t nseq,
 //
 // WP: indexable, WP[i] = aligned word i of the stream counted from the 4-byte boundary at or before its first byte; words
 // up to one past the stream's last byte are read.  `mis` = byte offset of the stream's first byte in word 0.
+// ... or through a window of W words of fast memory that the reader slides itself (the device: 1 KiB of LDS per stream; a block
+// staged whole would cost the LDS that lets eight blocks share a CU, and the kernel lives on blocks side by side).  Indices only
+// go down, a few words at a time; PosEnsure(w, lo, hi) makes words [lo, hi] addressable before they are read.
+template <typename BP, typename LP, int W>
+struct SlidingWords {
+  BP base;      // the 4-byte boundary at or before the stream's first byte
+  LP win;
+  int32_t lo;   // the window holds the words lo .. lo + W - 1
+  MI_ZHD void Init(BP b, LP l) {
+    base = b;
+    win = l;
+    lo = 0x3FFFFFFF;   // nothing yet
+  }
+  MI_ZHD void Ensure(int32_t need_lo, int32_t need_hi) {   // need_hi - need_lo < W
+    if (need_lo < lo || need_hi >= lo + W) {
+      lo = need_hi + 1 - W;
+      for (int j = 0; j < W; j++) win[j] = lo + j >= 0 ? Mem<BP>::Load32(base + 4 * (lo + j)) : 0u;
+    }
+  }
+  MI_ZHD uint32_t operator[](uint32_t i) const { return win[static_cast<int32_t>(i) - lo]; }
+};
+template <typename WP>
+MI_ZHD void PosEnsure(WP&, int32_t, int32_t) {}   // a plain array of words: everything is addressable
+template <typename BP, typename LP, int W>
+MI_ZHD void PosEnsure(SlidingWords<BP, LP, W>& w, int32_t lo, int32_t hi) { w.Ensure(lo, hi); }
+
 MI_ZHD uint32_t AlignBit(uint32_t hi, uint32_t lo, uint32_t sh) {   // (hi:lo) >> sh, low 32 bits; sh < 32
   return static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32) | lo) >> sh);
 }
 template <typename WP>
-MI_ZHD uint32_t PosField(WP w, int32_t at, uint32_t n) {   // bits [at, at + n) of the stream, n <= 32, at >= 0
+MI_ZHD uint32_t PosField(const WP& w, int32_t at, uint32_t n) {   // bits [at, at + n) of the stream, n <= 32, at >= 0
   const uint32_t i = static_cast<uint32_t>(at) >> 5, sh = static_cast<uint32_t>(at) & 31u;
   const uint32_t v = AlignBit(w[i + 1], w[i], sh);
   return n >= 32 ? v : (v & ((1u << n) - 1u));
@@ -533,9 +559,10 @@ MI_ZHD uint32_t PosField(WP w, int32_t at, uint32_t n) {   // bits [at, at + n) 
 // head position (in bits from the aligned base) of a backward stream of nbytes bytes that starts `mis` bytes into word 0;
 // -1: the stream is empty or its last byte is zero (no end mark)
 template <typename WP>
-MI_ZHD int32_t PosOpen(WP w, uint32_t mis, uint32_t nbytes) {
+MI_ZHD int32_t PosOpen(WP& w, uint32_t mis, uint32_t nbytes) {
   if (nbytes == 0) return -1;
   const uint32_t last_at = mis + nbytes - 1;
+  PosEnsure(w, static_cast<int32_t>(last_at >> 2), static_cast<int32_t>(last_at >> 2) + 1);
   const uint32_t last = (w[last_at >> 2] >> (8 * (last_at & 3u))) & 0xFFu;
   if (last == 0) return -1;
   return static_cast<int32_t>(8 * last_at + HighBit(last));
@@ -557,6 +584,7 @@ struct SeqPosDecoder {
     q = PosOpen(w, mis, nbytes);
     floor = static_cast<int32_t>(8 * mis);   // bits below belong to whatever lies in front of the stream
     if (q < 0 || q - static_cast<int32_t>(al_ll + al_of + al_ml) < floor) return false;
+    PosEnsure(w, (q - static_cast<int32_t>(al_ll + al_of + al_ml)) >> 5, (q >> 5) + 1);
     q -= static_cast<int32_t>(al_ll);
     sll = PosField(w, q, al_ll);
     q -= static_cast<int32_t>(al_of);
@@ -575,6 +603,7 @@ struct SeqPosDecoder {
     const int32_t p1 = q - static_cast<int32_t>(e_of), p2 = p1 - static_cast<int32_t>(e_ml), p3 = p2 - static_cast<int32_t>(e_ll),
                   p4 = p3 - static_cast<int32_t>(b_ll), p5 = p4 - static_cast<int32_t>(b_ml), p6 = p5 - static_cast<int32_t>(b_of);
     if (p6 < floor) return false;   // the stream ran out
+    PosEnsure(w, p6 >> 5, (q >> 5) + 1);
     const uint32_t ov = CellBase(co) + PosField(w, p1, e_of);
     *ml_out = CellBase(cm) + PosField(w, p2, e_ml);
     const uint32_t ll = CellBase(cl) + PosField(w, p3, e_ll);
@@ -616,6 +645,7 @@ MI_ZHD bool DecodeHuffmanStreamPos(WP w, uint32_t mis, uint32_t nbytes, uint32_t
   // format reads zeros there -- the words in front of the stream hold other bytes of the block, so they are masked)
   auto peek = [&](int32_t head) -> uint32_t {
     const int32_t at = head - static_cast<int32_t>(max_bits);
+    PosEnsure(w, (at > floor ? at : floor) >> 5, (head >> 5) + 1);
     if (at >= floor) return PosField(w, at, max_bits);
     const int32_t have = head - floor;   // < max_bits bits are left
     return have <= 0 ? 0u : (PosField(w, floor, static_cast<uint32_t>(have)) << (max_bits - static_cast<uint32_t>(have)));
@@ -630,7 +660,8 @@ MI_ZHD bool DecodeHuffmanStreamPos(WP w, uint32_t mis, uint32_t nbytes, uint32_t
   while (i + 4 <= nsym && q - floor >= 64) {
     const uint32_t hi_idx = static_cast<uint32_t>(q - 1) >> 5;          // word of the first unread bit
     const uint32_t sh = 31u - (static_cast<uint32_t>(q - 1) & 31u);      // unread bits above it in that word: none after the shift
-    const uint32_t w2 = w[hi_idx], w1 = w[hi_idx - 1], w0 = w[hi_idx - 2];
+    PosEnsure(w, static_cast<int32_t>(hi_idx) - 2 < 0 ? 0 : static_cast<int32_t>(hi_idx) - 2, static_cast<int32_t>(hi_idx));
+    const uint32_t w2 = w[hi_idx], w1 = w[hi_idx - 1], w0 = sh ? w[hi_idx - 2] : 0u;
     // the 64 bits below the head, left-aligned (bit 63 = the next bit to read)
     uint64_t buf = ((static_cast<uint64_t>(w2) << 32) | w1) << sh;
     buf |= sh ? (static_cast<uint64_t>(w0) >> (32u - sh)) : 0ull;

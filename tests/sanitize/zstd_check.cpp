@@ -92,6 +92,16 @@ static bool DecodeFrame(const std::vector<uint8_t>& frame, size_t expect_size, s
           uint8_t* dst = again.data() + ((4 - (reinterpret_cast<uintptr_t>(again.data()) & 3u)) & 3u) + ((reinterpret_cast<uintptr_t>(lits.data() + z.lit_pos + out0)) & 3u);
           if (!zstd::DecodeHuffmanStreamPos(words.data(), mis, nbytes, nsym, huf, max_bits, dst)) { *why = "positional literal stream " + std::to_string(s) + " of block " + std::to_string(bi); return false; }
           if (std::memcmp(dst, lits.data() + z.lit_pos + out0, nsym) != 0) { *why = "positional literal stream differs in block " + std::to_string(bi); return false; }
+          // ... and through a sliding window of 8 words (the device's is 128): crossed every few symbols
+          uint32_t win8[8];
+          zstd::SlidingWords<const uint8_t*, uint32_t*, 8> sw;
+          sw.Init(reinterpret_cast<const uint8_t*>(words.data()), win8);
+          std::vector<uint8_t> third(nsym + 8, 0);
+          uint8_t* dst3 = third.data() + (dst - again.data());
+          if (!zstd::DecodeHuffmanStreamPos(sw, mis, nbytes, nsym, huf, max_bits, dst3) || std::memcmp(dst3, dst, nsym) != 0) {
+            *why = "windowed positional literal stream differs in block " + std::to_string(bi);
+            return false;
+          }
         }
       }
     }
@@ -157,6 +167,13 @@ static bool DecodeFrame(const std::vector<uint8_t>& frame, size_t expect_size, s
         const bool ok2 = zstd::DecodeSequencesPos(words.data(), mis, nbytes, z.nseq, tll, al[0], tof, al[1], tml, al[2],
                                                   [&](uint32_t, uint32_t ll, uint32_t ml, uint32_t code) { b.insert(b.end(), {ll, ml, code}); return true; });
         if (!ok1 || !ok2 || a != b) { *why = "positional sequence decoder differs in block " + std::to_string(bi); return false; }
+        uint32_t win8[8];
+        zstd::SlidingWords<const uint8_t*, uint32_t*, 8> sw;
+        sw.Init(reinterpret_cast<const uint8_t*>(words.data()), win8);
+        std::vector<uint32_t> c3;
+        const bool ok3 = zstd::DecodeSequencesPos(sw, mis, nbytes, z.nseq, tll, al[0], tof, al[1], tml, al[2],
+                                                  [&](uint32_t, uint32_t ll, uint32_t ml, uint32_t code) { c3.insert(c3.end(), {ll, ml, code}); return true; });
+        if (!ok3 || a != c3) { *why = "windowed positional sequence decoder differs in block " + std::to_string(bi); return false; }
       }
     }
     if (lit_used < z.lit_regen) {
