@@ -274,17 +274,49 @@ __device__ __forceinline__ void lds_put_stream(uint8_t* dst, uint32_t (&W)[N + 2
 }
 
 
-// The first <= 48 bytes of a heap string starting at `src`: 13 aligned dwords cover them at any misalignment.
-__device__ __forceinline__ void heap_load13(gptr<const uint8_t> src, uint32_t cnt, uint32_t (&W)[14]) {
-  const uint32_t mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(src) & 3);
-  gptr<const uint32_t> q = (gptr<const uint32_t>)(src - mis);
-  const uint32_t ndw = (mis + (cnt < 48u ? cnt : 48u) + 3) >> 2;
-#pragma unroll
-  for (int d = 0; d < 13; d++) W[d] = static_cast<uint32_t>(d) < ndw ? __builtin_nontemporal_load(q + d) : 0u;
-  W[13] = 0u;
+// cnt >= 1 bytes of a heap string, src -> dst (LDS), both at any byte alignment: gfx950 takes unaligned 16- / 8- / 4-byte
+// accesses in global memory and in LDS alike, so a string travels in pieces of 16 bytes whose last piece ends where the
+// string ends and overlaps the one before it (the same bytes written twice) -- no funnel shifts, no head or tail bytes, and
+// never a byte read outside [src, src + cnt).  Up to 64 bytes are four loads in flight, those a shorter string does not
+// need predicated off; longer strings go on 16 bytes at a time.  (The formulation before this one covered 48 bytes with 13
+// aligned dword loads, 13 v_alignbyte_b32 and as many predicated dword stores per row: the kernel is bound by instruction
+// issue, and on DuckDB's own string heaps -- long strings back to back, no gaps for the inline ones, so no wave-wide copy --
+// every long row took it.)
+typedef u32x2 u32x2_a1 __attribute__((aligned(1)));
+typedef uint32_t u32_a1 __attribute__((aligned(1)));
+__device__ __forceinline__ void heap_bytes_to_lds(uint8_t* dst, gptr<const uint8_t> src, uint32_t cnt) {
+  if (cnt >= 16) {
+    const uint32_t last = cnt - 16;
+    const bool hb = last > 16, hc = last > 32;
+    const u32x4 a = __builtin_nontemporal_load((gptr<const u32x4_a1>)src);
+    const u32x4 e = __builtin_nontemporal_load((gptr<const u32x4_a1>)(src + last));
+    u32x4 b = a, c = a;
+    if (hb) b = __builtin_nontemporal_load((gptr<const u32x4_a1>)(src + 16));
+    if (hc) c = __builtin_nontemporal_load((gptr<const u32x4_a1>)(src + 32));
+    *reinterpret_cast<u32x4_a1*>(dst) = a;
+    if (hb) *reinterpret_cast<u32x4_a1*>(dst + 16) = b;
+    if (hc) *reinterpret_cast<u32x4_a1*>(dst + 32) = c;
+    *reinterpret_cast<u32x4_a1*>(dst + last) = e;
+#pragma clang loop unroll(disable)
+    for (uint32_t done = 48; done < last; done += 16)
+      *reinterpret_cast<u32x4_a1*>(dst + done) = __builtin_nontemporal_load((gptr<const u32x4_a1>)(src + done));
+  } else if (cnt >= 8) {
+    const u32x2 a = *(gptr<const u32x2_a1>)src, e = *(gptr<const u32x2_a1>)(src + (cnt - 8));
+    *reinterpret_cast<u32x2_a1*>(dst) = a;
+    *reinterpret_cast<u32x2_a1*>(dst + (cnt - 8)) = e;
+  } else if (cnt >= 4) {
+    const uint32_t a = *(gptr<const u32_a1>)src, e = *(gptr<const u32_a1>)(src + (cnt - 4));
+    *reinterpret_cast<u32_a1*>(dst) = a;
+    *reinterpret_cast<u32_a1*>(dst + (cnt - 4)) = e;
+  } else {
+    const uint8_t a = src[0], m = src[cnt >> 1], e = src[cnt - 1];   // 1: a a a; 2: a e e; 3: a m e
+    dst[0] = a;
+    dst[cnt >> 1] = m;
+    dst[cnt - 1] = e;
+  }
 }
 
-// Bytes [c0, c0 + cnt) of one string -> LDS at dst, a long string in pieces of 48 bytes (13 aligned dwords each).
+// Bytes [c0, c0 + cnt) of one string -> LDS at dst: an inline string from its registers, a long one from the heap.
 __device__ __forceinline__ void string_bytes_to_lds(uint8_t* dst, const u32x4& s, gptr<const uint8_t> heap, uint64_t ptr_base,
                                                     uint32_t c0, uint32_t cnt) {
   if (s.x <= 12) {
@@ -296,14 +328,7 @@ __device__ __forceinline__ void string_bytes_to_lds(uint8_t* dst, const u32x4& s
     return;
   }
   const uint64_t p = static_cast<uint64_t>(s.z) | (static_cast<uint64_t>(s.w) << 32);
-  gptr<const uint8_t> src = heap + (p - ptr_base) + c0;
-  const uint32_t mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(src) & 3);
-  uint32_t W[14];
-#pragma clang loop unroll(disable)
-  for (uint32_t done = 0; done < cnt; done += 48) {
-    heap_load13(src + done, cnt - done, W);
-    lds_put_stream<12>(dst + done, W, mis, cnt - done < 48u ? cnt - done : 48u);
-  }
+  heap_bytes_to_lds(dst, heap + (p - ptr_base) + c0, cnt);
 }
 
 // Stage bytes [shiftw, end) -> gbase[shiftw, end) by the whole workgroup (end > shiftw); gbase is 16-byte aligned:
@@ -339,9 +364,8 @@ __device__ __forceinline__ void stage_to_data(const uint8_t* st, uint32_t shiftw
 // assembled in LDS in windows of <= 8 KiB on two alternating stage buffers (one barrier per window) and leaves as coalesced
 // 16-byte nontemporal stores.  How the bytes reach LDS is decided per wave: when its long strings lie in the heap as they
 // will lie in the data buffer (vectors decoded from Arrow buffers, staged heaps), the span from the first to the last of
-// them is ONE coalesced copy and only the inline strings place themselves; otherwise every row brings its own bytes, 48 at
-// a time as 13 aligned dword loads, with dword stores (two v_alignbyte_b32 funnel shifts, <= 3 head / tail byte stores,
-// predicated straight-line code).  The kernel keeps to 64 VGPRs and 17 KiB of LDS: 8 workgroups per CU.
+// them is ONE coalesced copy and only the inline strings place themselves; otherwise every long row brings its own bytes
+// in unaligned 16-byte pieces (heap_bytes_to_lds).  The kernel keeps to 64 VGPRs and 17 KiB of LDS: 8 workgroups per CU.
 //
 // Look-back words: tile_state[tile] bits 62..63 = 0 nothing yet, 1 = sum of this tile, 2 = sum of every tile of the column up
 // to and including this one.  They are read and written with RELAXED agent-scope atomics: the word is the whole message, and
@@ -536,7 +560,7 @@ __global__ __launch_bounds__(kBlockThreads, 8) void encode_string_1p(const mi_co
     // Do the long strings of this wave's 64 rows lie in the heap the way they will lie in the data buffer (every one of them
     // at the same distance from its place in the sub-block)?  Vectors decoded from Arrow buffers do, and so does a staged
     // heap.  Then the bytes between the first and the last long string are one coalesced copy (16 bytes per lane) instead
-    // of 13 dword loads and as many funnel shifts per row, and only the short rows, whose bytes are inline, place them
+    // of two to four loads per row, and only the short rows, whose bytes are inline, place them
     // themselves -- after the copy, over whatever the heap holds where they go (LDS accesses of one wave execute in program
     // order).  The bytes between two long strings are < 64 * 12 bytes apart, so they share a 4 KiB page with the end of one
     // or the start of the other: reading them cannot fault.  Anything else takes the per-row path below.

@@ -10,27 +10,32 @@
 // block, and inside a frame with linked blocks -- what LZ4F_compressFrame writes -- a match may reach back into the
 // previous block, so "one wave per block, copy as you parse" serialises a whole buffer.  The work is therefore cut the
 // other way round, into steps that are each data parallel and never wait for another workgroup:
-//   1. lz4_parse    one workgroup (256 lanes) per block walks the tokens only (no data is copied): one descriptor per
-//                   sequence {output position, literal source, literal length, match length} + offset, and the block's
-//                   decompressed size.  The lanes walk 256 segments of the block speculatively, exchange where they leave
-//                   them and repeat until their start positions agree (see the kernel).  Every block of every buffer at once.
+//   1. lz4_parse_dp one workgroup (256 lanes) per block, tokens only (no data is copied): one descriptor per sequence
+//                   {output position, literal source, literal length, match length} + offset in the lane's slice, and the
+//                   block's decompressed size.  Every lane tabulates for every byte of its segment where a walk with a token
+//                   there leaves the segment (one backward pass in LDS), one lane follows the chain through the tables, then
+//                   every lane walks once from its true entry and stores.  Blocks too large for the tables keep lz4_parse,
+//                   the speculative formulation (guessed entries, repeated until they agree).
 //                   (ZSTD: zstd_entropy produces the same descriptors from the Huffman / FSE streams.)
 //   2. lz4_layout   one lane per buffer: first output byte of each of its blocks (running sum), and the check the
 //                   reference makes after decompressing: the sizes must add up to the declared uncompressed length.
 //                   (ZSTD: zstd_layout, which also settles the repeat offsets.)
-//   3. lz4_expand   one workgroup per block, output-centric: a thread owns 256 consecutive output bytes, finds its first
-//                   sequence by binary search and walks on from there.  Every decompressed byte gets a 32-bit LINK word -- a
-//                   literal's word holds the byte itself, a match byte's word the position it copies from (always an earlier
-//                   byte of the buffer; an overlapping match links straight into its first period).
-//   4. lz4_resolve_local / lz4_collect / lz4_resolve_skeleton
-//                   pointer jumping over the links, in place: first inside 8 KiB tiles in LDS until nothing moves, then over
-//                   the SKELETON only -- the still-open words that other tiles' open words point at -- four hops per round,
-//                   <= log5(tiles of the longest buffer) + 1 rounds launched blindly (a round that finds nothing left makes
-//                   the later ones return at once).
-//   5. lz4_emit     the last hop of everything outside the skeleton, then the bytes leave the link words for the
+//   3. k8_chunk_map numbers the CHUNKS (<= 8 KiB of one block's output) of the launch set: the later kernels run one
+//                   workgroup per chunk.
+//   4. k8_expand_local
+//                   a chunk's sequences are dealt to the threads one each; every decompressed byte gets a 32-bit LINK word in
+//                   LDS -- a literal's word holds the byte itself, a match byte's word the position it copies from (always an
+//                   earlier byte of the buffer; an overlapping match links straight into its first period) -- and the links
+//                   that stay inside the chunk are followed right there until nothing moves.  The words reach HBM once;
+//                   targets in earlier chunks are marked.
+//   5. lz4_collect / lz4_resolve_skeleton
+//                   pointer jumping over the SKELETON only -- the still-open words that other chunks' open words point at --
+//                   24 hops per round, 3 rounds launched blindly (a round that finds nothing left makes the later ones return
+//                   at once).
+//   6. k8_emit      the last hop of everything outside the skeleton, then the bytes leave the link words for the
 //                   decompressed body; a word still open here is an error, never silent data.
-// HBM traffic per decompressed byte: 4 B memset + 4 B expand + 8 B local pass + 5 B emit (+ the skeleton's few words).  The
-// token walk of step 1 is the latency-bound part -- hence the speculative lanes.
+// HBM traffic per decompressed byte: 4 B of link words written + 1 B of marks cleared by the batch's one memset + 4 B read and
+// 1 B written by k8_emit (+ the descriptors, 20 B per sequence, and the skeleton's few words).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -906,7 +911,8 @@ hipError_t LaunchLz4Decompress(const Lz4Args& a, int num_cus, hipStream_t stream
   if (a.n_blocks == 0) return hipSuccess;
   if (a.zblocks) {
     static const bool windowed = std::getenv("MI_ZSTD_WINDOWED") != nullptr;   // tests / A-B: the first formulation's readers
-    hipLaunchKernelGGL(zstd_entropy, dim3(a.n_blocks), dim3(kZstdThreads), 0, stream, a, windowed ? 0u : 1u);
+    static const bool probe = std::getenv("MI_ZSTD_PROBE") != nullptr;          // diagnostics: a few blocks print where their time went
+    hipLaunchKernelGGL(zstd_entropy, dim3(a.n_blocks), dim3(kZstdThreads), 0, stream, a, (windowed ? 0u : 1u) | (probe ? 0x100u : 0u));
     hipLaunchKernelGGL(zstd_layout, dim3(a.n_buffers), dim3(64), 0, stream, a);
   } else {
     // compressed blocks below 64 KiB (64 KiB is the default block size of every writer) are walked from an LDS copy

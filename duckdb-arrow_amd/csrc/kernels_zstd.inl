@@ -79,36 +79,144 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a, uint32_t
     return;
   }
   if (tid == 0) s_fail = 0;
-  const bool staged = pos != 0;   // uniform (the name is history: the positional path)
+  const bool staged = (pos & 1u) != 0;   // uniform (the name is history: the positional path)
+  const bool probe = (pos & 0x100u) != 0 && bi % 41u == 3u;   // MI_ZSTD_PROBE: this block prints its phases (10 ns ticks)
+  const uint64_t t_start = probe ? wall_clock64() : 0;
   __syncthreads();
   // --- tables ---------------------------------------------------------------------------------------------------------
+  // The descriptions (a Huffman tree: <= 129 bytes; three FSE distributions: <= 153 bytes together) are first copied to LDS by
+  // the whole wave -- the stream windows are not in use yet -- because parsing them is a chain of dependent byte reads, a few
+  // per symbol: from HBM that chain was most of the 0.27 ms the tables took.  One lane parses (weights / normalized counts, the
+  // FSE spread); the steps whose result does not depend on the order of execution -- the Huffman cells, an FSE cell's state
+  // number = its rank among its symbol's cells -- are done by the whole wave.
+  constexpr uint32_t kDescBytes = 256;   // staged per description; the rest of the staging area reads as zero
   if (wave == 0) {
-    if (lane == 0 && z.lit_type >= 2) {
+    if (z.lit_type >= 2) {   // uniform
       const zstd::BlockInfo hs = zb[z.huf_src];
-      uint32_t bits = 0;
-      const uint32_t desc = zstd::ReadHuffmanTable(comp + hs.comp_off + hs.lit_hdr, hs.lit_comp, huf, &bits, (ldsptr<uint8_t>)s_weights,
-                                                   (ldsptr<zstd::FseCell>)s_wcells, (ldsptr<int16_t>)s_counts[3], (ldsptr<uint16_t>)s_next[3]);
-      if (!desc) s_fail = 1;
-      s_desc = z.lit_type == 2 ? desc : 0;
-      s_huf_bits = bits;
+      ldsptr<uint8_t> desc_lds = (ldsptr<uint8_t>)s_win;
+      gptr<const uint8_t> src = comp + hs.comp_off + hs.lit_hdr;
+      const uint32_t avail = hs.lit_comp < kDescBytes ? hs.lit_comp : kDescBytes;
+      for (uint32_t i = lane; i < kDescBytes + 8; i += 64) desc_lds[i] = i < avail ? src[i] : uint8_t(0);
+      __builtin_amdgcn_wave_barrier();
+      uint32_t n = 0, bits = 0, desc = 0;
+      if (lane == 0)
+        desc = zstd::ReadHuffmanWeights((ldsptr<const uint8_t>)desc_lds, avail, &n, &bits, (ldsptr<uint8_t>)s_weights, (ldsptr<zstd::FseCell>)s_wcells,
+                                        (ldsptr<int16_t>)s_counts[3], (ldsptr<uint16_t>)s_next[3]);
+      __builtin_amdgcn_wave_barrier();
+      desc = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(desc)));
+      n = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(n)));
+      bits = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(bits)));
+      bool ok = desc != 0;
+      if (ok) {
+        // cells in the order of ascending weight, symbols of one weight in symbol order (FillHuffmanTable): a symbol's first
+        // cell from ballots, short runs written by the symbol's lane, long ones by the whole wave
+        uint32_t wgt[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) wgt[k] = lane + 64u * k < n ? s_weights[lane + 64u * k] : 0u;
+        const uint64_t below = (1ull << lane) - 1ull;
+        uint32_t at = 0;
+        for (uint32_t w = 1; w <= bits; w++) {
+          const uint32_t len = 1u << (w - 1);
+          const uint16_t tag = static_cast<uint16_t>((bits + 1 - w) << 8);
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const bool has = wgt[k] == w;
+            const uint64_t mask = __ballot(has ? 1 : 0);
+            if (mask == 0) continue;   // uniform
+            if (len < 64) {
+              if (has) {
+                const uint32_t start = at + static_cast<uint32_t>(__builtin_popcountll(mask & below)) * len;
+                for (uint32_t i = 0; i < len; i++) huf[start + i] = static_cast<uint16_t>(tag | (lane + 64u * k));
+              }
+            } else {
+              uint32_t start = at;
+              for (uint64_t m = mask; m; m &= m - 1, start += len) {
+                const uint16_t cell = static_cast<uint16_t>(tag | (static_cast<uint32_t>(__builtin_ctzll(m)) + 64u * k));
+                for (uint32_t i = lane; i < len; i += 64) huf[start + i] = cell;
+              }
+            }
+            at += static_cast<uint32_t>(__builtin_popcountll(mask)) * len;
+          }
+        }
+        ok = at == (1u << bits);
+      }
+      if (lane == 0) {
+        if (!ok) s_fail = 1;
+        s_desc = z.lit_type == 2 ? desc : 0;
+        s_huf_bits = bits;
+      }
     }
-  } else if (lane < 3 && z.nseq) {
-    const int t = static_cast<int>(lane);
-    const zstd::BlockInfo sb = zb[t == 0 ? z.ll_src : t == 1 ? z.of_src : z.ml_src];
-    const uint32_t so = sb.seq_pos + sb.seq_hdr;
-    ldsptr<zstd::FseCell> tab = t == 0 ? t_ll : t == 1 ? t_of : t_ml;
-    const uint32_t al = so < sb.comp_size ? zstd::BuildSequenceTable(comp + sb.comp_off + so, sb.comp_size - so, t, tab, (ldsptr<int16_t>)s_counts[t],
-                                                                      (ldsptr<uint16_t>)s_next[t])
-                                          : ~0u;
-    if (al == ~0u) s_fail = 1;
-    s_al[t] = al;
-  } else if (lane == 3 && z.nseq) {   // where the block's own bitstream begins: behind its table descriptions
-    const uint32_t so = z.seq_pos + z.seq_hdr;
-    const uint32_t bo = zstd::SequenceBitstreamOffset(c + so, z.comp_size - so, (ldsptr<int16_t>)s_counts[4]);
-    if (bo == 0 || so + bo >= z.comp_size) s_fail = 1;
-    s_bits_at = so + bo;
+  } else if (z.nseq) {   // uniform
+    // lanes 0..2: the literal-length, offset and match-length tables, each from the block that describes it; lane 3: where
+    // this block's own bitstream begins.  Four descriptions of 256 bytes in the sequences' window.
+    ldsptr<uint8_t> desc_lds = (ldsptr<uint8_t>)s_seqwin;
+    static_assert(kZstdSeqWindowWords * 4 == 4 * kDescBytes, "four staged descriptions");
+    {
+      const uint32_t r = lane >> 4;   // 16 lanes per description, 16 bytes each
+      const zstd::BlockInfo sb = zb[r == 0 ? z.ll_src : r == 1 ? z.of_src : r == 2 ? z.ml_src : bi];
+      const uint32_t so = sb.seq_pos + sb.seq_hdr;
+      const uint32_t avail = so < sb.comp_size ? sb.comp_size - so : 0u;
+      gptr<const uint8_t> src = comp + sb.comp_off + so;
+      uint8_t v[16];
+#pragma unroll
+      for (uint32_t i = 0; i < 16; i++) {
+        const uint32_t at = 16u * (lane & 15u) + i;
+        v[i] = at < avail ? src[at] : uint8_t(0);
+      }
+#pragma unroll
+      for (uint32_t i = 0; i < 16; i++) desc_lds[r * kDescBytes + 16u * (lane & 15u) + i] = v[i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t al = 0, nsym = 0;
+    if (lane < 3) {
+      const int t = static_cast<int>(lane);
+      const zstd::BlockInfo sb = zb[t == 0 ? z.ll_src : t == 1 ? z.of_src : z.ml_src];
+      const uint32_t so = sb.seq_pos + sb.seq_hdr;
+      const uint32_t avail = so < sb.comp_size ? (sb.comp_size - so < kDescBytes - 4 ? sb.comp_size - so : kDescBytes - 4) : 0u;
+      ldsptr<zstd::FseCell> tab = t == 0 ? t_ll : t == 1 ? t_of : t_ml;
+      al = avail ? zstd::BuildSequenceTable<false>((ldsptr<const uint8_t>)desc_lds + lane * kDescBytes, avail, t, tab, (ldsptr<int16_t>)s_counts[t],
+                                                   (ldsptr<uint16_t>)s_next[t], &nsym)
+                 : ~0u;
+      if (al == ~0u) s_fail = 1;
+      s_al[t] = al;
+    } else if (lane == 3) {
+      const uint32_t so = z.seq_pos + z.seq_hdr;
+      const uint32_t avail = z.comp_size - so < kDescBytes - 4 ? z.comp_size - so : kDescBytes - 4;
+      const uint32_t bo = zstd::SequenceBitstreamOffset((ldsptr<const uint8_t>)desc_lds + 3 * kDescBytes, avail, (ldsptr<int16_t>)s_counts[4]);
+      if (bo == 0 || so + bo >= z.comp_size) s_fail = 1;
+      s_bits_at = so + bo;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // the cells: a cell's state number is its symbol's counter + its rank among that symbol's cells in table order.  Lane s
+    // keeps the counter of symbol s (<= 53 symbols); 64 cells at a time, one ballot per distinct symbol among them.
+#pragma unroll 1
+    for (int t = 0; t < 3; t++) {
+      const uint32_t t_al = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(al), t));
+      const uint32_t t_nsym = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(nsym), t));
+      if (t_al == ~0u || t_nsym == 0) continue;   // malformed, or an RLE table (one cell, final)
+      ldsptr<zstd::FseCell> tab = t == 0 ? t_ll : t == 1 ? t_of : t_ml;
+      uint32_t counter = lane < t_nsym ? s_next[t][lane] : 0u;
+      const uint32_t size = 1u << t_al;
+      const uint64_t below = (1ull << lane) - 1ull;
+      for (uint32_t u0 = 0; u0 < size; u0 += 64) {
+        const uint32_t u = u0 + lane;
+        const bool valid = u < size;
+        const uint32_t sym = valid ? static_cast<uint32_t>(tab[u]) & 63u : 64u;
+        uint32_t ns = 1;
+        for (uint64_t left = __ballot(valid ? 1 : 0); left;) {   // uniform
+          const uint32_t ls = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(sym), __builtin_ctzll(left)));
+          const uint64_t same = __ballot(sym == ls ? 1 : 0);
+          const uint32_t base = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(counter), static_cast<int>(ls)));
+          if (sym == ls) ns = base + static_cast<uint32_t>(__builtin_popcountll(same & below));
+          if (lane == ls) counter = base + static_cast<uint32_t>(__builtin_popcountll(same));
+          left &= ~same;
+        }
+        if (valid) tab[u] = zstd::FinishFseCell(sym, ns, t_al, t);
+      }
+    }
   }
   __syncthreads();
+  const uint64_t t_tables = probe ? wall_clock64() : 0;
   const bool failed = s_fail != 0;   // uniform
   const uint32_t bits_at = z.nseq && !failed ? s_bits_at : 0, bits_len = z.nseq && !failed ? z.comp_size - bits_at : 0;
   // --- streams --------------------------------------------------------------------------------------------------------
@@ -134,28 +242,74 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a, uint32_t
         ok = ok && zstd::DecodeHuffmanStream(br, c + first, nbytes, nsym, huf, s_huf_bits, arena + z.lit_pos + out0);
       }
       if (!ok) lz4_fail(a.status);   // the block's size is still reported by wave 1; the batch is rejected through the status word
+      if (probe)
+        printf("zprobe lit block %u stream %u: tables %llu literals %llu ticks, %u symbols, %u bytes\n", bi, lane,
+               (unsigned long long)(t_tables - t_start), (unsigned long long)(wall_clock64() - t_tables), nsym, nbytes);
     }
     return;
   }
   if (staged) {
-    // ---- wave 1, positional path: lane 0 runs the FSE state machine alone, 64 sequences at a time, and leaves {literal length,
-    // match length, offset code} in LDS; everything else about those 64 sequences is done by the whole wave: positions by a
-    // wave scan, the repeat-offset history by a segmented scan of the sequences' functions (zstd_format.hpp RepFunction; a
-    // segment = one of the block's 256 descriptor slices), descriptors and offsets as coalesced stores.  On one lane that
-    // bookkeeping was four fifths of the 1 us a sequence cost.
-    __shared__ uint32_t s_trip[64][3];
+    // ---- wave 1, positional path.  The three FSE states (offset, match length, literal length) sit on lanes 0, 1, 2: a lane
+    // looks up ITS cell, the three exchange how many bits their fields take (v_readlane: the head position of the bitstream
+    // and every field position are scalars), and each reads its two fields -- the extra bits of its value, the bits of its
+    // next state -- from the window of the stream in LDS: one cell look-up and one pair of field reads per sequence as the
+    // dependent chain, a third of the instructions one lane needed for all three states.  The window (1 KiB) is refilled
+    // by the whole wave before a group of 64 sequences whenever fewer than 64 worst-case sequences (88 bits each) are left
+    // in it, so the state machine itself never waits for HBM.  The three values of a sequence go to s_trip; everything else
+    // about those 64 sequences is done by the whole wave: positions by a wave scan, the repeat-offset history by a segmented
+    // scan of the sequences' functions (zstd_format.hpp RepFunction; a segment = one of the block's 256 descriptor slices),
+    // descriptors and offsets as coalesced stores.
+    __shared__ uint32_t s_trip[64][3];   // {literal length, match length, offset value} of the group's sequences
     gptr<u32x4> rep_fn = GM<u32x4>(a.rep_state) + static_cast<size_t>(bi) * kParseLanes;
     const uint32_t I0 = zstd::RepSlot(0), I1 = zstd::RepSlot(1), I2 = zstd::RepSlot(2);
-    using SeqWords = zstd::SlidingWords<gptr<const uint8_t>, ldsptr<uint32_t>, kZstdSeqWindowWords>;
-    zstd::SeqPosDecoder<SeqWords, ldsptr<zstd::FseCell>> dec;
-    bool ok0 = !failed;
-    if (lane == 0 && ok0 && z.nseq) {
-      const uint32_t mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(c + bits_at) & 3u);
-      SeqWords sw;
-      sw.Init(c + bits_at - mis, (ldsptr<uint32_t>)s_seqwin);
-      ok0 = dec.Open(sw, mis, bits_len, t_ll, s_al[0], t_of, s_al[1], t_ml, s_al[2]);
+    constexpr int32_t kW = kZstdSeqWindowWords;
+    constexpr int32_t kGroupBits = 64 * 88;   // a sequence takes at most 30 + 16 + 16 extra bits and 9 + 9 + 8 state bits
+    ldsptr<uint32_t> win = (ldsptr<uint32_t>)s_seqwin;
+    const uint32_t mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(c + bits_at) & 3u);
+    gptr<const uint8_t> wbase = c + bits_at - mis;   // word 0 of the stream: the 4-byte boundary at or before its first byte
+    int32_t wlo = 0;                                  // the window holds words wlo .. wlo + kW - 1 (uniform)
+    auto refill = [&](int32_t top_word) {             // whole wave: top_word becomes the window's last word
+      wlo = top_word + 1 - kW;
+      uint32_t v[kW / 64];
+#pragma unroll
+      for (int k = 0; k < kW / 64; k++) {
+        const int32_t j = wlo + static_cast<int32_t>(lane) + 64 * k;
+        v[k] = j >= 0 ? zstd::Mem<gptr<const uint8_t>>::Load32(wbase + 4 * j) : 0u;
+      }
+#pragma unroll
+      for (int k = 0; k < kW / 64; k++) win[lane + 64 * k] = v[k];
+      __builtin_amdgcn_wave_barrier();
+    };
+    auto field = [&](int32_t at, uint32_t n) -> uint32_t {   // bits [at, at + n) of the stream, n < 32, inside the window
+      const int32_t i = (at >> 5) - wlo;
+      return __builtin_amdgcn_alignbit(win[i + 1], win[i], static_cast<uint32_t>(at) & 31u) & ((1u << n) - 1u);
+    };
+    bool ok0 = !failed;    // uniform from here on
+    int32_t q = 0;         // head of the backward bitstream, in bits from word 0 (uniform)
+    const int32_t floor = static_cast<int32_t>(8 * mis);
+    uint32_t state = 0;    // lanes 0..2: the lane's FSE state
+    const ldsptr<zstd::FseCell> tab = lane == 0 ? t_of : (lane == 1 ? t_ml : t_ll);
+    if (ok0 && z.nseq) {
+      ok0 = bits_len != 0;
+      if (ok0) {
+        const uint32_t last_at = mis + bits_len - 1;
+        refill(static_cast<int32_t>(last_at >> 2) + 1);
+        const uint32_t last = (win[static_cast<int32_t>(last_at >> 2) - wlo] >> (8 * (last_at & 3u))) & 0xFFu;
+        const uint32_t al_ll = s_al[0], al_of = s_al[1], al_ml = s_al[2];
+        const uint32_t last_u = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(last)));
+        ok0 = last_u != 0;
+        if (ok0) {
+          q = static_cast<int32_t>(8 * last_at + zstd::HighBit(last_u));
+          ok0 = q - static_cast<int32_t>(al_ll + al_of + al_ml) >= floor;
+        }
+        if (ok0) {   // the initial states: literal length, offset, match length (sequences of <= 9 bits: inside the window)
+          const int32_t q_ll = q - static_cast<int32_t>(al_ll), q_of = q_ll - static_cast<int32_t>(al_of), q_ml = q_of - static_cast<int32_t>(al_ml);
+          state = lane == 0 ? field(q_of, al_of) : (lane == 1 ? field(q_ml, al_ml) : field(q_ll, al_ll));
+          q = q_ml;
+        }
+      }
     }
-    bool ok = __shfl(ok0 ? 1 : 0, 0, 64) != 0;
+    bool ok = ok0;
     uint32_t out_base = 0, lit_base = 0, n_desc = 0;          // uniform: totals of the groups before this one
     uint32_t cx = I0, cy = I1, cz = I2;                        // the function of the slice that straddles the group's start, up to there
     uint32_t slice_base = 0;                                   // ... and the output position that slice began at
@@ -166,10 +320,14 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a, uint32_t
     };
     auto group = [&](uint32_t cnt) {   // the descriptors n_desc .. n_desc + cnt - 1, their triples in s_trip
       const bool active = lane < cnt;
-      const uint32_t ll = active ? s_trip[lane][0] : 0u, ml = active ? s_trip[lane][1] : 0u, code = active ? s_trip[lane][2] : 0u;
+      const uint32_t ll = active ? s_trip[lane][0] : 0u, ml = active ? s_trip[lane][1] : 0u, ov = active ? s_trip[lane][2] : 1u;
+      // the offset value as DecodeSequences emits it: > 3 an offset, 1..3 a repeat offset (shifted by one after an empty
+      // literal run); ov == 0 only for the literals-only descriptor behind the last sequence
+      const uint32_t code = ov > 3 ? ov - 3 : (ov == 0 ? 0u : (zstd::kRepMarker | (ov - 1 + (ll == 0 ? 1u : 0u))));
       const uint32_t incl_ll = wave_inclusive_scan_u32(ll), incl_out = wave_inclusive_scan_u32(ll + ml);
       const uint32_t lit_i = lit_base + incl_ll - ll, out_i = out_base + incl_out - (ll + ml);
-      bool bad = active && (lit_i > z.lit_regen || ll > z.lit_regen - lit_i || out_i > zstd::kBlockMax || ll + ml > zstd::kBlockMax - out_i);
+      bool bad = active && (lit_i > z.lit_regen || ll > z.lit_regen - lit_i || out_i > zstd::kBlockMax || ll + ml > zstd::kBlockMax - out_i ||
+                            (ov > 3 && ov - 3 >= zstd::kRepMarker));   // offset code 31: see DecodeSequences
       const uint32_t n = n_desc + lane, k = n / per, j = n - k * per;
       const bool head = active && j == 0;
       const uint64_t heads = __ballot(head ? 1 : 0);
@@ -229,24 +387,56 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a, uint32_t
       n_desc += cnt;
       if (__any(bad ? 1 : 0)) ok = false;
     };
+    uint64_t t_step = 0, t_group = 0;
     for (uint32_t g0 = 0; g0 < z.nseq && ok; g0 += 64) {
       const uint32_t cnt = z.nseq - g0 < 64u ? z.nseq - g0 : 64u;
-      if (lane == 0) {
-        for (uint32_t i = 0; i < cnt && ok0; i++) {
-          uint32_t ll, ml, code;
-          ok0 = dec.Step(g0 + i + 1 < z.nseq, &ll, &ml, &code);
-          s_trip[i][0] = ll;
-          s_trip[i][1] = ml;
-          s_trip[i][2] = code;
+      const uint64_t t0 = probe ? wall_clock64() : 0;
+      if (((q - kGroupBits) >> 5) < wlo) refill((q >> 5) + 1);   // uniform
+      if (lane < 3) {
+        const uint32_t m1 = lane >= 1 ? ~0u : 0u, m2 = lane >= 2 ? ~0u : 0u, n1 = lane <= 1 ? ~0u : 0u, n0 = lane == 0 ? ~0u : 0u;
+#pragma clang loop unroll(disable)
+        for (uint32_t i = 0; i < cnt; i++) {
+          const zstd::FseCell cell = tab[state];
+          // {state bits, extra bits} of the three lanes as scalars; the block's last sequence updates no state
+          uint32_t pack = static_cast<uint32_t>(cell >> 48);
+          if (g0 + i + 1 == z.nseq) pack &= 0xFF00u;
+          const uint32_t k_of = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(pack), 0)),
+                         k_ml = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(pack), 1)),
+                         k_ll = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(pack), 2));
+          const uint32_t e_of = k_of >> 8, e_ml = k_ml >> 8, e_ll = k_ll >> 8, b_of = k_of & 0xFFu, b_ml = k_ml & 0xFFu, b_ll = k_ll & 0xFFu;
+          // the fields below the head: offset extra, match-length extra, literal-length extra, then the bits of the next
+          // literal-length, match-length and offset states
+          const int32_t q_extra = q - static_cast<int32_t>(e_of + e_ml + e_ll), q_next = q_extra - static_cast<int32_t>(b_ll + b_ml + b_of);
+          if (q_next < floor) {   // the stream ran out (uniform)
+            ok0 = false;
+            break;
+          }
+          const int32_t pe = q - static_cast<int32_t>(e_of + (e_ml & m1) + (e_ll & m2));
+          const int32_t pb = q_extra - static_cast<int32_t>(b_ll + (b_ml & n1) + (b_of & n0));
+          const uint32_t value = zstd::CellBase(cell) + field(pe, pack >> 8);
+          state = zstd::CellNext(cell) + field(pb, pack & 0xFFu);
+          s_trip[i][2u - lane] = value;
+          q = q_next;
         }
-        if (ok0 && g0 + cnt == z.nseq) ok0 = dec.AtEnd();
       }
+      // (q and ok0 were computed from v_readlane results inside the three-lane region: make them wave-uniform again)
+      q = __builtin_amdgcn_readfirstlane(q);
+      ok0 = __builtin_amdgcn_readfirstlane(ok0 ? 1 : 0) != 0;
+      if (ok0 && g0 + cnt == z.nseq) ok0 = q == floor;
       __builtin_amdgcn_wave_barrier();
-      ok = __shfl(ok0 ? 1 : 0, 0, 64) != 0;
+      ok = ok0;
       if (!ok) break;
+      const uint64_t t1 = probe ? wall_clock64() : 0;
       group(cnt);
       __builtin_amdgcn_wave_barrier();
+      if (probe) {
+        t_step += t1 - t0;
+        t_group += wall_clock64() - t1;
+      }
     }
+    if (probe && lane == 0)
+      printf("zprobe seq block %u: tables %llu steps %llu groups %llu ticks, %u sequences, %u bytes of bitstream, %u literals\n", bi,
+             (unsigned long long)(t_tables - t_start), (unsigned long long)t_step, (unsigned long long)t_group, z.nseq, bits_len, z.lit_regen);
     if (ok && lit_base < z.lit_regen) {   // the literals behind the last sequence: a descriptor without a match
       if (lane == 0) {
         s_trip[0][0] = z.lit_regen - lit_base;

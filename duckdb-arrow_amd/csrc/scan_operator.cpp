@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -67,8 +69,17 @@ ArrowScan::ArrowScan(Context* ctx_p, std::vector<ArrowIPCBuffer> buffers_p, cons
   staging.resize(slots.size() + 2 * kMaxProducers + 2);   // slots + queues + the bodies being read + a decompressed copy
 }
 
+namespace {
+inline int64_t TraceNow() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
 ArrowScan::~ArrowScan() {
   StopProducer();
+  if (trace)
+    std::fprintf(stderr, "mi scan trace: %lld batches; pipeline thread: enqueue %.3f s, waiting for input %.3f s, waiting for the GPU %.3f s, polling %.3f s; "
+                         "producers (%d, summed): reading %.3f s, queue full %.3f s, no staging buffer %.3f s\n",
+                 static_cast<long long>(stats.record_batches), tr_enqueue_ns * 1e-9, tr_fetch_wait_ns * 1e-9, tr_event_wait_ns * 1e-9, tr_poll_ns * 1e-9, n_producers,
+                 tr_read_ns.load() * 1e-9, tr_push_wait_ns.load() * 1e-9, tr_lease_wait_ns.load() * 1e-9);
   try {
     ctx->Bind();
   } catch (...) {
@@ -1273,12 +1284,14 @@ std::shared_ptr<void> ArrowScan::LeaseStaging(size_t bytes, uint8_t** ptr) {
   Staging* st = nullptr;
   {
     std::unique_lock<std::mutex> lk(q_mu);
+    const int64_t t0 = trace ? TraceNow() : 0;
     q_cv.wait(lk, [&] {
       if (producer_stop) return true;
       for (auto& x : staging)
         if (!x.leased) return true;
       return false;
     });
+    if (trace) tr_lease_wait_ns += TraceNow() - t0;
     if (producer_stop) throw IOException("scan closed while reading");
     // prefer a free buffer that is already large enough
     for (auto& x : staging)
@@ -1309,7 +1322,9 @@ void ArrowScan::ProducerLoop(int p) {
   const size_t cap = n_producers > 1 ? 2 : static_cast<size_t>(kReadAhead);
   auto push = [&](Fetched&& f) {
     std::unique_lock<std::mutex> lk(q_mu);
+    const int64_t t0 = trace ? TraceNow() : 0;
     q_cv.wait(lk, [&] { return producer_stop || fetched[static_cast<size_t>(p)].size() < cap; });
+    if (trace) tr_push_wait_ns += TraceNow() - t0;
     if (producer_stop) return false;
     fetched[static_cast<size_t>(p)].push_back(std::move(f));
     lk.unlock();
@@ -1363,7 +1378,9 @@ void ArrowScan::ProducerLoop(int p) {
       Fetched f;
       const bool in_share = opts.world <= 1 || (ordinal % opts.world) == opts.rank;
       const bool mine = in_share && (share % n_producers) == p;
+      const int64_t t_read = trace ? TraceNow() : 0;
       const bool got = reader->GetNextBatch(&f.batch, opts.accept_dictionaries != 0, /*skip_body*/ !mine);
+      if (trace) tr_read_ns += TraceNow() - t_read;
       reader->ReleaseCurrentBody();  // the lease belongs to the batch alone
       if (!got) {
         si++;
@@ -1395,6 +1412,7 @@ void ArrowScan::ProducerLoop(int p) {
 void ArrowScan::StartProducer() {
   if (producer_started) return;
   producer_started = true;
+  trace = std::getenv("MI_SCAN_TRACE") != nullptr;
   // several producers only where record batches are independent of what came before them in the stream (no dictionary
   // batches, which every later batch of the file depends on) and where there is a pread to overlap (files, not caller buffers)
   n_producers = 1;
@@ -1432,7 +1450,9 @@ bool ArrowScan::SubmitNextBatch(bool may_block) {
       auto& q = fetched[static_cast<size_t>(next_fetch % n_producers)];
       if (q.empty()) {
         if (!may_block) return false;
+        const int64_t t0 = trace ? TraceNow() : 0;
         q_cv.wait(lk, [&] { return !q.empty(); });
+        if (trace) tr_fetch_wait_ns += TraceNow() - t0;
       }
       f = std::move(q.front());
       q.pop_front();
@@ -1459,7 +1479,9 @@ bool ArrowScan::SubmitNextBatch(bool may_block) {
     s.batch_index = f.ordinal;
     s.busy = true;
     try {
+      const int64_t t0 = trace ? TraceNow() : 0;
       EnqueueBatch(s);
+      if (trace) tr_enqueue_ns += TraceNow() - t0;
     } catch (...) {
       s.busy = false;
       s.batch = DecodedBatch();
@@ -1474,20 +1496,40 @@ bool ArrowScan::SubmitNextBatch(bool may_block) {
 bool ArrowScan::AcquireBatch(BatchRef* out) {
   if (!initialized) Init({});
   ctx->Bind();
-  // keep the pipeline full (blocks for input only when nothing is in flight: the batch the caller needs next)
-  while (FreeSlot() != nullptr && SubmitNextBatch(/*may_block*/ inflight.empty())) {
+  for (;;) {
+    // keep the pipeline full (blocks for input only when nothing is in flight: the batch the caller needs next)
+    while (FreeSlot() != nullptr && SubmitNextBatch(/*may_block*/ inflight.empty())) {
+    }
+    // compacted batches whose selected-row counts have arrived get their second stage, in batch order
+    for (size_t k = 0; k < inflight.size(); k++) {
+      Slot& s = slots[static_cast<size_t>(inflight[k])];
+      if (!s.needs_stage_b) continue;
+      if (k == 0 || hipEventQuery(s.filter_done) == hipSuccess) EnqueueStageB(s);
+      else break;
+    }
+    if (inflight.empty()) return false;  // exhausted
+    Slot& front = slots[static_cast<size_t>(inflight.front())];
+    // Wait for the batch the caller needs.  While slots are free and the input is not exhausted, keep an eye on the producers
+    // instead of sleeping in the event: a scan whose record batches spend milliseconds on the GPU (compressed bodies in HBM,
+    // 16 slots) otherwise submits only what the producers had ready at the moment of this call -- their queues hold a few
+    // batches -- and then waits a whole batch time with most slots idle.
+    if (exhausted || FreeSlot() == nullptr) {
+      const int64_t t0 = trace ? TraceNow() : 0;
+      MI_HIP_CHECK(hipEventSynchronize(front.d2h_done));
+      if (trace) tr_event_wait_ns += TraceNow() - t0;
+      break;
+    }
+    const hipError_t q = hipEventQuery(front.d2h_done);
+    if (q == hipSuccess) break;
+    if (q != hipErrorNotReady) MI_HIP_CHECK(q);
+    const int64_t t0 = trace ? TraceNow() : 0;
+    std::unique_lock<std::mutex> lk(q_mu);
+    auto& ready = fetched[static_cast<size_t>(next_fetch % n_producers)];
+    q_cv.wait_for(lk, std::chrono::microseconds(100), [&] { return !ready.empty(); });
+    if (trace) tr_poll_ns += TraceNow() - t0;
   }
-  // compacted batches whose selected-row counts have arrived get their second stage, in batch order
-  for (size_t k = 0; k < inflight.size(); k++) {
-    Slot& s = slots[static_cast<size_t>(inflight[k])];
-    if (!s.needs_stage_b) continue;
-    if (k == 0 || hipEventQuery(s.filter_done) == hipSuccess) EnqueueStageB(s);
-    else break;
-  }
-  if (inflight.empty()) return false;  // exhausted
   const int si = inflight.front();
   Slot& s = slots[static_cast<size_t>(si)];
-  MI_HIP_CHECK(hipEventSynchronize(s.d2h_done));
   inflight.pop_front();
   try {
     if (s.batch.deferred && !s.lz4_counted) {

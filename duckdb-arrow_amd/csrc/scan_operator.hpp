@@ -13,6 +13,7 @@
 // hipMemcpyAsync D2H (copy-back stream) -> DataChunks that alias the pinned output slot.
 #pragma once
 
+#include <atomic>
 #include <hip/hip_runtime_api.h>
 
 #include <condition_variable>
@@ -318,6 +319,10 @@ class ArrowScan : public ScanBase {
   bool compact = false;
   bool keep_on_device = false;
   mi_scan_stats stats{};
+  // MI_SCAN_TRACE: where the host threads' time went (seconds), printed when the scan closes (diagnostics only)
+  bool trace = false;
+  std::atomic<int64_t> tr_read_ns{0}, tr_push_wait_ns{0}, tr_lease_wait_ns{0};
+  int64_t tr_enqueue_ns = 0, tr_fetch_wait_ns = 0, tr_event_wait_ns = 0, tr_poll_ns = 0;
 };
 
 //! read_arrow over several GPUs of one process: one ArrowScan per context, record batch k of the file list

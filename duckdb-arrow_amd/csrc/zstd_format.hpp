@@ -255,14 +255,17 @@ MI_ZHD uint32_t ReadNCount(BP src, uint32_t avail, int type, CP counts, uint32_t
   return bytes;
 }
 
-// Normalized counts -> decoding table of 1 << al cells.  `next` is scratch for one uint16 per symbol.
+// Normalized counts -> decoding table of 1 << al cells.  `next` is scratch for one uint16 per symbol.  Two steps: the spread
+// (which symbol a cell decodes; serial: the walk over the table skips the cells of the "less than one" symbols) and the cells
+// themselves -- the k-th cell of a symbol in TABLE order gets state count + k, from which its bit count and base follow.  The
+// device runs the second step with the whole wave (kernels_zstd.inl); FinishFseCell is the part both share.
 template <typename CP, typename TP, typename NP>
-MI_ZHD bool BuildFseTable(CP counts, uint32_t nsym, uint32_t al, int type, TP table, NP next) {
+MI_ZHD bool BuildFseSpread(CP counts, uint32_t nsym, uint32_t al, TP table, NP next) {
   const uint32_t size = 1u << al, mask = size - 1;
   uint32_t high = size - 1;
   for (uint32_t s = 0; s < nsym; s++) {
     if (counts[s] == -1) {
-      table[high--] = s;   // until the last loop a cell holds its symbol
+      table[high--] = s;   // until FinishFseCell a cell holds its symbol
       next[s] = 1;
     } else {
       next[s] = static_cast<uint16_t>(counts[s]);
@@ -276,17 +279,26 @@ MI_ZHD bool BuildFseTable(CP counts, uint32_t nsym, uint32_t al, int type, TP ta
       do pos = (pos + step) & mask; while (pos > high);
     }
   }
-  if (pos != 0) return false;
+  return pos == 0;
+}
+// the cell of symbol s whose state counter stands at ns
+MI_ZHD FseCell FinishFseCell(uint32_t s, uint32_t ns, uint32_t al, int type) {
+  const uint32_t nbits = al - HighBit(ns);
+  const uint32_t nx = (ns << nbits) - (1u << al);
+  if (type == kLL) return MakeCell(LlBase(s), nx, nbits, LlBits(s));
+  if (type == kML) return MakeCell(MlBase(s), nx, nbits, MlBits(s));
+  if (type == kOF) return MakeCell(1u << s, nx, nbits, s);
+  return MakeCell(s, nx, nbits, 0);
+}
+template <typename CP, typename TP, typename NP>
+MI_ZHD bool BuildFseTable(CP counts, uint32_t nsym, uint32_t al, int type, TP table, NP next) {
+  if (!BuildFseSpread(counts, nsym, al, table, next)) return false;
+  const uint32_t size = 1u << al;
   for (uint32_t u = 0; u < size; u++) {
     const uint32_t s = static_cast<uint32_t>(table[u]);
     const uint32_t ns = next[s];
     next[s] = static_cast<uint16_t>(ns + 1);
-    const uint32_t nbits = al - HighBit(ns);
-    const uint32_t nx = (ns << nbits) - size;
-    if (type == kLL) table[u] = MakeCell(LlBase(s), nx, nbits, LlBits(s));
-    else if (type == kML) table[u] = MakeCell(MlBase(s), nx, nbits, MlBits(s));
-    else if (type == kOF) table[u] = MakeCell(1u << s, nx, nbits, s);
-    else table[u] = MakeCell(s, nx, nbits, 0);
+    table[u] = FinishFseCell(s, ns, al, type);
   }
   return true;
 }
@@ -299,8 +311,11 @@ MI_ZHD void BuildRleTable(uint32_t s, int type, TP table) {
 // (at the modes byte), `avail` = bytes from there to the end of the block; mode 3 (repeat) is resolved by the caller (it
 // passes the earlier block the table comes from).  Returns the accuracy log, ~0u = malformed.  counts/next: scratch
 // (53 entries are enough).
-template <typename BP, typename TP, typename CP, typename NP>
-MI_ZHD uint32_t BuildSequenceTable(BP seq, uint32_t avail, int type, TP table, CP counts, NP next) {
+// FINISH = false: the table is left after the spread (cells hold symbols, next[] the state counters) and *nsym_out says how
+// many symbols it has -- 0 for an RLE table, which is final as it is.
+template <bool FINISH = true, typename BP, typename TP, typename CP, typename NP>
+MI_ZHD uint32_t BuildSequenceTable(BP seq, uint32_t avail, int type, TP table, CP counts, NP next, uint32_t* nsym_out = nullptr) {
+  if (nsym_out) *nsym_out = 0;
   if (avail < 1) return ~0u;
   const uint32_t modes = seq[0];
   uint32_t at = 1;
@@ -319,6 +334,10 @@ MI_ZHD uint32_t BuildSequenceTable(BP seq, uint32_t avail, int type, TP table, C
     if (mode == 0) {
       const uint32_t ns = DefaultSymbols(type);
       for (uint32_t s = 0; s < ns; s++) counts[s] = static_cast<int16_t>(DefaultCount(type, s));
+      if (!FINISH) {
+        if (nsym_out) *nsym_out = ns;
+        return BuildFseSpread(counts, ns, DefaultLog(type), table, next) ? DefaultLog(type) : ~0u;
+      }
       return BuildFseTable(counts, ns, DefaultLog(type), type, table, next) ? DefaultLog(type) : ~0u;
     }
     if (mode == 1) {
@@ -330,6 +349,10 @@ MI_ZHD uint32_t BuildSequenceTable(BP seq, uint32_t avail, int type, TP table, C
       uint32_t al, ns;
       const uint32_t n = at < avail ? ReadNCount(seq + at, avail - at, type, counts, &al, &ns) : 0;
       if (!n) return ~0u;
+      if (!FINISH) {
+        if (nsym_out) *nsym_out = ns;
+        return BuildFseSpread(counts, ns, al, table, next) ? al : ~0u;
+      }
       return BuildFseTable(counts, ns, al, type, table, next) ? al : ~0u;
     }
     return ~0u;   // repeat of a repeat: the host walk resolves chains, so this is a malformed frame
@@ -360,8 +383,10 @@ MI_ZHD uint32_t SequenceBitstreamOffset(BP seq, uint32_t avail, CP counts) {
 // Huffman tree description -> decoding table of 1 << max_bits cells {symbol | nbits << 8}.  Returns the bytes of the
 // description (0 = malformed).  weights: 256 bytes of scratch; cells / counts / next: scratch for the weights' own FSE table
 // (64 cells, 16 counts).
-template <typename BP, typename HP, typename WP, typename TP, typename CP, typename NP>
-MI_ZHD uint32_t ReadHuffmanTable(BP src, uint32_t avail, HP table, uint32_t* max_bits_out, WP weights, TP cells, CP counts, NP next) {
+// Two steps, like the FSE tables: the weights (serial: direct nibbles, or an FSE stream of two alternating states) and the
+// table fill, which the device runs with the whole wave (kernels_zstd.inl).
+template <typename BP, typename WP, typename TP, typename CP, typename NP>
+MI_ZHD uint32_t ReadHuffmanWeights(BP src, uint32_t avail, uint32_t* n_out, uint32_t* max_bits_out, WP weights, TP cells, CP counts, NP next) {
   if (avail < 1) return 0;
   const uint32_t hb = src[0];
   uint32_t n = 0, used;
@@ -412,7 +437,14 @@ MI_ZHD uint32_t ReadHuffmanTable(BP src, uint32_t avail, HP table, uint32_t* max
   const uint32_t rest = (1u << max_bits) - sum;
   if (rest & (rest - 1)) return 0;   // not a power of two
   weights[n++] = static_cast<uint8_t>(HighBit(rest) + 1);
-  // cells in the order of ascending weight (= descending code length), symbols of one weight in symbol order
+  *n_out = n;
+  *max_bits_out = max_bits;
+  return used;
+}
+// cells {symbol | nbits << 8} in the order of ascending weight (= descending code length), symbols of one weight in symbol
+// order; a symbol of weight w owns 2^(w-1) consecutive cells
+template <typename HP, typename WP>
+MI_ZHD bool FillHuffmanTable(WP weights, uint32_t n, uint32_t max_bits, HP table) {
   uint32_t at = 0;
   for (uint32_t w = 1; w <= max_bits; w++) {
     const uint32_t len = 1u << (w - 1);
@@ -423,7 +455,13 @@ MI_ZHD uint32_t ReadHuffmanTable(BP src, uint32_t avail, HP table, uint32_t* max
       at += len;
     }
   }
-  if (at != (1u << max_bits)) return 0;
+  return at == (1u << max_bits);
+}
+template <typename BP, typename HP, typename WP, typename TP, typename CP, typename NP>
+MI_ZHD uint32_t ReadHuffmanTable(BP src, uint32_t avail, HP table, uint32_t* max_bits_out, WP weights, TP cells, CP counts, NP next) {
+  uint32_t n = 0, max_bits = 0;
+  const uint32_t used = ReadHuffmanWeights(src, avail, &n, &max_bits, weights, cells, counts, next);
+  if (!used || !FillHuffmanTable(weights, n, max_bits, table)) return 0;
   *max_bits_out = max_bits;
   return used;
 }
