@@ -506,10 +506,10 @@ def main():
                             leg[tag] = {"seconds": best, "rows_per_s": info["n_rows"] / best, "h2d_bytes": st["h2d_bytes"],
                                         "batches_decompressed_in_hbm": st["lz4_batches_on_device"] + st["zstd_batches_on_device"]}
                         os.remove(cpath)
-                        # the library asks for 20 hardware queues when it is loaded before the process's first HIP call and nobody
+                        # the library asks for 24 hardware queues when it is loaded before the process's first HIP call and nobody
                         # has set GPU_MAX_HW_QUEUES (c_api.cpp): this process runs that way.  The HIP runtime's own default (4),
                         # for contrast, in a process of its own
-                        leg["GPU_MAX_HW_QUEUES"] = os.environ.get("GPU_MAX_HW_QUEUES", "unset: the library's 20")
+                        leg["GPU_MAX_HW_QUEUES"] = os.environ.get("GPU_MAX_HW_QUEUES", "unset: the library's 24")
                         if codec == "zstd":
                             env = dict(os.environ, GPU_MAX_HW_QUEUES="4")
                             run = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lz4_bench.py"), "--codec", codec, "--sf", str(args.sf),

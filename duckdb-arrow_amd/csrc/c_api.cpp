@@ -209,11 +209,12 @@ int mi_reader_index(mi_reader* r, const mi_batch_index_entry** entries, int32_t*
 // otherwise) and reads the variable ONCE, when it initialises at the process's first HIP call.  The compressed-body scans (K8)
 // are sets of latency-bound kernels that want the record batches of many pipeline slots side by side, each slot on a stream of
 // its own: on 4 queues their kernels queue up behind one another (ZSTD, SF10: 2.6 s against 0.9 s on 20 queues).  So when the
-// library is loaded and nobody has chosen a value, it asks for 20 -- effective when the library is loaded before the process
-// touches HIP (a DuckDB process loading the extension; bench.py and the tools import the package first), a no-op otherwise;
-// an explicit GPU_MAX_HW_QUEUES in the environment always wins.
+// library is loaded and nobody has chosen a value, it asks for 24 -- 16 slots + the context's three streams, and a few for
+// whatever else in the process makes streams (with torch beside it the scan lost a fifth on 20) -- effective when the library
+// is loaded before the process touches HIP (a DuckDB process loading the extension; bench.py and the tools import the
+// package first), a no-op otherwise; an explicit GPU_MAX_HW_QUEUES in the environment always wins.
 namespace {
-__attribute__((constructor)) void MiRuntimeDefaults() { (void)setenv("GPU_MAX_HW_QUEUES", "20", /*overwrite*/ 0); }
+__attribute__((constructor)) void MiRuntimeDefaults() { (void)setenv("GPU_MAX_HW_QUEUES", "24", /*overwrite*/ 0); }
 }  // namespace
 
 int mi_device_count(void) {

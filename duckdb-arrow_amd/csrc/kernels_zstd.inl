@@ -80,7 +80,11 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a, uint32_t
   }
   if (tid == 0) s_fail = 0;
   const bool staged = (pos & 1u) != 0;   // uniform (the name is history: the positional path)
+#ifdef MI_ZSTD_PROBE_BUILD
   const bool probe = (pos & 0x100u) != 0 && bi % 41u == 3u;   // MI_ZSTD_PROBE: this block prints its phases (10 ns ticks)
+#else
+  constexpr bool probe = false;   // diagnostics builds only: -DMI_ZSTD_PROBE_BUILD
+#endif
   const uint64_t t_start = probe ? wall_clock64() : 0;
   __syncthreads();
   // --- tables ---------------------------------------------------------------------------------------------------------

@@ -47,6 +47,13 @@ mi_string_t MakeHostString(const std::string& s) {
   return r;
 }
 
+// ZSTD bodies in HBM pay only with many record batches side by side, and those need hardware queues of their own: the HIP
+// runtime reads GPU_MAX_HW_QUEUES once, at its first call (default 4; the library asks for 24 when it is loaded, c_api.cpp).
+bool ManyHardwareQueues() {
+  const char* v = std::getenv("GPU_MAX_HW_QUEUES");
+  return v != nullptr && std::atoi(v) >= 12;
+}
+bool DeferZstd(const mi_scan_options& o) { return o.host_decompress < 0 || (o.host_decompress == 0 && o.device_resident != 0 && ManyHardwareQueues()); }
 int PipelineDepth(const mi_scan_options& o) { return std::max(2, std::min(16, o.pipeline_depth > 0 ? o.pipeline_depth : 3)); }
 }  // namespace
 
@@ -58,7 +65,7 @@ ArrowScan::ArrowScan(Context* ctx_p, std::vector<std::string> paths, const mi_sc
     sources.push_back(std::move(s));
   }
   slots.resize(static_cast<size_t>(PipelineDepth(opts)));
-  staging.resize(slots.size() + 2 * kMaxProducers + 2);   // slots + queues + the bodies being read + a decompressed copy
+  staging.resize(16 + 2 * kMaxProducers + 2);   // the deepest pipeline's slots + queues + the bodies being read + a decompressed copy (buffers are allocated on first use)
 }
 
 ArrowScan::ArrowScan(Context* ctx_p, std::vector<ArrowIPCBuffer> buffers_p, const mi_scan_options& o)
@@ -66,7 +73,7 @@ ArrowScan::ArrowScan(Context* ctx_p, std::vector<ArrowIPCBuffer> buffers_p, cons
   Source s;
   sources.push_back(std::move(s));
   slots.resize(static_cast<size_t>(PipelineDepth(opts)));
-  staging.resize(slots.size() + 2 * kMaxProducers + 2);   // slots + queues + the bodies being read + a decompressed copy
+  staging.resize(16 + 2 * kMaxProducers + 2);   // the deepest pipeline's slots + queues + the bodies being read + a decompressed copy (buffers are allocated on first use)
 }
 
 namespace {
@@ -76,9 +83,10 @@ inline int64_t TraceNow() { return std::chrono::duration_cast<std::chrono::nanos
 ArrowScan::~ArrowScan() {
   StopProducer();
   if (trace)
-    std::fprintf(stderr, "mi scan trace: %lld batches; pipeline thread: enqueue %.3f s, waiting for input %.3f s, waiting for the GPU %.3f s, polling %.3f s; "
+    std::fprintf(stderr, "mi scan trace: %lld batches, %.2f in flight after a submit, %.2f ms from a submit to its batch being handed out; pipeline thread: enqueue %.3f s (K8: tables and copies %.3f s, launches %.3f s), waiting for input %.3f s, waiting for the GPU %.3f s, polling %.3f s; "
                          "producers (%d, summed): reading %.3f s, queue full %.3f s, no staging buffer %.3f s\n",
-                 static_cast<long long>(stats.record_batches), tr_enqueue_ns * 1e-9, tr_fetch_wait_ns * 1e-9, tr_event_wait_ns * 1e-9, tr_poll_ns * 1e-9, n_producers,
+                 static_cast<long long>(stats.record_batches), stats.record_batches ? double(tr_inflight_sum) / stats.record_batches : 0.0,
+                 stats.record_batches ? tr_latency_ns * 1e-6 / stats.record_batches : 0.0, tr_enqueue_ns * 1e-9, tr_k8_prep_ns * 1e-9, tr_k8_launch_ns * 1e-9, tr_fetch_wait_ns * 1e-9, tr_event_wait_ns * 1e-9, tr_poll_ns * 1e-9, n_producers,
                  tr_read_ns.load() * 1e-9, tr_push_wait_ns.load() * 1e-9, tr_lease_wait_ns.load() * 1e-9);
   try {
     ctx->Bind();
@@ -112,6 +120,8 @@ ArrowScan::~ArrowScan() {
   }
   for (void* p : d_in_lists)
     if (p) (void)hipFree(p);
+  for (void* p : retired_device) (void)hipFree(p);
+  for (void* p : retired_host) (void)hipHostFree(p);
   dicts.clear();
   fetched.clear();
   extra_readers.clear();
@@ -143,9 +153,9 @@ void ArrowScan::OpenSource(size_t i) {
   // bodies are decompressed by the reader's host threads: on this platform D2H copies run as copy kernels, which then
   // queue up with the K8 kernels instead of overlapping them (SF10: 0.85 s against 0.68 s, tools/lz4_bench.py)
   s.reader->SetDeferLz4(opts.host_decompress < 0 || (opts.host_decompress == 0 && opts.device_resident != 0));
-  // ZSTD in HBM only on request: its entropy stage is one serial chain per 128 KiB block, so it pays when many record batches
-  // run side by side -- with the HIP runtime's default of 4 hardware queues the reader's host threads are faster
-  s.reader->SetDeferZstd(opts.host_decompress < 0);
+  // ZSTD likewise, when the process has hardware queues for many record batches side by side (its entropy stage is one serial
+  // chain per 128 KiB block: with the HIP runtime's default of 4 queues the reader's host threads are faster)
+  s.reader->SetDeferZstd(DeferZstd(opts));
   s.reader->GetBaseSchema();
   s.opened = true;
 }
@@ -371,24 +381,23 @@ void ArrowScan::EnsurePipelineDepth(int depth) {
   std::vector<Slot> bigger(static_cast<size_t>(depth));
   for (size_t i = 0; i < slots.size(); i++) bigger[i] = std::move(slots[i]);
   slots = std::move(bigger);
-  staging.resize(slots.size() + 2 * kMaxProducers + 2);   // slots + queues + the bodies being read + a decompressed copy
+  staging.resize(16 + 2 * kMaxProducers + 2);   // the deepest pipeline's slots + queues + the bodies being read + a decompressed copy (buffers are allocated on first use)
   if (initialized)
     for (auto& s : slots) InitSlot(s);
 }
 
 void ArrowScan::EnsureSlotBuffers(Slot& s, size_t in_bytes, size_t out_bytes) {
   ctx->Bind();
-  auto grow = [](size_t need, size_t cap) { return std::max(need, cap + cap / 2); };
   if (in_bytes > s.d_in_cap) {
-    if (s.d_in) MI_HIP_CHECK(hipFree(s.d_in));
+    if (s.d_in) RetireDevice(s.d_in);
     s.d_in = nullptr;
-    s.d_in_cap = RoundUp(grow(in_bytes, s.d_in_cap), 1 << 16);
+    s.d_in_cap = RoundUp(GrowCap(in_bytes, s.d_in_cap), 1 << 16);
     MI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s.d_in), s.d_in_cap));
   }
   if (out_bytes > s.d_out_cap) {
-    if (s.d_out) MI_HIP_CHECK(hipFree(s.d_out));
+    if (s.d_out) RetireDevice(s.d_out);
     s.d_out = nullptr;
-    s.d_out_cap = RoundUp(grow(out_bytes, s.d_out_cap), 1 << 16);
+    s.d_out_cap = RoundUp(GrowCap(out_bytes, s.d_out_cap), 1 << 16);
     MI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s.d_out), s.d_out_cap));
   }
 }
@@ -396,9 +405,9 @@ void ArrowScan::EnsureSlotBuffers(Slot& s, size_t in_bytes, size_t out_bytes) {
 void ArrowScan::EnsureHostOut(Slot& s, size_t bytes) {
   if (opts.device_resident || bytes <= s.h_out_cap) return;
   ctx->Bind();
-  if (s.h_out) MI_HIP_CHECK(hipHostFree(s.h_out));
+  if (s.h_out) RetireHost(s.h_out);
   s.h_out = nullptr;
-  s.h_out_cap = RoundUp(std::max(bytes, s.h_out_cap + s.h_out_cap / 2), 1 << 16);
+  s.h_out_cap = RoundUp(GrowCap(bytes, s.h_out_cap), 1 << 16);
   MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.h_out), s.h_out_cap, hipHostMallocDefault));
 }
 
@@ -559,8 +568,8 @@ void ArrowScan::UploadAux(Slot& s, const std::vector<uint64_t>& aux) {
   const size_t aux_bytes = aux.size() * 8;
   if (!aux_bytes) return;
   if (aux_bytes > s.h_aux_cap) {
-    if (s.h_aux) MI_HIP_CHECK(hipHostFree(s.h_aux));
-    if (s.d_aux) MI_HIP_CHECK(hipFree(s.d_aux));
+    if (s.h_aux) RetireHost(s.h_aux);
+    if (s.d_aux) RetireDevice(s.d_aux);
     s.h_aux_cap = s.d_aux_cap = RoundUp(aux_bytes * 2, 4096);
     MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.h_aux), s.h_aux_cap, hipHostMallocDefault));
     MI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s.d_aux), s.d_aux_cap));
@@ -595,9 +604,9 @@ void ArrowScan::EnqueueBatch(Slot& s) {
   const bool mirror = b.deferred && !opts.device_resident;
   po.zero_copy_direct = zero_copy && !agg.on && !s.compact && !mirror;
   if (mirror && static_cast<size_t>(b.body_size) + 64 > s.h_mirror_cap) {
-    if (s.h_mirror) MI_HIP_CHECK(hipHostFree(s.h_mirror));
+    if (s.h_mirror) RetireHost(s.h_mirror);
     s.h_mirror = nullptr;
-    s.h_mirror_cap = RoundUp(std::max(static_cast<size_t>(b.body_size) + 64, s.h_mirror_cap + s.h_mirror_cap / 2), 1 << 16);
+    s.h_mirror_cap = RoundUp(GrowCap(static_cast<size_t>(b.body_size) + 64, s.h_mirror_cap), 1 << 16);
     MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.h_mirror), s.h_mirror_cap, hipHostMallocDefault));
   }
   po.unset_all_valid = opts.unset_all_valid != 0;
@@ -680,7 +689,7 @@ void ArrowScan::EnqueueBatch(Slot& s) {
   EnsureSlotBuffers(s, static_cast<size_t>(b.body_size) + 64, s.stage_a_bytes + stage_b_worst + 64);
   EnsureHostOut(s, s.d2h_bytes + 64);
   if (static_cast<size_t>(n_windows + 1) * 4 > s.h_counts_cap) {
-    if (s.h_counts) MI_HIP_CHECK(hipHostFree(s.h_counts));
+    if (s.h_counts) RetireHost(s.h_counts);
     s.h_counts_cap = RoundUp(static_cast<size_t>(n_windows + 1) * 8, 4096);
     MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.h_counts), s.h_counts_cap, hipHostMallocDefault));
   }
@@ -932,6 +941,7 @@ void ArrowScan::EnqueueBatch(Slot& s) {
 // cross PCIe, the frames' blocks (tables built by the host reader from the block headers) are expanded into s.d_in at the
 // decompressed layout every span of the batch already refers to.
 void ArrowScan::EnqueueLz4(Slot& s) {
+  const int64_t t_k8 = trace ? TraceNow() : 0;
   const DecodedBatch& b = s.batch;
   const DeferredLz4Body& d = *b.deferred;
   if (!s.lz4_stream) {
@@ -981,19 +991,19 @@ void ArrowScan::EnqueueLz4(Slot& s) {
   const size_t o_lane_out = take(nb * 256 * 4), o_lane_n = take(nb * 256 * 4), o_rep = take(is_zstd ? nb * 256 * 16 : 0);
   const size_t o_link = take(out_size * 4 + 16), o_skel = take(out_size * 4 + 16);
   if (at > s.d_lz4_cap) {
-    if (s.d_lz4) MI_HIP_CHECK(hipFree(s.d_lz4));
+    if (s.d_lz4) RetireDevice(s.d_lz4);
     s.d_lz4 = nullptr;
-    s.d_lz4_cap = RoundUp(std::max(at, s.d_lz4_cap + s.d_lz4_cap / 2), 1 << 20);
+    s.d_lz4_cap = RoundUp(GrowCap(at, s.d_lz4_cap), 1 << 20);
     MI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s.d_lz4), s.d_lz4_cap));
   }
   if (comp_need > s.d_comp_cap) {
-    if (s.d_comp) MI_HIP_CHECK(hipFree(s.d_comp));
+    if (s.d_comp) RetireDevice(s.d_comp);
     s.d_comp = nullptr;
-    s.d_comp_cap = RoundUp(std::max(comp_need, s.d_comp_cap + s.d_comp_cap / 2), 1 << 16);
+    s.d_comp_cap = RoundUp(GrowCap(comp_need, s.d_comp_cap), 1 << 16);
     MI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s.d_comp), s.d_comp_cap));
   }
   if (tables_bytes > s.h_lz4_cap) {
-    if (s.h_lz4) MI_HIP_CHECK(hipHostFree(s.h_lz4));
+    if (s.h_lz4) RetireHost(s.h_lz4);
     s.h_lz4 = nullptr;
     s.h_lz4_cap = RoundUp(std::max(tables_bytes, s.h_lz4_cap * 2), 1 << 16);
     MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.h_lz4), s.h_lz4_cap, hipHostMallocDefault));
@@ -1101,7 +1111,12 @@ void ArrowScan::EnqueueLz4(Slot& s) {
   a.zblocks = is_zstd ? s.d_lz4 + o_zblocks : nullptr;
   a.literals = s.d_comp;
   a.rep_state = is_zstd ? reinterpret_cast<uint32_t*>(s.d_lz4 + o_rep) : nullptr;
+  const int64_t t_launch = trace ? TraceNow() : 0;
   MI_HIP_CHECK(device::LaunchLz4Decompress(a, ctx->num_cus, q));
+  if (trace) {
+    tr_k8_prep_ns += t_launch - t_k8;
+    tr_k8_launch_ns += TraceNow() - t_launch;
+  }
   MI_HIP_CHECK(hipMemcpyAsync(&s.h_status[2], a.status, sizeof(uint32_t), hipMemcpyDeviceToHost, q));
   MI_HIP_CHECK(hipMemcpyAsync(&s.h_status[4], a.round_left + 37, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, q));
   s.lz4_counted = false;
@@ -1303,9 +1318,9 @@ std::shared_ptr<void> ArrowScan::LeaseStaging(size_t bytes, uint8_t** ptr) {
   }
   if (bytes + 64 > st->cap) {
     ctx->Bind();
-    if (st->p) MI_HIP_CHECK(hipHostFree(st->p));
+    if (st->p) RetireHost(st->p);
     st->p = nullptr;
-    st->cap = RoundUp(std::max(bytes + 64, st->cap + st->cap / 2), 1 << 16);
+    st->cap = RoundUp(GrowCap(bytes + 64, st->cap), 1 << 16);
     MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&st->p), st->cap, hipHostMallocDefault));
   }
   *ptr = st->p;
@@ -1359,7 +1374,7 @@ void ArrowScan::ProducerLoop(int p) {
           }
           mine[si] = std::make_unique<IPCFileStreamReader>(sources[si].path);
           mine[si]->SetDeferLz4(opts.host_decompress < 0 || (opts.host_decompress == 0 && opts.device_resident != 0));
-          mine[si]->SetDeferZstd(opts.host_decompress < 0);
+          mine[si]->SetDeferZstd(DeferZstd(opts));
           mine[si]->GetBaseSchema();
           if (!wanted.empty()) mine[si]->SetColumnProjection(wanted);
         }
@@ -1473,6 +1488,20 @@ bool ArrowScan::SubmitNextBatch(bool may_block) {
       continue;
     }
     next_fetch++;
+    if (f.batch.deferred && opts.pipeline_depth == 0) {
+      // compressed bodies that are expanded in HBM spend 0.5 (LZ4) to 5 ms (ZSTD) in latency-bound kernels that leave the chip
+      // nearly idle: a caller who left the depth to the scan gets as many record batches side by side as that takes
+      const size_t wanted = f.batch.deferred->codec == 1 ? 16 : 8;
+      if (slots.size() < wanted) {
+        const size_t had = slots.size();
+        std::vector<Slot> bigger(wanted);
+        for (size_t i = 0; i < had; i++) bigger[i] = std::move(slots[i]);   // (only this thread touches the slots; the rest of the scan names them by index)
+        slots = std::move(bigger);
+        if (initialized)
+          for (size_t i = had; i < wanted; i++) InitSlot(slots[i]);
+        slot = FreeSlot();
+      }
+    }
     Slot& s = *slot;
     s.batch = std::move(f.batch);
     s.source = f.source;
@@ -1481,7 +1510,11 @@ bool ArrowScan::SubmitNextBatch(bool may_block) {
     try {
       const int64_t t0 = trace ? TraceNow() : 0;
       EnqueueBatch(s);
-      if (trace) tr_enqueue_ns += TraceNow() - t0;
+      if (trace) {
+        s.tr_enqueued_ns = TraceNow();
+        tr_enqueue_ns += s.tr_enqueued_ns - t0;
+        tr_inflight_sum += static_cast<int64_t>(inflight.size()) + 1;
+      }
     } catch (...) {
       s.busy = false;
       s.batch = DecodedBatch();
@@ -1531,6 +1564,7 @@ bool ArrowScan::AcquireBatch(BatchRef* out) {
   const int si = inflight.front();
   Slot& s = slots[static_cast<size_t>(si)];
   inflight.pop_front();
+  if (trace) tr_latency_ns += TraceNow() - s.tr_enqueued_ns;
   try {
     if (s.batch.deferred && !s.lz4_counted) {
       s.lz4_counted = true;

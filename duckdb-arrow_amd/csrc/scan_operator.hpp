@@ -183,6 +183,7 @@ class ArrowScan : public ScanBase {
     ~DictState();
   };
   struct Slot {
+    int64_t tr_enqueued_ns = 0;       // MI_SCAN_TRACE: when the batch was submitted
     // one record batch in flight
     uint8_t* d_in = nullptr;   size_t d_in_cap = 0;    // body in HBM
     uint8_t* d_out = nullptr;  size_t d_out_cap = 0;   // decoded vectors in HBM
@@ -315,6 +316,14 @@ class ArrowScan : public ScanBase {
   FilterCnf filter;
   //! filter column k -> output column (>= 0) or ~index into filter_only_columns (< 0)
   std::vector<int32_t> filter_columns;
+  // Buffers a slot has outgrown.  hipFree / hipHostFree wait for the device to go idle -- with the other slots' record batches
+  // in flight that is a pipeline stall of milliseconds -- so they are kept until the scan closes (growth is geometric: at
+  // most twice the final sizes in all).
+  std::vector<void*> retired_device, retired_host;
+  std::mutex retire_mu;   // the pipeline thread and the producers (staging buffers) both retire
+  void RetireDevice(void* p) { std::lock_guard<std::mutex> lk(retire_mu); retired_device.push_back(p); }
+  void RetireHost(void* p) { std::lock_guard<std::mutex> lk(retire_mu); retired_host.push_back(p); }
+  static size_t GrowCap(size_t need, size_t cap) { return std::max(need + need / 4, cap + cap / 2); }   // record batches of a file differ by a few percent
   std::vector<void*> d_in_lists;         // per leaf (clause order): its IN-list in HBM, or NULL
   bool compact = false;
   bool keep_on_device = false;
@@ -322,7 +331,7 @@ class ArrowScan : public ScanBase {
   // MI_SCAN_TRACE: where the host threads' time went (seconds), printed when the scan closes (diagnostics only)
   bool trace = false;
   std::atomic<int64_t> tr_read_ns{0}, tr_push_wait_ns{0}, tr_lease_wait_ns{0};
-  int64_t tr_enqueue_ns = 0, tr_fetch_wait_ns = 0, tr_event_wait_ns = 0, tr_poll_ns = 0;
+  int64_t tr_latency_ns = 0, tr_inflight_sum = 0, tr_k8_prep_ns = 0, tr_k8_launch_ns = 0, tr_enqueue_ns = 0, tr_fetch_wait_ns = 0, tr_event_wait_ns = 0, tr_poll_ns = 0;
 };
 
 //! read_arrow over several GPUs of one process: one ArrowScan per context, record batch k of the file list

@@ -463,16 +463,18 @@ typedef struct mi_scan_options {
                                  * (flat vectors of mi_data_chunk.size = sel_count rows, sel = NULL; rows that fail the
                                  * predicate are never decoded or copied back); 0 = full vectors + a selection vector.
                                  * Needs flat projected columns (no nested types, no string views). */
-  int32_t pipeline_depth;       /* record batches in flight on the GPU (pinned + HBM slots); 0 = 3 */
-  int32_t host_decompress;      /* compressed bodies: 0 = auto: LZ4_FRAME bodies of a device-resident consumer are shipped over
-                                 * PCIe as they are and decompressed in HBM (K8), everything else is decompressed by the
-                                 * reader's host threads; 1 = host threads always; -1 = K8 for LZ4_FRAME and ZSTD bodies,
-                                 * also for host consumers (string payloads are copied back beside the vectors).  ZSTD in HBM
-                                 * is one serial chain per 128 KiB block: it needs many record batches side by side
-                                 * (pipeline_depth 16 and GPU_MAX_HW_QUEUES >= 16 in the process environment) to beat the
-                                 * host threads, hence not the default.  Dictionary batches, big-endian streams, record
-                                 * batches with list columns and ZSTD frames with a dictionary id or a content checksum always
-                                 * take the host threads. */
+  int32_t pipeline_depth;       /* record batches in flight on the GPU (pinned + HBM slots), at most 16; 0 = the scan decides: 3, and
+                                 * 8 / 16 once it meets LZ4_FRAME / ZSTD bodies that it expands in HBM (latency-bound kernels
+                                 * that leave the chip idle unless many record batches run side by side) */
+  int32_t host_decompress;      /* compressed bodies: 0 = auto: the bodies of a device-resident consumer are shipped over PCIe as
+                                 * they are and decompressed in HBM (K8) -- LZ4_FRAME always, ZSTD when the process has
+                                 * hardware queues for 16 record batches side by side (GPU_MAX_HW_QUEUES >= 12 in the
+                                 * environment; the HIP runtime reads it once, at its first call, default 4: the library sets
+                                 * it to 24 when it is loaded and nobody has set it) -- everything else is decompressed by the
+                                 * reader's host threads; 1 = host threads always; -1 = K8 for LZ4_FRAME and ZSTD bodies, also
+                                 * for host consumers (string payloads are copied back beside the vectors).  Dictionary
+                                 * batches, big-endian streams, record batches with list columns and ZSTD frames with a
+                                 * dictionary id or a content checksum always take the host threads. */
   int32_t _reserved[3];
 } mi_scan_options;
 
