@@ -4,7 +4,7 @@
 # never combined with hip/hsa/sys tracing).  Outputs land under gpurun_out/<tag>_<workload>_*; tools/profile_summary.py
 # turns them into profiles/<tag>/<workload>/.  Workloads: decode (bench.py, the headline), encode (tools/encode_bench.py,
 # BASELINE config 4), commits (tools/commits_bench.py, config 5), filter (tools/filter_bench.py, K6 + gather), lz4
-# (tools/lz4_bench.py, K8 through the scan operator), zstd (the same with --codec zstd: 16 slots, GPU_MAX_HW_QUEUES=20).
+# (tools/lz4_bench.py, K8 through the scan operator), zstd (the same with --codec zstd, 16 slots).
 set -eo pipefail
 tag=${1:-r03}
 shift || true
@@ -14,13 +14,11 @@ export TMPDIR=/tmp
 for w in $workloads; do
   case $w in
     decode)  full="bench.py --no-operator-path"; short="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-operator-path --no-encode-leg" ;;
-    encode)  full="tools/encode_bench.py --sf 10 --per-column"; short="tools/encode_bench.py --sf 10 --rounds 3" ;;
+    encode)  full="tools/encode_bench.py --sf 10 --per-column --native-heap"; short="tools/encode_bench.py --sf 10 --rounds 3" ;;
     commits) full="tools/commits_bench.py"; short="tools/commits_bench.py" ;;
     filter)  full="tools/filter_bench.py"; short="tools/filter_bench.py" ;;
-    lz4)     full="tools/lz4_bench.py --sf 10"; short="tools/lz4_bench.py --sf 2" ;;
-    zstd)    full="tools/lz4_bench.py --codec zstd --depth 16 --sf 10"; short="tools/lz4_bench.py --codec zstd --depth 16 --sf 2 --legs lz4_in_hbm" ;;   # the HIP runtime's default queues
-    zstd20)  export GPU_MAX_HW_QUEUES=20   # read once by the HIP runtime; exported, not passed through env(1): rocprofv3 needs the program itself behind --
-             full="tools/lz4_bench.py --codec zstd --depth 16 --sf 10"; short="tools/lz4_bench.py --codec zstd --depth 16 --sf 2 --legs lz4_in_hbm" ;;
+    lz4)     full="tools/lz4_bench.py --sf 10 --legs plain,lz4_host_threads,lz4_in_hbm"; short="tools/lz4_bench.py --sf 2 --legs lz4_in_hbm" ;;
+    zstd)    full="tools/lz4_bench.py --codec zstd --depth 16 --sf 10 --legs plain,lz4_host_threads,lz4_in_hbm"; short="tools/lz4_bench.py --codec zstd --depth 16 --sf 2 --legs lz4_in_hbm" ;;
     *) echo "unknown workload $w"; exit 2 ;;
   esac
   p=gpurun_out/${tag}_${w}
