@@ -54,7 +54,7 @@ bool ManyHardwareQueues() {
   return v != nullptr && std::atoi(v) >= 12;
 }
 bool DeferZstd(const mi_scan_options& o) { return o.host_decompress < 0 || (o.host_decompress == 0 && o.device_resident != 0 && ManyHardwareQueues()); }
-int PipelineDepth(const mi_scan_options& o) { return std::max(2, std::min(16, o.pipeline_depth > 0 ? o.pipeline_depth : 3)); }
+int PipelineDepth(const mi_scan_options& o) { return std::max(2, std::min(kMaxDepth, o.pipeline_depth > 0 ? o.pipeline_depth : 3)); }
 }  // namespace
 
 ArrowScan::ArrowScan(Context* ctx_p, std::vector<std::string> paths, const mi_scan_options& o) : ctx(ctx_p), opts(o) {
@@ -65,7 +65,7 @@ ArrowScan::ArrowScan(Context* ctx_p, std::vector<std::string> paths, const mi_sc
     sources.push_back(std::move(s));
   }
   slots.resize(static_cast<size_t>(PipelineDepth(opts)));
-  staging.resize(16 + 2 * kMaxProducers + 2);   // the deepest pipeline's slots + queues + the bodies being read + a decompressed copy (buffers are allocated on first use)
+  staging.resize(kMaxDepth + 2 * kMaxProducers + 2);   // the deepest pipeline's slots + queues + the bodies being read + a decompressed copy (buffers are allocated on first use)
 }
 
 ArrowScan::ArrowScan(Context* ctx_p, std::vector<ArrowIPCBuffer> buffers_p, const mi_scan_options& o)
@@ -73,7 +73,7 @@ ArrowScan::ArrowScan(Context* ctx_p, std::vector<ArrowIPCBuffer> buffers_p, cons
   Source s;
   sources.push_back(std::move(s));
   slots.resize(static_cast<size_t>(PipelineDepth(opts)));
-  staging.resize(16 + 2 * kMaxProducers + 2);   // the deepest pipeline's slots + queues + the bodies being read + a decompressed copy (buffers are allocated on first use)
+  staging.resize(kMaxDepth + 2 * kMaxProducers + 2);   // the deepest pipeline's slots + queues + the bodies being read + a decompressed copy (buffers are allocated on first use)
 }
 
 namespace {
@@ -375,13 +375,13 @@ void ArrowScan::InitSlot(Slot& s) {
 // Takes effect only before the first batch has been requested: the read-ahead thread sizes its staging ring from the slot
 // count (a pump that asks later works with the slots there are: it waits for a release when all of them are held).
 void ArrowScan::EnsurePipelineDepth(int depth) {
-  depth = std::min(depth, 16);
+  depth = std::min(depth, kMaxDepth);
   if (static_cast<int>(slots.size()) >= depth) return;
   if (producer_started || !inflight.empty()) return;   // a scan that has started keeps the depth it has
   std::vector<Slot> bigger(static_cast<size_t>(depth));
   for (size_t i = 0; i < slots.size(); i++) bigger[i] = std::move(slots[i]);
   slots = std::move(bigger);
-  staging.resize(16 + 2 * kMaxProducers + 2);   // the deepest pipeline's slots + queues + the bodies being read + a decompressed copy (buffers are allocated on first use)
+  staging.resize(kMaxDepth + 2 * kMaxProducers + 2);   // the deepest pipeline's slots + queues + the bodies being read + a decompressed copy (buffers are allocated on first use)
   if (initialized)
     for (auto& s : slots) InitSlot(s);
 }
@@ -953,7 +953,7 @@ void ArrowScan::EnqueueLz4(Slot& s) {
     // the deployment to at least slots + 3 -- every slot gets a stream of its own: 0.24 s instead of 0.29 s at 8 slots
     // and 20 queues (profiles/r02/lz4/streams_ab.txt); on the default 4 queues the same choice was the 0.46 s above.
     int kLz4Streams = d.codec == 1 ? 16 : 3;
-    if (d.codec != 1) {
+    {
       const char* hwq = std::getenv("GPU_MAX_HW_QUEUES");
       const int n_slots = static_cast<int>(slots.size());
       if (hwq != nullptr && std::atoi(hwq) >= n_slots + 3) kLz4Streams = n_slots;

@@ -106,6 +106,8 @@ class ScanBase {
   virtual void Stats(mi_scan_stats* out) = 0;   // adds to *out
 };
 
+constexpr int kMaxDepth = 16;   // pipeline slots of a scan at most (24 and 32 were measured with 40 hardware queues: slower for both codecs of K8)
+
 class ArrowScan : public ScanBase {
  public:
   ArrowScan(Context* ctx, std::vector<std::string> paths, const mi_scan_options& opts);
