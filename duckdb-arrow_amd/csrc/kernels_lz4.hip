@@ -40,6 +40,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "device_common.hpp"
 #include "kernels.hpp"

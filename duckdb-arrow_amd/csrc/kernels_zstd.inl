@@ -23,6 +23,13 @@ constexpr int kZstdSeqWindowWords = 256;         // the sequences' bitstream: 1 
 template <typename T>
 using ldsptr = T __attribute__((address_space(3)))*;
 
+// old, with the (wave-uniform) value written into lane LANE: v_writelane_b32
+template <int LANE>
+__device__ __forceinline__ int32_t write_lane(int32_t uniform_value, int32_t old) {
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(uniform_value), "n"(LANE));
+  return old;
+}
+
 // pos != 0 (the default): the streams are decoded with the POSITIONAL decoders of zstd_format.hpp -- a field of the bitstream
 // is an indexed read from a 0.5 - 1 KiB window of the stream in LDS that the decoding lane slides itself, not a turn of a
 // shifting bit buffer with its counters and refill tests -- and wave 1 shares the work on the sequences (see there).  pos == 0:
@@ -397,31 +404,52 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a, uint32_t
       const uint64_t t0 = probe ? wall_clock64() : 0;
       if (((q - kGroupBits) >> 5) < wlo) refill((q >> 5) + 1);   // uniform
       if (lane < 3) {
-        const uint32_t m1 = lane >= 1 ? ~0u : 0u, m2 = lane >= 2 ? ~0u : 0u, n1 = lane <= 1 ? ~0u : 0u, n0 = lane == 0 ? ~0u : 0u;
-#pragma clang loop unroll(disable)
-        for (uint32_t i = 0; i < cnt; i++) {
+        // One step of the three lanes.  Everything the lanes share is scalar: the six field positions are computed on the scalar
+        // unit and dealt to the lanes with v_writelane (a lane-dependent select costs the vector unit three instructions, and
+        // the vector unit -- one instruction of a 64-wide wave per four cycles, three lanes of it in use -- is what saturates
+        // when every CU holds eight blocks); LAST: the block's last sequence reads no state bits.
+        const uint32_t win_bias = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(win)) - 4u * static_cast<uint32_t>(wlo);   // byte address of word 0, were it in the window
+        auto word_pair = [&](int32_t at, uint32_t* lo_w, uint32_t* hi_w) {
+          const ldsptr<uint32_t> w = (ldsptr<uint32_t>)(static_cast<uintptr_t>(4u * static_cast<uint32_t>(at >> 5) + win_bias));
+          *lo_w = w[0];
+          *hi_w = w[1];
+        };
+        auto step = [&](uint32_t i, auto last_tag) -> bool {
+          constexpr bool LAST = decltype(last_tag)::value;
           const zstd::FseCell cell = tab[state];
-          // {state bits, extra bits} of the three lanes as scalars; the block's last sequence updates no state
-          uint32_t pack = static_cast<uint32_t>(cell >> 48);
-          if (g0 + i + 1 == z.nseq) pack &= 0xFF00u;
+          const uint32_t pack = static_cast<uint32_t>(cell >> 48);   // state bits | extra bits << 8
           const uint32_t k_of = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(pack), 0)),
                          k_ml = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(pack), 1)),
                          k_ll = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(pack), 2));
-          const uint32_t e_of = k_of >> 8, e_ml = k_ml >> 8, e_ll = k_ll >> 8, b_of = k_of & 0xFFu, b_ml = k_ml & 0xFFu, b_ll = k_ll & 0xFFu;
           // the fields below the head: offset extra, match-length extra, literal-length extra, then the bits of the next
           // literal-length, match-length and offset states
-          const int32_t q_extra = q - static_cast<int32_t>(e_of + e_ml + e_ll), q_next = q_extra - static_cast<int32_t>(b_ll + b_ml + b_of);
-          if (q_next < floor) {   // the stream ran out (uniform)
-            ok0 = false;
-            break;
+          const int32_t p_of_e = q - static_cast<int32_t>(k_of >> 8), p_ml_e = p_of_e - static_cast<int32_t>(k_ml >> 8),
+                        p_ll_e = p_ml_e - static_cast<int32_t>(k_ll >> 8);
+          const int32_t p_ll_b = LAST ? p_ll_e : p_ll_e - static_cast<int32_t>(k_ll & 0xFFu), p_ml_b = LAST ? p_ll_e : p_ll_b - static_cast<int32_t>(k_ml & 0xFFu),
+                        p_of_b = LAST ? p_ll_e : p_ml_b - static_cast<int32_t>(k_of & 0xFFu);
+          if (p_of_b < floor) return false;   // the stream ran out (uniform)
+          int32_t pe = p_ll_e;
+          pe = write_lane<0>(p_of_e, pe);
+          pe = write_lane<1>(p_ml_e, pe);
+          uint32_t e_lo, e_hi;
+          word_pair(pe, &e_lo, &e_hi);
+          uint32_t b_lo = 0, b_hi = 0;
+          int32_t pb = p_ll_b;
+          if (!LAST) {
+            pb = write_lane<0>(p_of_b, pb);
+            pb = write_lane<1>(p_ml_b, pb);
+            word_pair(pb, &b_lo, &b_hi);
           }
-          const int32_t pe = q - static_cast<int32_t>(e_of + (e_ml & m1) + (e_ll & m2));
-          const int32_t pb = q_extra - static_cast<int32_t>(b_ll + (b_ml & n1) + (b_of & n0));
-          const uint32_t value = zstd::CellBase(cell) + field(pe, pack >> 8);
-          state = zstd::CellNext(cell) + field(pb, pack & 0xFFu);
+          const uint32_t value = zstd::CellBase(cell) + __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(e_hi, e_lo, static_cast<uint32_t>(pe)), 0u, pack >> 8);
+          if (!LAST) state = zstd::CellNext(cell) + __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(b_hi, b_lo, static_cast<uint32_t>(pb)), 0u, pack & 0xFFu);
           s_trip[i][2u - lane] = value;
-          q = q_next;
-        }
+          q = p_of_b;
+          return true;
+        };
+        const uint32_t n_more = g0 + cnt == z.nseq ? cnt - 1 : cnt;   // sequences of this group that are followed by another one
+#pragma clang loop unroll(disable)
+        for (uint32_t i = 0; i < n_more && ok0; i++) ok0 = step(i, std::false_type());
+        if (ok0 && n_more < cnt) ok0 = step(n_more, std::true_type());
       }
       // (q and ok0 were computed from v_readlane results inside the three-lane region: make them wave-uniform again)
       q = __builtin_amdgcn_readfirstlane(q);
