@@ -208,7 +208,7 @@ int mi_reader_index(mi_reader* r, const mi_batch_index_entry** entries, int32_t*
 // The HIP runtime multiplexes every stream of a process onto GPU_MAX_HW_QUEUES hardware queues (4 unless the variable says
 // otherwise) and reads the variable ONCE, when it initialises at the process's first HIP call.  The compressed-body scans (K8)
 // are sets of latency-bound kernels that want the record batches of many pipeline slots side by side, each slot on a stream of
-// its own: on 4 queues their kernels queue up behind one another (ZSTD, SF10: 2.6 s against 0.9 s on 20 queues).  So when the
+// its own: on 4 queues their kernels queue up behind one another (ZSTD, SF10: 0.63 s against 0.34 s).  So when the
 // library is loaded and nobody has chosen a value, it asks for 24 -- 16 slots + the context's three streams, and a few for
 // whatever else in the process makes streams (with torch beside it the scan lost a fifth on 20) -- effective when the library
 // is loaded before the process touches HIP (a DuckDB process loading the extension; bench.py and the tools import the

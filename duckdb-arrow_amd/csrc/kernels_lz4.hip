@@ -911,9 +911,12 @@ hipError_t LaunchLz4Decompress(const Lz4Args& a, int num_cus, hipStream_t stream
   MI_DROP_STALE_ERROR();
   if (a.n_blocks == 0) return hipSuccess;
   if (a.zblocks) {
-    static const bool windowed = std::getenv("MI_ZSTD_WINDOWED") != nullptr;   // tests / A-B: the first formulation's readers
-    static const bool probe = std::getenv("MI_ZSTD_PROBE") != nullptr;          // diagnostics: a few blocks print where their time went
-    hipLaunchKernelGGL(zstd_entropy, dim3(a.n_blocks), dim3(kZstdThreads), 0, stream, a, (windowed ? 0u : 1u) | (probe ? 0x100u : 0u));
+#ifdef MI_ZSTD_PROBE_BUILD
+    static const bool probe = std::getenv("MI_ZSTD_PROBE") != nullptr;          // diagnostics build: a few blocks print where their time went
+#else
+    constexpr bool probe = false;
+#endif
+    hipLaunchKernelGGL(zstd_entropy, dim3(a.n_blocks), dim3(kZstdThreads), 0, stream, a, probe ? 0x100u : 0u);
     hipLaunchKernelGGL(zstd_layout, dim3(a.n_buffers), dim3(64), 0, stream, a);
   } else {
     // compressed blocks below 64 KiB (64 KiB is the default block size of every writer) are walked from an LDS copy

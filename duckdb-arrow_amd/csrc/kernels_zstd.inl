@@ -30,13 +30,13 @@ __device__ __forceinline__ int32_t write_lane(int32_t uniform_value, int32_t old
   return old;
 }
 
-// pos != 0 (the default): the streams are decoded with the POSITIONAL decoders of zstd_format.hpp -- a field of the bitstream
-// is an indexed read from a 0.5 - 1 KiB window of the stream in LDS that the decoding lane slides itself, not a turn of a
-// shifting bit buffer with its counters and refill tests -- and wave 1 shares the work on the sequences (see there).  pos == 0:
-// the BackBits readers of the first formulation, everything about a sequence on one lane (MI_ZSTD_WINDOWED: tests, A/B).
+// The streams are decoded POSITIONALLY: the head of a backward bitstream is a bit position, a field an indexed read from a
+// 0.5 - 1 KiB window of the stream in LDS -- not a turn of a shifting bit buffer with its counters and refill tests (the first
+// formulation: BackBits in zstd_format.hpp, still what the table descriptions are read with) -- and wave 1 shares the work on
+// the sequences (see there).  `flags`: bit 8 = diagnostics (probe builds only).
 // (Staging the whole block in LDS instead of windows was measured and dropped: 36 - 100 KiB per workgroup leave room for two
 // blocks per CU instead of eight, and the kernel is a set of serial chains -- what it needs is many blocks side by side.)
-__global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a, uint32_t pos) {
+__global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a, uint32_t flags) {
   __shared__ uint16_t s_huf[1u << zstd::kHufMaxBits];
   __shared__ zstd::FseCell s_ll[512], s_of[256], s_ml[512], s_wcells[64];   // 8 bytes a cell
   __shared__ uint8_t s_weights[256];
@@ -86,9 +86,8 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a, uint32_t
     return;
   }
   if (tid == 0) s_fail = 0;
-  const bool staged = (pos & 1u) != 0;   // uniform (the name is history: the positional path)
 #ifdef MI_ZSTD_PROBE_BUILD
-  const bool probe = (pos & 0x100u) != 0 && bi % 41u == 3u;   // MI_ZSTD_PROBE: this block prints its phases (10 ns ticks)
+  const bool probe = (flags & 0x100u) != 0 && bi % 41u == 3u;   // MI_ZSTD_PROBE: this block prints its phases (10 ns ticks)
 #else
   constexpr bool probe = false;   // diagnostics builds only: -DMI_ZSTD_PROBE_BUILD
 #endif
@@ -240,17 +239,11 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a, uint32_t
       uint32_t first, nbytes, out0, nsym;
       bool ok = zstd::LiteralStream(z, c, s_desc, lane, &first, &nbytes, &out0, &nsym);
       ok = ok && first + nbytes <= z.comp_size;
-      if (staged) {
+      {
         const uint32_t mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(c + first) & 3u);
         zstd::SlidingWords<gptr<const uint8_t>, ldsptr<uint32_t>, kZstdWindowWords> sw;
         sw.Init(c + first - mis, (ldsptr<uint32_t>)s_win[lane]);
         ok = ok && zstd::DecodeHuffmanStreamPos(sw, mis, nbytes, nsym, huf, s_huf_bits, arena + z.lit_pos + out0);
-      } else {
-        // the stream is read through a window in LDS that the lane refills itself: between refills the loop touches HBM only
-        // to store (a load would wait for the last store -- one counter for both -- at every refill of the bit buffer)
-        zstd::BackBits<gptr<const uint8_t>, zstd::WindowWords<gptr<const uint8_t>, ldsptr<uint32_t>, kZstdWindowWords>> br;
-        br.src.win = (ldsptr<uint32_t>)s_win[lane];
-        ok = ok && zstd::DecodeHuffmanStream(br, c + first, nbytes, nsym, huf, s_huf_bits, arena + z.lit_pos + out0);
       }
       if (!ok) lz4_fail(a.status);   // the block's size is still reported by wave 1; the batch is rejected through the status word
       if (probe)
@@ -259,8 +252,8 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a, uint32_t
     }
     return;
   }
-  if (staged) {
-    // ---- wave 1, positional path.  The three FSE states (offset, match length, literal length) sit on lanes 0, 1, 2: a lane
+  {
+    // ---- wave 1.  The three FSE states (offset, match length, literal length) sit on lanes 0, 1, 2: a lane
     // looks up ITS cell, the three exchange how many bits their fields take (v_readlane: the head position of the bitstream
     // and every field position are scalars), and each reads its two fields -- the extra bits of its value, the bits of its
     // next state -- from the window of the stream in LDS: one cell look-up and one pair of field reads per sequence as the
@@ -506,82 +499,6 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a, uint32_t
     }
     return;
   }
-  if (lane != 0) {
-    return;
-  }
-  // wave 1, lane 0: the sequences (blocks too large to stage: the windowed reader, everything on this lane)
-  uint32_t out_pos = 0, lit_used = 0, k = 0, j = 0, lane_base = 0, n_desc = 0;
-  uint32_t S[3] = {zstd::RepSlot(0), zstd::RepSlot(1), zstd::RepSlot(2)};   // the history, as a function of the slice's start
-  gptr<u32x4> rep_fn = GM<u32x4>(a.rep_state) + static_cast<size_t>(bi) * kParseLanes;
-  auto close_slice = [&]() {
-    u32x4 f;
-    f.x = S[0]; f.y = S[1]; f.z = S[2]; f.w = 0;
-    rep_fn[k] = f;
-    S[0] = zstd::RepSlot(0); S[1] = zstd::RepSlot(1); S[2] = zstd::RepSlot(2);
-  };
-  bool ok = !failed;
-  auto put = [&](uint32_t ll, uint32_t ml, uint32_t code) {
-    if (j == 0) {
-      lane_base = out_pos;
-      lane_out[k] = out_pos;
-    }
-    uint32_t off = 0;
-    if (ml) {
-      off = zstd::RepStep(code, S);
-      if (off == 0) ok = false;
-    }
-    u32x4 d;
-    d.x = out_pos - lane_base;
-    d.y = z.lit_pos + lit_used;
-    d.z = ll;
-    d.w = ml;
-    seq[k * per + j] = d;
-    seq_off[k * per + j] = off;
-    lit_used += ll;
-    out_pos += ll + ml;
-    n_desc++;
-    if (++j == per) {
-      lane_nseq[k] = per;
-      close_slice();
-      k++;
-      j = 0;
-    }
-  };
-  if (ok && z.nseq) {
-    auto emit = [&](uint32_t, uint32_t ll, uint32_t ml, uint32_t code) {
-      if (ll > z.lit_regen - lit_used || ll + ml > zstd::kBlockMax - out_pos) return false;
-      put(ll, ml, code);
-      return ok;
-    };
-    // like the literal streams: read through a window in LDS, so that the loop's only traffic to HBM is its stores
-    zstd::BackBits<gptr<const uint8_t>, zstd::WindowWords<gptr<const uint8_t>, ldsptr<uint32_t>, kZstdSeqWindowWords>> br;
-    br.src.win = (ldsptr<uint32_t>)s_seqwin;
-    ok = zstd::DecodeSequences(br, c + bits_at, bits_len, z.nseq, t_ll, s_al[0], t_of, s_al[1], t_ml, s_al[2], emit);
-  }
-  if (ok && lit_used < z.lit_regen) {
-    ok = z.lit_regen - lit_used <= zstd::kBlockMax - out_pos;
-    if (ok) put(z.lit_regen - lit_used, 0, 0);   // offset 0: not a match, zstd_layout's repeat offsets pass it by
-  }
-  if (!ok) {
-    lz4_fail(a.status);
-    out_pos = 0;
-    n_desc = 0;
-    k = 0;
-    j = 0;
-  }
-  if (j) {
-    lane_nseq[k] = j;
-    close_slice();
-    k++;
-  }
-  S[0] = zstd::RepSlot(0); S[1] = zstd::RepSlot(1); S[2] = zstd::RepSlot(2);
-  for (; k < kParseLanes; k++) {   // empty slices begin where the block ends and leave the history as it is
-    lane_out[k] = out_pos;
-    lane_nseq[k] = 0;
-    close_slice();
-  }
-  a.block_out_size[bi] = out_pos;
-  a.block_nseq[bi] = n_desc;
 }
 
 __global__ __launch_bounds__(64) void zstd_layout(Lz4Args a) {

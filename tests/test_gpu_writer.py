@@ -202,17 +202,19 @@ def test_encode_string_windows_and_huge_strings_match_oracle(con, torch, shape):
 
 
 @pytest.mark.parametrize("layout", ["arrow_like", "nulls_take_no_heap", "long_strings_only", "every_other_wave_shuffled",
-                                    "long_mean_90_arrow_like"])
+                                    "long_mean_90_arrow_like", "long_mean_90_shuffled"])
 def test_encode_string_heap_layouts_match_oracle(con, torch, layout):
     """K7d picks, per wave of 64 rows, between one coalesced copy of the heap bytes between the first and the last long
     string (when the long strings lie in the heap as they will lie in the data buffer) and the per-row path.  Layouts:
     an Arrow-like heap (every row's bytes in row order; the slots of inline strings hold garbage here, the inline bytes
     must win), NULL rows that own no heap bytes, a heap of long strings only (DuckDB's own), waves with shuffled
-    pointers next to contiguous ones, and sub-blocks whose contiguous run crosses several LDS windows."""
+    pointers next to contiguous ones, sub-blocks whose contiguous run crosses several LDS windows, and the same long strings
+    (up to 180 bytes: more than the four 16-byte pieces the per-row path keeps in flight, and rows that a window cuts
+    anywhere) with shuffled pointers."""
     rng = np.random.default_rng({"arrow_like": 21, "nulls_take_no_heap": 22, "long_strings_only": 23,
-                                 "every_other_wave_shuffled": 24, "long_mean_90_arrow_like": 25}[layout])
+                                 "every_other_wave_shuffled": 24, "long_mean_90_arrow_like": 25, "long_mean_90_shuffled": 26}[layout])
     n = 9000
-    lens = rng.integers(0, 181, n) if layout == "long_mean_90_arrow_like" else rng.integers(0, 61, n)
+    lens = rng.integers(0, 181, n) if layout.startswith("long_mean_90") else rng.integers(0, 61, n)
     ok = np.ones(n, bool) if layout in ("arrow_like", "long_mean_90_arrow_like") else rng.random(n) < 0.9
     if layout == "long_strings_only":
         lens[rng.random(n) < 0.5] = 20    # runs of long strings back to back: contiguous waves exist in this layout too
@@ -221,9 +223,9 @@ def test_encode_string_heap_layouts_match_oracle(con, torch, layout):
     heap_len = {"arrow_like": lambda i: lens[i], "long_mean_90_arrow_like": lambda i: lens[i],
                 "nulls_take_no_heap": lambda i: lens[i] if ok[i] else 0,
                 "long_strings_only": lambda i: lens[i] if lens[i] > 12 else 0,
-                "every_other_wave_shuffled": lambda i: lens[i]}[layout]
+                "every_other_wave_shuffled": lambda i: lens[i], "long_mean_90_shuffled": lambda i: lens[i]}[layout]
     order = np.arange(n)
-    if layout == "every_other_wave_shuffled":
+    if layout in ("every_other_wave_shuffled", "long_mean_90_shuffled"):
         for w in range(0, n // 64, 2):
             order[64 * w: 64 * w + 64] = rng.permutation(order[64 * w: 64 * w + 64])
     starts = np.zeros(n, np.int64)

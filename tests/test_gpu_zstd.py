@@ -142,33 +142,3 @@ def test_damaged_zstd_input_is_an_error_not_a_crash(con, tmp_path):
     got, _ = _device_scan(con, path, host_decompress="gpu")    # the context still works
     assert got == [canon_python(c) for c in con.read_arrow(path, host_decompress=True).fetch_columns()]
 
-
-def test_zstd_windowed_readers_for_blocks_too_large_to_stage(tmp_path):
-    """zstd_entropy decodes from an LDS copy of the block with the positional decoders (the default for every block that fits);
-    blocks too large to stage keep the windowed bit readers -- forced for every block here (MI_ZSTD_WINDOWED) in a fresh
-    process.  Same vectors as pyarrow's reading of the table."""
-    import subprocess, sys, textwrap
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = textwrap.dedent("""
-        import os, sys
-        sys.path.insert(0, %r)
-        sys.path.insert(0, os.path.join(%r, "tests"))
-        import numpy as np, pyarrow as pa, pyarrow.ipc as ipc
-        import duckdb_arrow_amd as da
-        from helpers import pyarrow_columns, canon_python
-        rng = np.random.default_rng(6)
-        n = 200000
-        t = pa.table({"k": pa.array(np.arange(n, dtype=np.int64) * 7), "s": pa.array(["text %%d %%s" %% (i %% 811, "w" * (i %% 29)) for i in range(n)]),
-                      "q": pa.array(rng.integers(0, 50, n).astype(np.int32)), "r": pa.array(rng.integers(0, 1 << 40, n, dtype=np.int64))})
-        p = %r
-        with ipc.new_stream(p, t.schema, options=ipc.IpcWriteOptions(compression=pa.Codec("zstd", compression_level=3))) as w:
-            w.write_table(t, max_chunksize=70000)
-        con = da.Connection(0)
-        rel = con.read_arrow(p, host_decompress="gpu")
-        got = rel.fetch_columns()
-        assert rel.stats()["zstd_batches_on_device"] == 3
-        assert [canon_python(c) for c in got] == pyarrow_columns(t)
-        print("ok")
-    """) % (root, root, str(tmp_path / "w.arrows"))
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, MI_ZSTD_WINDOWED="1"), timeout=300)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
