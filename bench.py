@@ -186,6 +186,7 @@ def main():
     ap.add_argument("--no-validity", action="store_true", help="pyarrow-style stream without validity bitmaps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-operator-path", action="store_true", help="skip the /dev/shm operator-path legs")
+    ap.add_argument("--no-numa-bind", action="store_true", help="leave this process's threads where the scheduler puts them (default: the GPU's NUMA node)")
     ap.add_argument("--no-encode-leg", action="store_true", help="skip the K7 encode kernels over the decoded vectors (config 4)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (decode; the encode leg gets half)")
     ap.add_argument("--prewarm-seconds", type=float, default=1.5, help="untimed clock ramp before the warmup steps")
@@ -252,6 +253,10 @@ def main():
     t_gen = time.time() - t0
 
     ctx = da.Context(local_rank)
+    # the host side of this rank on its GPU's NUMA node (a deployment pins a worker the same way): the page cache of the files
+    # the operator-path legs write, the consumer thread, the CPU baselines' threads; the library's own threads go there by
+    # themselves (MI_NUMA_BIND).  Reported in the line.
+    numa_node = -1 if args.no_numa_bind else ctx.bind_this_thread()
     t0 = time.time()
     hs = HbmStream(ctx, buf, device="cuda:%d" % local_rank)   # mi_hbm_open: parse + upload + layout + plan, all in the library
     torch.cuda.synchronize()
@@ -559,6 +564,7 @@ def main():
             "vs_baseline": None,
             "dtype": "u8/int32/int64 (byte and integer transcode, no FP)",
             "data": "synthetic",
+            "host_threads_on_gpu_numa_node": numa_node,   # -1: not bound (--no-numa-bind, or the platform names no node)
             "config": {"workload": "TPC-H SF%g lineitem.arrows full-column scan per GPU (%d rows, %d record batches of 122880, "
                                    "16 columns, validity bitmaps %s), IPC bodies resident in HBM, every vector materialised"
                                    % (args.sf, info["n_rows"], info["n_batches"], "absent" if args.no_validity else "present"),

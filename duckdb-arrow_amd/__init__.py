@@ -173,6 +173,30 @@ class Context:
 
     __del__ = close
 
+    def numa(self):
+        """(NUMA node of the GPU or -1, the node's CPUs as a set) -- mi_ctx_numa."""
+        node = C.c_int32(-1)
+        buf = C.create_string_buffer(4096)
+        _ffi.check(_ffi.lib().mi_ctx_numa(self._h, C.byref(node), buf, len(buf)))
+        cpus = set()
+        for part in buf.value.decode().split(","):
+            if part:
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+        return node.value, cpus
+
+    def bind_this_thread(self):
+        """Pins the CALLING thread (threads it starts afterwards inherit) to the CPUs of the GPU's NUMA node, within what it may
+        use: for the threads of a host program that write the files a scan reads or consume its chunks.  Returns the node, or
+        -1 when nothing was bound."""
+        import os
+        node, cpus = self.numa()
+        allowed = os.sched_getaffinity(0)
+        if node < 0 or not (cpus & allowed):
+            return -1
+        os.sched_setaffinity(0, cpus & allowed)
+        return node
+
 
 def make_task(kind, nrows, buf1, out_data, *, validity=0, buf2=0, out_validity=0, out_aux=0, ptr_base=0, row_offset=0,
               buf2_len=0, param=0, param2=0, null_count=-1, depth=0, parent_div=0, sel=0, sel_count=0):

@@ -190,6 +190,7 @@ SIGNATURES = {
     "mi_reader_index": (C.c_int, [P, C.POINTER(C.POINTER(BatchIndexEntry)), C.POINTER(C.c_int32)]),
     "mi_ctx_create": (C.c_int, [C.c_int32, PP]),
     "mi_ctx_destroy": (None, [P]),
+    "mi_ctx_numa": (C.c_int, [P, C.POINTER(C.c_int32), C.c_char_p, C.c_int32]),
     "mi_device_count": (C.c_int, []),
     "mi_plan_create": (C.c_int, [P, C.POINTER(ColTask), C.c_int32, PP]),
     "mi_plan_destroy": (None, [P]),

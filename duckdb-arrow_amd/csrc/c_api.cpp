@@ -234,6 +234,19 @@ int mi_ctx_create(int32_t device_id, mi_ctx** out) {
 
 void mi_ctx_destroy(mi_ctx* ctx) { delete ctx; }
 
+int mi_ctx_numa(mi_ctx* ctx, int32_t* node, char* cpulist, int32_t cap) {
+  return Wrap([&] {
+    if (!ctx || !node) throw InvalidInputException("mi_ctx_numa: NULL argument");
+    *node = ctx->ctx->numa_node;
+    if (cpulist && cap > 0) {
+      const std::string& l = ctx->ctx->local_cpulist;
+      const size_t n = std::min(l.size(), static_cast<size_t>(cap - 1));
+      std::memcpy(cpulist, l.data(), n);
+      cpulist[n] = 0;
+    }
+  });
+}
+
 int mi_plan_create(mi_ctx* ctx, const mi_col_task* tasks, int32_t n_tasks, mi_plan** out) {
   return Wrap([&] {
     if (!ctx || !out || n_tasks < 0 || (!tasks && n_tasks)) throw InvalidInputException("mi_plan_create: bad argument");

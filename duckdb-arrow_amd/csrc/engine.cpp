@@ -1,10 +1,18 @@
 // engine.cpp -- device context + transcode plans.  See engine.hpp.
 #include "engine.hpp"
 
+#include "ipc_stream_reader.hpp"
+
 #include <hip/hip_runtime.h>
 
+#include <sched.h>
+
 #include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <fstream>
 
 namespace miarrow {
 
@@ -27,6 +35,51 @@ Context::Context(int device_id) : device(device_id) {
   MI_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   MI_HIP_CHECK(hipStreamCreateWithFlags(&h2d_stream, hipStreamNonBlocking));
   MI_HIP_CHECK(hipStreamCreateWithFlags(&d2h_stream, hipStreamNonBlocking));
+  // the device's place in the host (best effort: any failure leaves numa_node = -1 and nothing is bound)
+  const char* nb = std::getenv("MI_NUMA_BIND");
+  char bus[64] = {0};
+  if (!(nb && nb[0] == '0') && hipDeviceGetPCIBusId(bus, sizeof(bus) - 1, device) == hipSuccess) {
+    for (char* q = bus; *q; q++) *q = static_cast<char>(std::tolower(static_cast<unsigned char>(*q)));
+    const std::string dir = std::string("/sys/bus/pci/devices/") + bus + "/";
+    std::ifstream fn(dir + "numa_node"), fc(dir + "local_cpulist");
+    int node = -1;
+    std::string list;
+    if (fn >> node && node >= 0 && std::getline(fc, list) && !list.empty()) {
+      // "0-63,128-191"
+      std::vector<int> cpus;
+      size_t at = 0;
+      bool ok = true;
+      while (at < list.size() && ok) {
+        size_t end = list.find(',', at);
+        if (end == std::string::npos) end = list.size();
+        const std::string part = list.substr(at, end - at);
+        int lo = 0, hi = 0;
+        const int got = std::sscanf(part.c_str(), "%d-%d", &lo, &hi);
+        if (got == 1) hi = lo;
+        ok = got >= 1 && lo >= 0 && hi >= lo && hi < CPU_SETSIZE;
+        for (int c = lo; ok && c <= hi; c++) cpus.push_back(c);
+        at = end + 1;
+      }
+      if (ok && !cpus.empty()) {
+        numa_node = node;
+        local_cpus = std::move(cpus);
+        local_cpulist = list;
+      }
+    }
+  }
+  (void)hipGetLastError();
+}
+
+void Context::BindThisThread() const { BindThisThreadToNode(numa_node, local_cpus); }
+
+Context::PreferNode::PreferNode(const Context* c) {
+  if (c && c->numa_node >= 0) {
+    miarrow::PreferNode(c->numa_node);
+    on = true;
+  }
+}
+Context::PreferNode::~PreferNode() {
+  if (on) miarrow::PreferNode(-1);
 }
 
 Context::~Context() {

@@ -28,6 +28,23 @@ struct Context {
   hipStream_t h2d_stream = nullptr;   // pinned host -> HBM
   hipStream_t d2h_stream = nullptr;   // HBM -> pinned host
 
+  // Where the device hangs in the host: its NUMA node and that node's CPUs (/sys/bus/pci/devices/<bus id>/numa_node and
+  // local_cpulist; -1 / empty when the platform does not say).  The library's OWN host threads -- read-ahead producers, the
+  // I/O pool while it works for this context -- run there and allocate their pinned buffers there (BindThisThread): a pread
+  // into pinned memory followed by a DMA to the device crosses the socket interconnect twice when it happens on the other
+  // socket (two-socket boxes: 199 against 300 M rows/s for the same host-consumer scan, by where the threads happened to
+  // run).  The caller's threads are never touched.  MI_NUMA_BIND=0 turns it off.
+  int numa_node = -1;
+  std::vector<int> local_cpus;
+  std::string local_cpulist;            // as the kernel prints it ("0-63,128-191")
+  void BindThisThread() const;          // affinity = local_cpus (within what the thread may use), allocations prefer numa_node
+  // RAII: allocations of the calling thread prefer the device's node inside the scope (pinned buffers the caller's thread makes)
+  struct PreferNode {
+    explicit PreferNode(const Context* c);
+    ~PreferNode();
+    bool on = false;
+  };
+
   explicit Context(int device_id);
   ~Context();
   void Bind() const;  // hipSetDevice

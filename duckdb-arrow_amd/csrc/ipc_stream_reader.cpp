@@ -3,13 +3,17 @@
 
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/stat.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 
 #include <algorithm>
 #include <condition_variable>
 #include <deque>
 #include <exception>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <cctype>
@@ -202,6 +206,54 @@ bool IPCStreamReader::GetNextBatch(DecodedBatch* out, bool accept_dictionaries, 
 // default 8, grown by multi-device scans to 8 per device) and serves any number of callers at once: a Run() is a batch of
 // tasks in one shared queue, the caller works on its own batch while it waits.
 namespace {
+struct IoAffinity {
+  cpu_set_t cpus;
+  int node = -1;
+};
+thread_local const IoAffinity* tls_io_affinity = nullptr;   // what this thread is bound to; its pool jobs ask the same of the workers
+constexpr int kMpolDefault = 0, kMpolPreferred = 1;          // <linux/mempolicy.h>
+void SetPreferredNode(int node) {
+  if (node < 0) {
+    (void)syscall(SYS_set_mempolicy, kMpolDefault, nullptr, 0);
+    return;
+  }
+  unsigned long mask[16] = {0};
+  if (node >= static_cast<int>(sizeof(mask) * 8)) return;
+  mask[static_cast<size_t>(node) / (8 * sizeof(unsigned long))] |= 1ul << (static_cast<size_t>(node) % (8 * sizeof(unsigned long)));
+  (void)syscall(SYS_set_mempolicy, kMpolPreferred, mask, sizeof(mask) * 8);
+}
+void ApplyIoAffinity(const IoAffinity* a) {
+  cpu_set_t allowed, want;
+  CPU_ZERO(&allowed);
+  CPU_ZERO(&want);
+  // a thread that was narrowed to another node before may widen again: ask for the process's CPUs first
+  if (sched_getaffinity(getpid(), sizeof(allowed), &allowed) != 0) return;
+  int n = 0;
+  for (int c = 0; c < CPU_SETSIZE; c++)
+    if (CPU_ISSET(c, &a->cpus) && CPU_ISSET(c, &allowed)) {
+      CPU_SET(c, &want);
+      n++;
+    }
+  if (n == 0) return;   // the process may not run on that node at all: stay
+  (void)sched_setaffinity(0, sizeof(want), &want);
+  SetPreferredNode(a->node);
+  tls_io_affinity = a;
+}
+const IoAffinity* IoAffinityOf(int node, const std::vector<int>& cpus) {
+  static std::mutex mu;
+  static std::map<int, std::unique_ptr<IoAffinity>> by_node;   // a node's CPUs do not change: one object per node, never freed
+  std::lock_guard<std::mutex> lk(mu);
+  auto& slot = by_node[node];
+  if (!slot) {
+    slot = std::make_unique<IoAffinity>();
+    CPU_ZERO(&slot->cpus);
+    for (int c : cpus)
+      if (c >= 0 && c < CPU_SETSIZE) CPU_SET(c, &slot->cpus);
+    slot->node = node;
+  }
+  return slot.get();
+}
+
 class IoPool {
  public:
   static IoPool& Get() {
@@ -231,6 +283,7 @@ class IoPool {
     job.fn = &fn;
     job.n = n;
     job.pending = n;
+    job.affinity = tls_io_affinity;   // the caller's binding, if it has one
     {
       std::lock_guard<std::mutex> lk(mu);
       jobs.push_back(&job);
@@ -245,6 +298,7 @@ class IoPool {
  private:
   struct Job {
     const std::function<void(int)>* fn = nullptr;
+    const IoAffinity* affinity = nullptr;
     int n = 0, next = 0, pending = 0;
     std::exception_ptr error;
     std::condition_variable done_cv;
@@ -283,6 +337,7 @@ class IoPool {
         i = job->next++;
         if (job->next >= job->n) jobs.erase(std::find(jobs.begin(), jobs.end(), job));  // nothing left to hand out
       }
+      if (job->affinity && job->affinity != tls_io_affinity) ApplyIoAffinity(job->affinity);   // ~2 us, once per change of caller
       std::exception_ptr err;
       try {
         (*job->fn)(i);
@@ -314,6 +369,12 @@ class IoPool {
 }  // namespace
 
 void EnsureIoThreads(int n) { IoPool::Get().Ensure(n); }
+
+void BindThisThreadToNode(int node, const std::vector<int>& cpus) {
+  if (node < 0 || cpus.empty()) return;
+  ApplyIoAffinity(IoAffinityOf(node, cpus));
+}
+void PreferNode(int node) { SetPreferredNode(node); }
 
 // ------------------------------------------------------------------------------------------------ compression
 // Body compression (Message.fbs BodyCompression, method BUFFER): every buffer is `int64 uncompressed_length` (-1 = the

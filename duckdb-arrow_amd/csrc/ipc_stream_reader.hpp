@@ -26,6 +26,12 @@ void ParallelFor(int n, const std::function<void(int)>& fn);
 int IoThreads();
 //! Grows the pool to at least n threads (bounded by the host's cores); multi-device scans ask for 8 per device
 void EnsureIoThreads(int n);
+// NUMA locality of the host side (engine.hpp, Context::BindThisThread).  BindThisThreadToNode pins the calling thread to
+// `cpus` (within what it may use) and makes its allocations prefer `node`; from then on the tasks it gives the I/O pool
+// (parallel preads of a body, host decompression) run under the same binding: a pool worker adopts the binding of the batch
+// of tasks it takes.  PreferNode(node) / PreferNode(-1): only the allocation policy of the calling thread.
+void BindThisThreadToNode(int node, const std::vector<int>& cpus);
+void PreferNode(int node);
 
 
 

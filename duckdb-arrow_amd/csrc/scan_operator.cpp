@@ -407,6 +407,7 @@ void ArrowScan::EnsureHostOut(Slot& s, size_t bytes) {
   ctx->Bind();
   if (s.h_out) RetireHost(s.h_out);
   s.h_out = nullptr;
+  Context::PreferNode near_the_gpu(ctx);   // (the caller's thread allocates: only its policy, for the length of this call)
   s.h_out_cap = RoundUp(GrowCap(bytes, s.h_out_cap), 1 << 16);
   MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.h_out), s.h_out_cap, hipHostMallocDefault));
 }
@@ -1348,6 +1349,7 @@ void ArrowScan::ProducerLoop(int p) {
   };
   try {
     ctx->Bind();
+    ctx->BindThisThread();   // the GPU's NUMA node: this thread's preads (and the I/O pool's, for it) and its pinned staging buffers
     size_t si = 0;
     int64_t ordinal = 0, share = 0;   // record batches of the file list; of those, this scan's (rank / world)
     while (si < sources.size()) {

@@ -267,6 +267,13 @@ typedef struct mi_plan mi_plan;
 int mi_ctx_create(int32_t device_id, mi_ctx** out);
 void mi_ctx_destroy(mi_ctx* ctx);
 int mi_device_count(void);
+/* Where the context's GPU hangs in the host: its NUMA node (-1 = the platform does not say) and that node's CPUs as the
+ * kernel prints them ("0-63,128-191", NUL-terminated, truncated to cap).  The library's own host threads (read-ahead,
+ * I/O pool) run there and allocate their pinned buffers there by themselves (MI_NUMA_BIND=0 turns that off); a host
+ * process that wants its own threads and page cache on the same node (the threads that write the files a scan will read,
+ * the consumer of the chunks) binds them with this.  DuckDB has no such seam: the reference reads through DuckDB's
+ * FileSystem on whatever thread the scheduler picks (src/file_scanner/arrow_multi_file_info.cpp:77-86). */
+int mi_ctx_numa(mi_ctx* ctx, int32_t* node, char* cpulist, int32_t cap);
 
 /* One column of one record batch.  All pointers are DEVICE addresses (HBM).  Arrow buffers must be 8-byte
  * aligned and padded to a multiple of 8 bytes, as the IPC format guarantees for message bodies. */

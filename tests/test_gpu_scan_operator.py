@@ -619,3 +619,27 @@ def test_device_resident_chunks_of_every_shape(con, golden_dir, rel_path, zero_c
             hv = _mirror_device_vector(hip, ch.columns[ci], ty, ch.size, keep)
             got[ci].extend(da._vector_values(hv, ty, ch.size))
     assert [canon_python(c) for c in got] == [canon_python(c) for c in want]
+
+
+def test_context_reports_the_gpus_numa_node(con):
+    """mi_ctx_numa: the node of the GPU and its CPUs as /sys names them (-1 and nothing on a platform that does not say); the
+    library's own host threads run there (Context::BindThisThread), the caller's thread only when it asks."""
+    import os
+    node, cpus = con.ctx.numa()
+    assert node >= -1
+    if node < 0:
+        assert not cpus
+        return
+    assert cpus and all(0 <= c < 4096 for c in cpus)
+    with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+        want = set()
+        for part in f.read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            want.update(range(int(lo), int(hi or lo) + 1))
+    assert cpus == want
+    before = os.sched_getaffinity(0)
+    try:
+        assert con.ctx.bind_this_thread() == (node if cpus & before else -1)
+        assert os.sched_getaffinity(0) == ((cpus & before) or before)
+    finally:
+        os.sched_setaffinity(0, before)

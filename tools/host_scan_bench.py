@@ -12,15 +12,21 @@ def main():
     ap.add_argument("--dir", default="/dev/shm")
     ap.add_argument("--files", type=int, default=8)
     ap.add_argument("--depth", default="3,6")
+    ap.add_argument("--no-bind", action="store_true", help="leave this process's own threads (the file writer, the consumer) where the scheduler puts them")
     args = ap.parse_args()
     import duckdb_arrow_amd as da
+    con = da.Connection(0)
+    # the host program on the GPU's NUMA node: the page cache of the files it writes, the thread that takes the chunks (the
+    # library's own threads go there by themselves unless MI_NUMA_BIND=0)
+    node = -1 if args.no_bind else con.ctx.bind_this_thread()
     buf, info = da.synth_lineitem_stream(scale_factor=args.sf, seed=42)
     d = os.path.join(args.dir, "mi_hostscan_%d" % os.getpid())
     os.makedirs(d, exist_ok=True)
     paths = [os.path.join(d, "lineitem_%d.arrows" % i) for i in range(args.files)]
     offs, nb = info["batch_offsets"], info["n_batches"]
     per = (nb + args.files - 1) // args.files
-    out = {"rows": info["n_rows"], "MI_IO_THREADS": os.environ.get("MI_IO_THREADS", "default")}
+    out = {"rows": info["n_rows"], "MI_IO_THREADS": os.environ.get("MI_IO_THREADS", "default"), "gpu_numa_node": con.ctx.numa()[0],
+           "process_bound_to_node": node, "MI_NUMA_BIND": os.environ.get("MI_NUMA_BIND", "default (on)")}
     try:
         for i, p in enumerate(paths):
             lo, hi = offs[min(nb, i * per)], offs[min(nb, (i + 1) * per)]
@@ -29,7 +35,6 @@ def main():
                 f.write(memoryview(buf[lo:hi]))
                 f.write(b"\xff\xff\xff\xff\x00\x00\x00\x00")
         del buf
-        con = da.Connection(0)
         for depth in [int(x) for x in args.depth.split(",")]:
             for tag, kw in (("materialise_all", {"zero_copy_direct": False}), ("default_alias_plain_columns", {})):
                 best, st = None, None
