@@ -186,6 +186,7 @@ bool IPCStreamReader::GetNextBatch(DecodedBatch* out, bool accept_dictionaries, 
     *out = DecodedBatch();
     out->length = meta.length;
     out->body_file_offset = cur_body_offset;
+    out->compression = meta.compression;
     return true;
   }
   cur_deferred.reset();

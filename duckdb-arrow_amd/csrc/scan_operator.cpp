@@ -1335,7 +1335,8 @@ std::shared_ptr<void> ArrowScan::LeaseStaging(size_t bytes, uint8_t** ptr) {
 }
 
 void ArrowScan::ProducerLoop(int p) {
-  const size_t cap = n_producers > 1 ? 2 : static_cast<size_t>(kReadAhead);
+  size_t cap = n_producers > 1 ? 2 : static_cast<size_t>(kReadAhead);
+  if (const char* v = std::getenv("MI_SCAN_READAHEAD")) cap = static_cast<size_t>(std::max(1, std::min(4, std::atoi(v))));   // fetched batches a producer holds (A/B)
   auto push = [&](Fetched&& f) {
     std::unique_lock<std::mutex> lk(q_mu);
     const int64_t t0 = trace ? TraceNow() : 0;
@@ -1432,10 +1433,26 @@ void ArrowScan::StartProducer() {
   trace = std::getenv("MI_SCAN_TRACE") != nullptr;
   // several producers only where record batches are independent of what came before them in the stream (no dictionary
   // batches, which every later batch of the file depends on) and where there is a pread to overlap (files, not caller buffers)
+  // How many: ONE when the bodies only have to be read (plain bodies, and compressed ones that are expanded in HBM) -- its preads
+  // already run on the whole I/O pool, and with a CPU quota of 16 more threads only throttle one another (SF10 host consumer:
+  // 0.18 s with one producer, 0.20 with three) -- THREE when the reader's host threads decompress them (a producer then spends
+  // most of its time waiting for its own body's decompression: LZ4 0.29 against 0.60 s, ZSTD 0.61 against 1.27 s).  Which it
+  // is shows in the first record batch's header.
   n_producers = 1;
   if (!is_buffers && !opts.accept_dictionaries) {
+    int wanted = 1;
+    try {
+      IPCFileStreamReader peek(sources[0].path);
+      peek.GetBaseSchema();
+      DecodedBatch first;
+      if (peek.GetNextBatch(&first, /*accept_dictionaries*/ false, /*skip_body*/ true) && first.compression >= 0) {
+        const bool in_hbm = first.compression == 1 ? DeferZstd(opts) : (opts.host_decompress < 0 || (opts.host_decompress == 0 && opts.device_resident != 0));
+        if (!in_hbm) wanted = 3;
+      }
+    } catch (...) {   // whatever is wrong with the file, the scan itself will say
+    }
     const char* v = std::getenv("MI_SCAN_PRODUCERS");
-    n_producers = std::max(1, std::min(kMaxProducers, v ? std::atoi(v) : 3));
+    n_producers = std::max(1, std::min(kMaxProducers, v ? std::atoi(v) : wanted));
   }
   fetched.assign(static_cast<size_t>(n_producers), {});
   extra_readers.resize(static_cast<size_t>(n_producers - 1));

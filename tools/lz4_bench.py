@@ -21,7 +21,7 @@ def main():
     plain = os.path.join(args.dir, "mi_lz4_plain_sf%g.arrows" % args.sf)
     packed = os.path.join(args.dir, "mi_lz4_packed_sf%g.arrows" % args.sf)
     out = {"rows": info["n_rows"], "plain_bytes": int(buf.size), "codec": args.codec, "pipeline_depth": args.depth,
-           "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "unset: the library asks for 24 at load time"), "MI_IO_THREADS": os.environ.get("MI_IO_THREADS", "unset (16)")}
+           "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "unset: the library asks for 24 at load time"), "MI_IO_THREADS": os.environ.get("MI_IO_THREADS", "unset (8)")}
     try:
         buf.tofile(plain)
         t0 = time.perf_counter()
