@@ -72,7 +72,7 @@ namespace {
 constexpr uint32_t kLinkKnown = 0x80000000u;
 constexpr uint32_t kSkelCount = 36;            // round_left[36]: entries of the skeleton list
 constexpr int kSkelHops = 24;                  // links followed per skeleton round (a lane stops at the first known word): 3 rounds for a 3 MB buffer, 5 with 4 hops
-constexpr uint32_t kLocalTileQuads = 2048;     // lz4_resolve_local: 8 KiB of output = 32 KiB of LDS per workgroup
+constexpr uint32_t kLocalTileQuads = 2048;     // lz4_collect: 8 KiB of output per workgroup
 
 __device__ __forceinline__ void lz4_fail(uint32_t* status) { atomicOr(status, MI_ST_DECOMPRESS); }
 
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(kParseLanes) void lz4_parse(Lz4Args a) {
     atomicAdd(&a.round_left[39], rounds);
     atomicAdd(&a.round_left[37], 1u);
   }
-  // where each lane's sequences and output bytes begin inside the block: lz4_expand reads the lanes' slices as they are
+  // where each lane's sequences and output bytes begin inside the block: k8_expand_local reads the lanes' slices as they are
   uint32_t seq_before = w.nseq, out_before = w.olen;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {

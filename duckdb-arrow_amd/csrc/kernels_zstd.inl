@@ -6,14 +6,14 @@
 // whose bytes describe them, so no block waits for another:
 //   zstd_entropy   one workgroup of two waves per block.  Wave 0 builds the Huffman table and decodes the 4 literal streams on
 //                  4 lanes into the literal scratch (behind the compressed body, same allocation); wave 1 builds the three FSE
-//                  tables on 3 lanes and decodes the sequences on one: the descriptors {output position, literal source,
-//                  literal length, match length} + offset that lz4_expand reads, in 256 equal slices per block.
+//                  tables and decodes the sequences, the three FSE states on three lanes: the descriptors {output position, literal source,
+//                  literal length, match length} + offset that k8_expand_local reads, in 256 equal slices per block.
 //                  Repeat offsets -- the one state that runs from block to block -- are kept symbolic (zstd_format.hpp, RepStep):
 //                  a slice records its effect on the history as a function of the history it started from.
 //   zstd_layout    one wave per buffer, its blocks in order: first output byte of every block, the size check of the reference
 //                  (base_stream_reader.cpp:24-29), and a prefix scan over the 256 slice functions of each block that gives every
-//                  slice the history it really starts from; lz4_expand resolves a symbolic offset with it in one step.
-// From there on a ZSTD batch is an LZ4 batch: lz4_expand writes the link words, the resolve kernels follow them, lz4_emit
+//                  slice the history it really starts from; k8_expand_local resolves a symbolic offset with it in one step.
+// From there on a ZSTD batch is an LZ4 batch: k8_expand_local writes the link words, the skeleton kernels follow them, k8_emit
 // writes the bytes.  The serial chains (one table lookup in LDS per symbol) are latency-bound and leave the chip almost idle:
 // the scan runs the batches of several slots side by side.
 
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a, uint32_t
   gptr<uint32_t> lane_out = GM<uint32_t>(a.lane_out) + static_cast<size_t>(bi) * kParseLanes;
   gptr<uint32_t> lane_nseq = GM<uint32_t>(a.lane_nseq) + static_cast<size_t>(bi) * kParseLanes;
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-  if (z.type == 0) {   // raw: lz4_expand copies it (Lz4BlockDev::stored)
+  if (z.type == 0) {   // raw: k8_expand_local copies it (Lz4BlockDev::stored)
     if (tid == 0) {
       a.block_out_size[bi] = z.comp_size;
       a.block_nseq[bi] = 0;
