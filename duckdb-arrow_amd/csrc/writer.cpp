@@ -48,7 +48,9 @@ size_t RoundUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
 template <typename T>
 void GrowPinned(T** p, size_t* cap_bytes, size_t need_bytes, size_t keep_bytes) {
   if (need_bytes <= *cap_bytes && *p) return;
-  size_t ncap = RoundUp(std::max(need_bytes, *cap_bytes + *cap_bytes / 2), 1 << 16);
+  // a quarter of headroom: row groups of one table differ by a few percent, and growing means hipHostFree / hipFree, which
+  // wait for the device to go idle -- with the other sink threads' row groups in flight a stall of milliseconds
+  size_t ncap = RoundUp(std::max(need_bytes + need_bytes / 4, *cap_bytes + *cap_bytes / 2), 1 << 16);
   void* np = nullptr;
   MI_HIP_CHECK(hipHostMalloc(&np, ncap, hipHostMallocDefault));
   if (*p) {
@@ -63,7 +65,7 @@ void GrowDevice(uint8_t** p, size_t* cap, size_t need) {
   if (need <= *cap && *p) return;
   if (*p) MI_HIP_CHECK(hipFree(*p));
   *p = nullptr;
-  *cap = RoundUp(std::max(need, *cap + *cap / 2), 1 << 16);
+  *cap = RoundUp(std::max(need + need / 4, *cap + *cap / 2), 1 << 16);
   MI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(p), *cap));
 }
 
