@@ -636,7 +636,7 @@ def test_context_reports_the_gpus_numa_node(con):
         for part in f.read().strip().split(","):
             lo, _, hi = part.partition("-")
             want.update(range(int(lo), int(hi or lo) + 1))
-    assert cpus == want
+    assert cpus <= want      # the device's local CPUs are CPUs of that node
     before = os.sched_getaffinity(0)
     try:
         assert con.ctx.bind_this_thread() == (node if cpus & before else -1)
