@@ -23,12 +23,6 @@ constexpr int kZstdSeqWindowWords = 256;         // the sequences' bitstream: 1 
 template <typename T>
 using ldsptr = T __attribute__((address_space(3)))*;
 
-// old, with the (wave-uniform) value written into lane LANE: v_writelane_b32
-template <int LANE>
-__device__ __forceinline__ int32_t write_lane(int32_t uniform_value, int32_t old) {
-  asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(uniform_value), "n"(LANE));
-  return old;
-}
 
 // The streams are decoded POSITIONALLY: the head of a backward bitstream is a bit position, a field an indexed read from a
 // 0.5 - 1 KiB window of the stream in LDS -- not a turn of a shifting bit buffer with its counters and refill tests (the first
@@ -398,9 +392,9 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a, uint32_t
       if (((q - kGroupBits) >> 5) < wlo) refill((q >> 5) + 1);   // uniform
       if (lane < 3) {
         // One step of the three lanes.  Everything the lanes share is scalar: the six field positions are computed on the scalar
-        // unit and dealt to the lanes with v_writelane (a lane-dependent select costs the vector unit three instructions, and
-        // the vector unit -- one instruction of a 64-wide wave per four cycles, three lanes of it in use -- is what saturates
-        // when every CU holds eight blocks); LAST: the block's last sequence reads no state bits.
+        // unit and a lane picks its two.  (Dealing them with v_writelane instead of selects took the step from 36 to 25 vector
+        // instructions and changed neither the kernel's time nor the scan's: the chain is latency, not issue.)  LAST: the
+        // block's last sequence reads no state bits.
         const uint32_t win_bias = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(win)) - 4u * static_cast<uint32_t>(wlo);   // byte address of word 0, were it in the window
         auto word_pair = [&](int32_t at, uint32_t* lo_w, uint32_t* hi_w) {
           const ldsptr<uint32_t> w = (ldsptr<uint32_t>)(static_cast<uintptr_t>(4u * static_cast<uint32_t>(at >> 5) + win_bias));
@@ -421,18 +415,12 @@ __global__ __launch_bounds__(kZstdThreads) void zstd_entropy(Lz4Args a, uint32_t
           const int32_t p_ll_b = LAST ? p_ll_e : p_ll_e - static_cast<int32_t>(k_ll & 0xFFu), p_ml_b = LAST ? p_ll_e : p_ll_b - static_cast<int32_t>(k_ml & 0xFFu),
                         p_of_b = LAST ? p_ll_e : p_ml_b - static_cast<int32_t>(k_of & 0xFFu);
           if (p_of_b < floor) return false;   // the stream ran out (uniform)
-          int32_t pe = p_ll_e;
-          pe = write_lane<0>(p_of_e, pe);
-          pe = write_lane<1>(p_ml_e, pe);
+          const int32_t pe = lane == 0 ? p_of_e : (lane == 1 ? p_ml_e : p_ll_e);
           uint32_t e_lo, e_hi;
           word_pair(pe, &e_lo, &e_hi);
           uint32_t b_lo = 0, b_hi = 0;
-          int32_t pb = p_ll_b;
-          if (!LAST) {
-            pb = write_lane<0>(p_of_b, pb);
-            pb = write_lane<1>(p_ml_b, pb);
-            word_pair(pb, &b_lo, &b_hi);
-          }
+          const int32_t pb = lane == 0 ? p_of_b : (lane == 1 ? p_ml_b : p_ll_b);
+          if (!LAST) word_pair(pb, &b_lo, &b_hi);
           const uint32_t value = zstd::CellBase(cell) + __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(e_hi, e_lo, static_cast<uint32_t>(pe)), 0u, pack >> 8);
           if (!LAST) state = zstd::CellNext(cell) + __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(b_hi, b_lo, static_cast<uint32_t>(pb)), 0u, pack & 0xFFu);
           s_trip[i][2u - lane] = value;
