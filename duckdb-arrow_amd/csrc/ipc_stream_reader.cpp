@@ -18,6 +18,7 @@
 #include <thread>
 #include <cctype>
 #include <cerrno>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <sstream>
@@ -265,10 +266,31 @@ class IoPool {
     std::lock_guard<std::mutex> lk(mu);
     return n_threads;
   }
+  // CPUs the process may really use: the hardware's, or the cgroup's CPU quota when there is one (a container sees all 256
+  // CPUs of the box and gets 16 CPUs' worth of time: threads beyond the quota only throttle one another -- with 12 and 16
+  // I/O threads the SF10 host-consumer scan took 0.204 s, with 8 0.18 s)
+  static int CpuBudget() {
+    int hw = std::max(1, static_cast<int>(std::thread::hardware_concurrency()));
+    long long quota = -1, period = 0;
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "<quota|max> <period>"
+      char q[32] = {0};
+      if (std::fscanf(f, "%31s %lld", q, &period) == 2 && std::strcmp(q, "max") != 0) quota = std::atoll(q);
+      std::fclose(f);
+    } else if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
+      if (std::fscanf(g, "%lld", &quota) != 1) quota = -1;
+      std::fclose(g);
+      if (FILE* h = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+        if (std::fscanf(h, "%lld", &period) != 1) period = 0;
+        std::fclose(h);
+      }
+    }
+    if (quota > 0 && period > 0) hw = std::min<long long>(hw, std::max<long long>(1, quota / period));
+    return hw;
+  }
   void Ensure(int n) {
     std::lock_guard<std::mutex> lk(mu);
-    const int cap = std::max(1, static_cast<int>(std::thread::hardware_concurrency()));
-    n = std::min(n, std::max(cap, 8));
+    const int cap = CpuBudget();
+    n = std::min(n, std::max(cap / 2, 8));   // half of the budget: the pipeline threads, the HIP runtime's and the caller's need the rest
     while (n_threads < n) {
       workers.emplace_back([this] { Loop(); });
       n_threads++;
