@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 
 #include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cctype>
@@ -73,13 +75,15 @@ Context::Context(int device_id) : device(device_id) {
 void Context::BindThisThread() const { BindThisThreadToNode(numa_node, local_cpus); }
 
 Context::PreferNode::PreferNode(const Context* c) {
-  if (c && c->numa_node >= 0) {
+  if (c && c->numa_node >= 0 && c->numa_node < static_cast<int>(sizeof(saved_mask) * 8)) {
+    // the calling thread is the host program's: remember its policy (most have none: MPOL_DEFAULT)
+    if (syscall(SYS_get_mempolicy, &saved_mode, saved_mask, sizeof(saved_mask) * 8, nullptr, 0) != 0) return;
     miarrow::PreferNode(c->numa_node);
     on = true;
   }
 }
 Context::PreferNode::~PreferNode() {
-  if (on) miarrow::PreferNode(-1);
+  if (on) (void)syscall(SYS_set_mempolicy, saved_mode, saved_mode == 0 ? nullptr : saved_mask, saved_mode == 0 ? 0 : sizeof(saved_mask) * 8);
 }
 
 Context::~Context() {

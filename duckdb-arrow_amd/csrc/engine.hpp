@@ -43,6 +43,8 @@ struct Context {
     explicit PreferNode(const Context* c);
     ~PreferNode();
     bool on = false;
+    int saved_mode = 0;                 // the caller's own policy, put back when the scope ends
+    unsigned long saved_mask[16] = {0};
   };
 
   explicit Context(int device_id);
